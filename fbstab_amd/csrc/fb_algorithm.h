@@ -1,0 +1,286 @@
+// The FBstab outer proximal-point loop and inner semismooth Newton loop,
+// executed by ONE workgroup for ONE QP, entirely on the device
+// (reference: fbstab/fbstab_algorithm-impl.h:113-224 `Solve` and :229-304
+// `SolveProximalSubproblem`; semantics and quirks per SURVEY.md appendix A/C).
+//
+// What is restructured relative to the reference (same mathematics, different
+// evaluation order, so results agree to rounding, not bitwise):
+//   * the natural residual (rz, rl) is evaluated from the problem data once
+//     per proximal iteration; inside the Newton loop it is carried forward
+//     with the exact affine update  r(x + t dx) = r(x) + t*W,
+//     W = (H dz + G'dl + A'dv, -G dz), which the problem policy produces
+//     together with the Newton step.  A line-search trial therefore costs one
+//     pass over the iterate vectors and no pass over the problem data
+//     (the reference re-evaluates 4 GEMVs per trial, full_residual.cc:49-74);
+//   * the trial point xp is never materialised (impl:283-297 only needs its
+//     merit);
+//   * the inner residual and the penalised natural residual share (rz, rl)
+//     (full_residual.cc:52-66 vs :79-91 differ only by the sigma terms).
+//
+// A Problem policy `P` (fb_mpc.h, fb_dense.h) owns the iterate vectors and
+// provides: forcing_norm, load_guess, residual, newton_step, feasibility,
+// bvec, and the write_* functions.  All threads of the workgroup call every
+// function; scalar results are workgroup-uniform.
+#pragma once
+
+#include "fb_common.h"
+
+namespace fbk {
+
+template <class P, class C>
+struct Solver {
+  P& p;
+  const C& c;
+  const fbstab_options_t& o;
+
+  FB_DEV Solver(P& p_, const C& c_, const fbstab_options_t& o_) : p(p_), c(c_), o(o_) {}
+
+  // sqrt(sum rz^2 + sum rl^2 + sum pnr(y,v)^2): norm of the penalised natural
+  // residual at the current x (full_residual.cc:99-109, :40-42).
+  FB_DEV double pnr_norm() const {
+    double s[1] = {0.0};
+    for (int i = c.tid; i < p.nz; i += C::nt) s[0] += p.rz[i] * p.rz[i];
+    for (int i = c.tid; i < p.nl; i += C::nt) s[0] += p.rl[i] * p.rl[i];
+    for (int i = c.tid; i < p.nv; i += C::nt) {
+      const double r = pnr(p.y[i], p.v[i], o.alpha);
+      s[0] += r * r;
+    }
+    c.sum(s);
+    return sqrt(s[0]);
+  }
+
+  // (Ei, Eo) at x + t*dx for the proximal subproblem centred at xbar
+  // (full_residual.cc:49-74 and :99-109).  t == 0 never touches dx/W.
+  FB_DEV void norms_at(double t, double sigma, bool want_outer, double* Ei, double* Eo) const {
+    double s[2] = {0.0, 0.0};
+    for (int i = c.tid; i < p.nz; i += C::nt) {
+      double r = p.rz[i], zi = p.z[i];
+      if (t != 0.0) {
+        r += t * p.wz[i];
+        zi += t * p.dz[i];
+      }
+      const double ri = r + sigma * (zi - p.zb[i]);
+      s[0] += ri * ri;
+      s[1] += r * r;
+    }
+    for (int i = c.tid; i < p.nl; i += C::nt) {
+      double r = p.rl[i], li = p.l[i];
+      if (t != 0.0) {
+        r += t * p.wl[i];
+        li += t * p.dl[i];
+      }
+      const double ri = r + sigma * (li - p.lb[i]);
+      s[0] += ri * ri;
+      s[1] += r * r;
+    }
+    for (int i = c.tid; i < p.nv; i += C::nt) {
+      double vi = p.v[i], yi = p.y[i];
+      if (t != 0.0) {
+        vi += t * p.dv[i];
+        yi -= t * p.adz[i];
+      }
+      const double ys = yi + sigma * (vi - p.vb[i]);
+      const double r = pfb(ys, vi, o.alpha);
+      s[0] += r * r;
+      if (want_outer) {
+        const double q = pnr(yi, vi, o.alpha);
+        s[1] += q * q;
+      }
+    }
+    c.sum(s);
+    *Ei = sqrt(s[0]);
+    *Eo = sqrt(s[1]);
+  }
+
+  // x <- x + t*dx and the matching residual update (impl:298,
+  // full_variable.cc:55-65: y += t*(dy - b) with dy = b - A dz).
+  FB_DEV void accept(double t) const {
+    for (int i = c.tid; i < p.nz; i += C::nt) {
+      p.z[i] += t * p.dz[i];
+      p.rz[i] += t * p.wz[i];
+    }
+    for (int i = c.tid; i < p.nl; i += C::nt) {
+      p.l[i] += t * p.dl[i];
+      p.rl[i] += t * p.wl[i];
+    }
+    for (int i = c.tid; i < p.nv; i += C::nt) {
+      p.v[i] += t * p.dv[i];
+      p.y[i] -= t * p.adz[i];
+    }
+    c.sync();
+  }
+
+  // SolveProximalSubproblem (impl:229-304).  Returns Eo; *fail is set when
+  // the linear solver could not factor (the reference throws, impl:263-274).
+  FB_DEV double subproblem(double tol, double sigma, double Ek, int* newton_iters,
+                           double* rk_last, bool* fail) const {
+    double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double Eo = 0.0;
+    for (int i = 0; i < o.max_inner_iters; i++) {
+      double Ei;
+      norms_at(0.0, sigma, true, &Ei, &Eo);
+      *rk_last = Eo;
+      if ((Ei <= tol && Eo < Ek) || (Ei <= o.inner_tol_min)) break;
+      if (*newton_iters >= o.max_newton_iters) break;
+      if (!p.newton_step(c, sigma, o.alpha)) {
+        *fail = true;
+        return Eo;
+      }
+      (*newton_iters)++;
+      const double cm = 0.5 * Ei * Ei;
+      merit[4] = merit[3];
+      merit[3] = merit[2];
+      merit[2] = merit[1];
+      merit[1] = merit[0];
+      merit[0] = cm;
+      double m0 = cm;
+      if (o.nonmonotone_linesearch) {
+        for (int k = 1; k < 5; k++) m0 = merit[k] > m0 ? merit[k] : m0;
+      }
+      double t = 1.0;
+      for (int j = 0; j < o.max_linesearch_iters; j++) {
+        double Et, unused;
+        norms_at(t, sigma, false, &Et, &unused);
+        const double mp = 0.5 * Et * Et;
+        if (mp <= m0 - 2.0 * t * o.eta * cm) break;
+        t *= o.beta;
+      }
+      accept(t);
+    }
+    // ProjectDuals (impl:301, full_variable.cc:75)
+    for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
+    c.sync();
+    return Eo;
+  }
+
+  // FBstabAlgorithm::Solve (impl:113-224).
+  FB_DEV void solve(fbstab_solver_out_t* out) const {
+    const double sigma = o.sigma0;
+    const double combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
+    p.load_guess(c);  // xk <- (z0,l0,v0), y = b - A z (impl:140, :334-347)
+    copy_x_to_xbar();
+    double dx_norm = sqrt((double)(p.nz + p.nl + p.nv));  // dx.Fill(1) (impl:142)
+    p.residual(c);
+    double Ek = pnr_norm();
+    const double E0 = Ek;
+    double rk_last = Ek;
+    int newton = 0, prox = 0;
+    int eflag = FBSTAB_MAXITERATIONS;
+    double inner_tol = 0.0;
+    if (o.inner_tol_min > o.inner_tol_max) {
+      eflag = FBSTAB_SATURATE_ERROR;  // tools::saturate would throw (impl:150-151)
+      p.write_x(c);
+      finish(out, eflag, rk_last, newton, prox, E0);
+      return;
+    }
+    inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
+
+    bool done = false;
+    for (int k = 0; k < o.max_prox_iters && !done; k++) {
+      rk_last = Ek;
+      if (Ek <= combo_tol || dx_norm <= o.stall_tol) {
+        eflag = FBSTAB_SUCCESS;
+        p.write_x(c);
+        done = true;
+        break;
+      }
+      if (o.inner_tol_min > Ek) {  // tools::saturate(lo > hi) throws (impl:179-180)
+        eflag = FBSTAB_SATURATE_ERROR;
+        p.write_x(c);
+        done = true;
+        break;
+      }
+      inner_tol = sat(inner_tol * o.delta, o.inner_tol_min, Ek);
+      bool fail = false;
+      const double Eo = subproblem(inner_tol, sigma, Ek, &newton, &rk_last, &fail);
+      if (fail) {
+        eflag = FBSTAB_DIVERGENCE;
+        p.write_x(c);
+        done = true;
+        break;
+      }
+      if (newton >= o.max_newton_iters) {  // impl:188-199
+        eflag = FBSTAB_MAXITERATIONS;
+        if (Eo < Ek) {
+          p.residual(c);
+          rk_last = pnr_norm();
+          p.write_x(c);
+        } else {
+          rk_last = Ek;
+          p.write_xbar(c);
+        }
+        done = true;
+        break;
+      }
+      // dx <- x(k+1) - x(k) (impl:202-203); its norm excludes y
+      // (full_variable.cc:77-83).
+      double s[1] = {0.0};
+      for (int i = c.tid; i < p.nz; i += C::nt) {
+        const double d = p.z[i] - p.zb[i];
+        p.dz[i] = d;
+        s[0] += d * d;
+      }
+      for (int i = c.tid; i < p.nl; i += C::nt) {
+        const double d = p.l[i] - p.lb[i];
+        p.dl[i] = d;
+        s[0] += d * d;
+      }
+      for (int i = c.tid; i < p.nv; i += C::nt) {
+        const double d = p.v[i] - p.vb[i];
+        p.dv[i] = d;
+        s[0] += d * d;
+      }
+      c.sum(s);
+      dx_norm = sqrt(s[0]);
+      c.sync();
+      if (o.check_feasibility) {
+        const int f = p.feasibility(c, o.infeas_tol);
+        if (f != kFeasible) {
+          eflag = f == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
+                  : f == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
+                                         : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
+          p.write_certificate(c);  // x <- dx (impl:205-210); residual stays stale
+          done = true;
+          break;
+        }
+      }
+      copy_x_to_xbar();
+      prox++;
+      // Residual at the projected x(k+1): serves the next loop-top test
+      // (impl:162-163) and the first inner iteration (impl:239-243).
+      p.residual(c);
+      Ek = pnr_norm();
+    }
+    if (!done) {
+      // Timeout exit (impl:219-223): residual is whatever rk last held.
+      eflag = FBSTAB_MAXITERATIONS;
+      p.write_x(c);
+    }
+    finish(out, eflag, rk_last, newton, prox, E0);
+  }
+
+ private:
+  FB_DEV void copy_x_to_xbar() const {
+    for (int i = c.tid; i < p.nz; i += C::nt) p.zb[i] = p.z[i];
+    for (int i = c.tid; i < p.nl; i += C::nt) p.lb[i] = p.l[i];
+    for (int i = c.tid; i < p.nv; i += C::nt) {
+      p.vb[i] = p.v[i];
+      p.yb[i] = p.y[i];
+    }
+    c.sync();
+  }
+  FB_DEV void finish(fbstab_solver_out_t* out, int eflag, double residual, int newton,
+                     int prox, double E0) const {
+    if (c.tid == 0) {
+      out->eflag = eflag;
+      out->pad_ = 0;
+      out->residual = residual;
+      out->newton_iters = newton;
+      out->prox_iters = prox;
+      out->solve_time = -1.0;  // filled by the host with the batch wall time
+      out->initial_residual = E0;
+    }
+  }
+};
+
+}  // namespace fbk

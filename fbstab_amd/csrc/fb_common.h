@@ -1,0 +1,135 @@
+// Shared device-side building blocks of the MI355X batched FBstab kernels:
+// the per-workgroup thread context (barrier + workgroup reductions), the
+// penalised Fischer-Burmeister function and its generalised gradient.
+//
+// The kernels are written against the small `Ctx` abstraction below instead of
+// raw threadIdx/__syncthreads so that the very same solver logic can also be
+// compiled as ordinary single-threaded C++ (FB_HOSTSIM) by tests/hostsim, which
+// lets the CPU test-suite exercise the kernel logic where no GPU exists.  That
+// build is a debugging aid owned by tests/; the product library contains the
+// gfx950 code only and has no CPU execution path.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/fbstab_types.h"
+
+#if defined(FB_HOSTSIM)
+#define FB_DEV inline
+#define FB_LDS
+#else
+#include <hip/hip_runtime.h>
+#define FB_DEV __device__ __forceinline__
+// Explicit LDS address space: every access through an lds_ptr is a ds_* op.
+#define FB_LDS __attribute__((address_space(3)))
+#endif
+
+namespace fbk {
+
+typedef FB_LDS double* lds_ptr;
+
+// Maximum number of values reduced together by one block_reduce call.
+constexpr int kMaxReduce = 12;
+
+struct OpSum {
+  static FB_DEV double apply(double a, double b) { return a + b; }
+};
+struct OpMax {
+  static FB_DEV double apply(double a, double b) { return a > b ? a : b; }
+};
+
+// Per-thread view of the workgroup.  NT threads cooperate on one QP.
+template <int NT>
+struct Ctx {
+  int tid;
+  lds_ptr red;  // LDS scratch, kMaxReduce * (NT/64) doubles (unused if NT<=64)
+
+  static constexpr int nt = NT;
+
+  FB_DEV void sync() const {
+#if !defined(FB_HOSTSIM)
+    __syncthreads();
+#endif
+  }
+
+  // In-place reduction of K values over the NT threads; every thread gets the
+  // result (bitwise identical in all threads, so branches on it are uniform).
+  template <class Op, int K>
+  FB_DEV void reduce(double (&v)[K]) const {
+#if !defined(FB_HOSTSIM)
+    static_assert(K <= kMaxReduce, "too many values");
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = Op::apply(v[k], __shfl_xor(v[k], m, 64));
+    }
+    if (NT > 64) {
+      const int wave = tid >> 6;
+      const int nw = NT / 64;
+      sync();  // previous users of `red` are done
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[k * nw + wave] = v[k];
+      }
+      sync();
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        double s = red[k * nw];
+        for (int w = 1; w < nw; w++) s = Op::apply(s, red[k * nw + w]);
+        v[k] = s;
+      }
+    }
+#else
+    (void)v;
+#endif
+  }
+  template <int K>
+  FB_DEV void sum(double (&v)[K]) const { reduce<OpSum, K>(v); }
+  template <int K>
+  FB_DEV void max(double (&v)[K]) const { reduce<OpMax, K>(v); }
+};
+
+FB_DEV double fmax0(double a) { return a > 0.0 ? a : 0.0; }
+
+// tools::saturate for lo <= hi (tools/utilities.h:19-28); callers test lo > hi first.
+FB_DEV double sat(double x, double lo, double hi) {
+  const double t = x < hi ? x : hi;
+  return t > lo ? t : lo;
+}
+
+// phi(a,b) = alpha (a + b - sqrt(a^2+b^2)) + (1-alpha) max(0,a) max(0,b)
+// (reference: full_residual.cc:115-118).
+FB_DEV double pfb(double a, double b, double alpha) {
+  const double fb = a + b - sqrt(a * a + b * b);
+  return alpha * fb + (1.0 - alpha) * fmax0(a) * fmax0(b);
+}
+
+// alpha*min(y,v) + (1-alpha) max(0,y) max(0,v): the v-block of the penalised
+// natural residual (reference: full_residual.cc:93-105).
+FB_DEV double pnr(double y, double v, double alpha) {
+  const double m = y < v ? y : v;
+  return alpha * m + (1.0 - alpha) * fmax0(y) * fmax0(v);
+}
+
+// Generalised gradient of phi (reference: riccati_linear_solver.cc:346-365 and
+// dense_cholesky_solver.cc:129-148, zero_tolerance_ = 1e-13).
+FB_DEV void pfb_gradient(double a, double b, double alpha, double* g0, double* g1) {
+  const double r = sqrt(a * a + b * b);
+  const double d = 0.70710678118654752440;  // 1/sqrt(2)
+  if (r < 1e-13) {
+    *g0 = alpha * (1.0 - d);
+    *g1 = alpha * (1.0 - d);
+  } else if (a > 0.0 && b > 0.0) {
+    *g0 = alpha * (1.0 - a / r) + (1.0 - alpha) * b;
+    *g1 = alpha * (1.0 - b / r) + (1.0 - alpha) * a;
+  } else {
+    *g0 = alpha * (1.0 - a / r);
+    *g1 = alpha * (1.0 - b / r);
+  }
+}
+
+// Result of the infeasibility test (reference: full_feasibility.h enum).
+enum Feasibility { kFeasible = 0, kPrimalInfeasible = 1, kDualInfeasible = 2, kBothInfeasible = 3 };
+
+}  // namespace fbk

@@ -1,0 +1,344 @@
+// Dense problem policy for the batched FBstab kernel: one workgroup owns one
+// dense QP  min 1/2 z'Hz + f'z  s.t. Gz = h, Az <= b  with H (nz x nz),
+// G (nl x nz), A (nv x nz) column-major (fbstab/fbstab_dense.h:55-64).
+//
+// Reference code answered to:
+//   * DenseData products and axpys            dense_data.cc:12-41
+//   * DenseCholeskySolver::Initialize/Solve   dense_cholesky_solver.cc:32-127
+//     (E = H + sigma I + A'Gamma A, K = [E .; G -sigma I], pivoted LDL' with
+//     symmetric pivoting on the largest |diagonal| as Eigen::LDLT does,
+//     pseudo-inverse of D in the solve)
+//   * FullFeasibility::CheckFeasibility       full_feasibility.cc:25-88
+//
+// K and every iterate vector live in LDS for the whole solve; H, G, A are read
+// from HBM/L2 where they are used.  The LDL' here is right-looking (rank-1
+// trailing updates spread over the workgroup) where Eigen's is left-looking;
+// pivot order is the same rule, summation order differs (rounding only).
+#pragma once
+
+#include <float.h>
+
+#include "fb_common.h"
+#include "fb_mpc.h"  // FB_LDS, lds_ptr
+
+namespace fbk {
+
+struct DenseData {
+  const double *H, *f, *G, *h, *A, *b;
+};
+
+struct DenseLayout {
+  int nz, nl, nv, nk;
+  // LDS carve (offsets in doubles)
+  int o_k, o_rhs, o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz,
+      o_rz, o_rl, o_wz, o_wl, o_gam, o_rvm, o_perm, o_red, lds_doubles;
+
+#if !defined(FB_HOSTSIM)
+  __host__ __device__
+#endif
+  void init(int nz_, int nl_, int nv_, int nthreads) {
+    nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
+    int s = 0;
+    o_k = s; s += nk * nk;
+    o_rhs = s; s += nk;
+    o_z = s; s += nz;  o_l = s; s += nl;  o_v = s; s += nv;  o_y = s; s += nv;
+    o_zb = s; s += nz; o_lb = s; s += nl; o_vb = s; s += nv; o_yb = s; s += nv;
+    o_dz = s; s += nz; o_dl = s; s += nl; o_dv = s; s += nv; o_adz = s; s += nv;
+    o_rz = s; s += nz; o_rl = s; s += nl; o_wz = s; s += nz; o_wl = s; s += nl;
+    o_gam = s; s += nv; o_rvm = s; s += nv;
+    o_perm = s; s += (nk + 1) / 2 + 1;  // nk ints
+    o_red = s; s += kMaxReduce * ((nthreads + 63) / 64);
+    lds_doubles = (s + 1) & ~1;
+  }
+};
+
+template <class C>
+struct DenseProblem {
+  DenseLayout lay;
+  DenseData D;
+  double *uz, *ul, *uv, *uy;
+  lds_ptr lds;
+  int nz, nl, nv;
+  lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
+  lds_ptr gam, rvm, K, rhs;
+  FB_LDS int* perm;
+
+  FB_DEV void bind(const DenseLayout& L_, const DenseData& D_, double* uz_, double* ul_,
+                   double* uv_, double* uy_, lds_ptr lds_) {
+    lay = L_; D = D_; uz = uz_; ul = ul_; uv = uv_; uy = uy_; lds = lds_;
+    nz = lay.nz; nl = lay.nl; nv = lay.nv;
+    K = lds + lay.o_k; rhs = lds + lay.o_rhs;
+    z = lds + lay.o_z; l = lds + lay.o_l; v = lds + lay.o_v; y = lds + lay.o_y;
+    zb = lds + lay.o_zb; lb = lds + lay.o_lb; vb = lds + lay.o_vb; yb = lds + lay.o_yb;
+    dz = lds + lay.o_dz; dl = lds + lay.o_dl; dv = lds + lay.o_dv; adz = lds + lay.o_adz;
+    rz = lds + lay.o_rz; rl = lds + lay.o_rl; wz = lds + lay.o_wz; wl = lds + lay.o_wl;
+    gam = lds + lay.o_gam; rvm = lds + lay.o_rvm;
+    perm = (FB_LDS int*)(lds + lay.o_perm);
+  }
+
+  // dot of column j of a column-major m-row matrix with an LDS vector
+  FB_DEV double col_dot(const double* M, int m, int j, lds_ptr x) const {
+    const double* col = M + (long)j * m;
+    double s = 0.0;
+    for (int k = 0; k < m; k++) s += col[k] * x[k];
+    return s;
+  }
+  // dot of row i of a column-major m x n matrix with an LDS vector
+  FB_DEV double row_dot(const double* M, int m, int n, int i, lds_ptr x) const {
+    double s = 0.0;
+    for (int k = 0; k < n; k++) s += M[i + (long)k * m] * x[k];
+    return s;
+  }
+
+  FB_DEV double forcing_norm(const C& c) const {  // dense_data.h:72-73
+    double s[1] = {0.0};
+    for (int i = c.tid; i < nz; i += C::nt) s[0] += D.f[i] * D.f[i];
+    for (int i = c.tid; i < nl; i += C::nt) s[0] += D.h[i] * D.h[i];
+    for (int i = c.tid; i < nv; i += C::nt) s[0] += D.b[i] * D.b[i];
+    c.sum(s);
+    return sqrt(s[0]);
+  }
+  FB_DEV double bvec(int i) const { return D.b[i]; }
+
+  FB_DEV void load_guess(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) z[i] = uz[i];
+    for (int i = c.tid; i < nl; i += C::nt) l[i] = ul[i];
+    for (int i = c.tid; i < nv; i += C::nt) v[i] = uv[i];
+    c.sync();
+    for (int i = c.tid; i < nv; i += C::nt) y[i] = D.b[i] - row_dot(D.A, nv, nz, i, z);
+    c.sync();
+  }
+
+  // rz = Hz + f + G'l + A'v ; rl = h - Gz (full_residual.cc:79-91)
+  FB_DEV void residual(const C& c) const {
+    for (int i = c.tid; i < nz + nl; i += C::nt) {
+      if (i < nz) {
+        rz[i] = D.f[i] + row_dot(D.H, nz, nz, i, z) + col_dot(D.G, nl, i, l) +
+                col_dot(D.A, nv, i, v);
+      } else {
+        const int j = i - nz;
+        rl[j] = D.h[j] - row_dot(D.G, nl, nz, j, z);
+      }
+    }
+    c.sync();
+  }
+
+  FB_DEV int feasibility(const C& c, double tol) const {  // full_feasibility.cc:25-88
+    double mx[5] = {-1e300, 0.0, 0.0, 0.0, 0.0};
+    double sm[2] = {0.0, 0.0};
+    double ul_[1] = {0.0};
+    for (int i = c.tid; i < nz + nl + nv; i += C::nt) {
+      if (i < nz) {
+        mx[2] = fmax(mx[2], fabs(row_dot(D.H, nz, nz, i, dz)));
+        mx[3] = fmax(mx[3], fabs(dz[i]));
+        mx[4] = fmax(mx[4], fabs(col_dot(D.A, nv, i, dv) + col_dot(D.G, nl, i, dl)));
+        sm[0] += D.f[i] * dz[i];
+      } else if (i < nz + nl) {
+        const int j = i - nz;
+        mx[1] = fmax(mx[1], fabs(row_dot(D.G, nl, nz, j, dz)));
+        ul_[0] = fmax(ul_[0], fabs(dl[j]));
+        sm[1] += D.h[j] * dl[j];
+      } else {
+        const int j = i - nz - nl;
+        mx[0] = fmax(mx[0], row_dot(D.A, nv, nz, j, dz));
+        ul_[0] = fmax(ul_[0], fabs(dv[j]));
+        sm[1] += D.b[j] * dv[j];
+      }
+    }
+    c.max(mx);
+    c.sum(sm);
+    c.max(ul_);
+    const double d1 = mx[0], d2 = mx[1], d3 = mx[2], w = mx[3], p1 = mx[4];
+    const double d4 = sm[0], p2 = sm[1], u = ul_[0];
+    bool dual_feasible = true, primal_feasible = true;
+    if ((d1 <= w * tol) && (d2 <= tol * w) && (d3 <= tol * w) && (d4 < 0) && (w > 1e-14))
+      dual_feasible = false;
+    if ((p1 <= tol * u) && (p2 < 0)) primal_feasible = false;
+    if (primal_feasible && dual_feasible) return kFeasible;
+    if (primal_feasible && !dual_feasible) return kDualInfeasible;
+    if (!primal_feasible && dual_feasible) return kPrimalInfeasible;
+    return kBothInfeasible;
+  }
+
+  // Pivoted LDL' of the lower triangle of K in place (Eigen::LDLT semantics).
+  FB_DEV bool ldlt(const C& c) const {
+    const int n = lay.nk;
+    bool found_zero_pivot = false;
+    for (int k = 0; k < n; k++) {
+      // largest |diagonal| in the trailing corner; the first maximum wins
+      double best[1] = {-1.0};
+      for (int i = k + c.tid; i < n; i += C::nt) best[0] = fmax(best[0], fabs(K[i + i * n]));
+      c.max(best);
+      double cand[1] = {-1e300};
+      for (int i = k + c.tid; i < n; i += C::nt)
+        if (fabs(K[i + i * n]) == best[0]) cand[0] = fmax(cand[0], -(double)i);
+      c.max(cand);
+      const int p = (int)(-cand[0]);
+      if (c.tid == 0) perm[k] = p;
+      if (p != k) {
+        c.sync();
+        const int s = n - p - 1;
+        for (int j = c.tid; j < k; j += C::nt) {
+          const double t = K[k + j * n];
+          K[k + j * n] = K[p + j * n];
+          K[p + j * n] = t;
+        }
+        for (int i = c.tid; i < s; i += C::nt) {
+          const double t = K[(p + 1 + i) + k * n];
+          K[(p + 1 + i) + k * n] = K[(p + 1 + i) + p * n];
+          K[(p + 1 + i) + p * n] = t;
+        }
+        for (int i = k + 1 + c.tid; i < p; i += C::nt) {
+          const double t = K[i + k * n];
+          K[i + k * n] = K[p + i * n];
+          K[p + i * n] = t;
+        }
+        if (c.tid == 0) {
+          const double t = K[k + k * n];
+          K[k + k * n] = K[p + p * n];
+          K[p + p * n] = t;
+        }
+      }
+      c.sync();
+      const double d = K[k + k * n];
+      const bool valid = fabs(d) > 0.0;
+      if (found_zero_pivot && valid) return false;
+      if (!valid) found_zero_pivot = true;
+      const int rs = n - k - 1;
+      if (rs > 0 && valid) {
+        // trailing update of the lower triangle: K(i,j) -= K(i,k) K(j,k) / d
+        const double id = 1.0 / d;
+        const int tot = rs * rs;
+        for (int e = c.tid; e < tot; e += C::nt) {
+          const int i = k + 1 + e % rs, j = k + 1 + e / rs;
+          if (i >= j) K[i + j * n] -= K[i + k * n] * (K[j + k * n] * id);
+        }
+        c.sync();
+        for (int i = k + 1 + c.tid; i < n; i += C::nt) K[i + k * n] *= id;
+      }
+      c.sync();
+    }
+    return true;
+  }
+
+  // rhs <- K^{-1} rhs using P' L^{-T} D^{+} L^{-1} P.
+  FB_DEV void ldlt_solve(const C& c) const {
+    const int n = lay.nk;
+    if (c.tid == 0) {
+      for (int k = 0; k < n; k++) {
+        const int p = perm[k];
+        if (p != k) { const double t = rhs[k]; rhs[k] = rhs[p]; rhs[p] = t; }
+      }
+    }
+    c.sync();
+    for (int k = 0; k < n - 1; k++) {
+      const double xk = rhs[k];
+      for (int i = k + 1 + c.tid; i < n; i += C::nt) rhs[i] -= K[i + k * n] * xk;
+      c.sync();
+    }
+    for (int i = c.tid; i < n; i += C::nt) {
+      const double d = K[i + i * n];
+      rhs[i] = fabs(d) > DBL_MIN ? rhs[i] / d : 0.0;
+    }
+    c.sync();
+    for (int k = n - 1; k > 0; k--) {
+      const double xk = rhs[k];
+      for (int j = c.tid; j < k; j += C::nt) rhs[j] -= K[k + j * n] * xk;
+      c.sync();
+    }
+    if (c.tid == 0) {
+      for (int k = n - 1; k >= 0; k--) {
+        const int p = perm[k];
+        if (p != k) { const double t = rhs[k]; rhs[k] = rhs[p]; rhs[p] = t; }
+      }
+    }
+    c.sync();
+  }
+
+  FB_DEV bool newton_step(const C& c, double sigma, double alpha) const {
+    const int n = lay.nk;
+    // PFB gradients (dense_cholesky_solver.cc:54-61)
+    for (int i = c.tid; i < nv; i += C::nt) {
+      const double ys = y[i] + sigma * (v[i] - vb[i]);
+      double g0, g1;
+      pfb_gradient(ys, v[i], alpha, &g0, &g1);
+      const double mu = g1 + sigma * g0;
+      gam[i] = g0 / mu;
+      rvm[i] = -pfb(ys, v[i], alpha) / mu;
+    }
+    c.sync();
+    // K = [H + sigma I + A'Gamma A  .; G  -sigma I] (lower; :52-69) and the
+    // eliminated right-hand side (:98-104).
+    for (int e = c.tid; e < n * n + n; e += C::nt) {
+      if (e < n * n) {
+        const int i = e % n, j = e / n;
+        if (i < j) continue;
+        double s;
+        if (i < nz) {
+          s = D.H[i + (long)j * nz] + (i == j ? sigma : 0.0);
+          const double* ai = D.A + (long)i * nv;
+          const double* aj = D.A + (long)j * nv;
+          for (int k = 0; k < nv; k++) s += gam[k] * ai[k] * aj[k];
+        } else if (j < nz) {
+          s = D.G[(i - nz) + (long)j * nl];
+        } else {
+          s = (i == j) ? -sigma : 0.0;
+        }
+        K[e] = s;
+      } else {
+        const int j = e - n * n;
+        if (j < nz) {
+          rhs[j] = -(rz[j] + sigma * (z[j] - zb[j])) - col_dot(D.A, nv, j, rvm);
+        } else {
+          const int q = j - nz;
+          rhs[j] = rl[q] + sigma * (l[q] - lb[q]);
+        }
+      }
+    }
+    c.sync();
+    if (!ldlt(c)) return false;
+    ldlt_solve(c);
+    for (int i = c.tid; i < n; i += C::nt) {
+      if (i < nz) dz[i] = rhs[i];
+      else dl[i - nz] = rhs[i];
+    }
+    c.sync();
+    // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124)
+    for (int i = c.tid; i < nv; i += C::nt) {
+      const double a = row_dot(D.A, nv, nz, i, dz);
+      adz[i] = a;
+      dv[i] = rvm[i] + gam[i] * a;
+    }
+    c.sync();
+    // W = (H dz + G'dl + A'dv, -G dz)
+    for (int i = c.tid; i < nz + nl; i += C::nt) {
+      if (i < nz)
+        wz[i] = row_dot(D.H, nz, nz, i, dz) + col_dot(D.G, nl, i, dl) + col_dot(D.A, nv, i, dv);
+      else
+        wl[i - nz] = -row_dot(D.G, nl, nz, i - nz, dz);
+    }
+    c.sync();
+    return true;
+  }
+
+  FB_DEV void write_x(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) uz[i] = z[i];
+    for (int i = c.tid; i < nl; i += C::nt) ul[i] = l[i];
+    for (int i = c.tid; i < nv; i += C::nt) { uv[i] = v[i]; uy[i] = y[i]; }
+  }
+  FB_DEV void write_xbar(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) uz[i] = zb[i];
+    for (int i = c.tid; i < nl; i += C::nt) ul[i] = lb[i];
+    for (int i = c.tid; i < nv; i += C::nt) { uv[i] = vb[i]; uy[i] = yb[i]; }
+  }
+  FB_DEV void write_certificate(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) uz[i] = dz[i];
+    for (int i = c.tid; i < nl; i += C::nt) ul[i] = dl[i];
+    for (int i = c.tid; i < nv; i += C::nt) {
+      uv[i] = dv[i];
+      uy[i] = (y[i] - yb[i]) + bvec(i);
+    }
+  }
+};
+
+}  // namespace fbk

@@ -1,0 +1,725 @@
+// MPC problem policy for the batched FBstab kernel: one workgroup owns one
+// stage-structured QP
+//   min sum_i 1/2 [x;u]'[Q S';S R][x;u] + q'x + r'u
+//   s.t. x(i+1) = A x + B u + c,  x(0) = x0,  E x + L u + d <= 0
+// in the reference's MatrixSequence layout (fbstab/fbstab_mpc.h:67-81,
+// tools/matrix_sequence.h:81-83).
+//
+// What it implements, and the reference code each part answers to:
+//   * implicit block products with H, G, A (mpc_data.cc:17-238) and the
+//     f/h/b vectors (mpc_data.cc:240-289), evaluated stage by stage from an
+//     LDS tile of that stage's matrices (coalesced HBM/L2 loads);
+//   * the Newton step of RiccatiLinearSolver (riccati_linear_solver.cc:77-344):
+//     barrier-augmented stage Hessians, the matrix recursion and the
+//     forward/backward vector recursions, fused into ONE forward sweep over
+//     the stages (factor + forward substitution) and ONE backward sweep;
+//   * the infeasibility certificates of FullFeasibility
+//     (full_feasibility.cc:25-88).
+//
+// Differences from the reference that change rounding but not mathematics:
+//   * triangular factors M, SG, L(i) are inverted explicitly once per stage
+//     (each column by an independent forward substitution) and then applied
+//     as matrix products, so that no stage needs more than the three Cholesky
+//     chains as sequential work;
+//   * the forward vector recursion runs inside the factor sweep, and the
+//     backward sweep reuses tx = inv(M) h and tu = inv(SG)(SM tx + ru) from it
+//     (the reference recomputes them, riccati_linear_solver.cc:299-312);
+//   * dv = rv/mus + Gamma .* (A dz)  ==  (rv + gamma .* A dz) ./ mus.
+#pragma once
+
+#include "fb_common.h"
+
+namespace fbk {
+
+// Pointers to one QP's problem data (already offset to that QP).
+struct MpcData {
+  const double *Q, *R, *S, *q, *r, *A, *B, *c, *E, *L, *d, *x0;
+};
+
+// Sizes and derived offsets, identical on host (workspace sizing) and device.
+struct MpcLayout {
+  int N, nx, nu, nc, ns, nz, nl, nv;
+  // per-stage factor record (doubles) kept in global scratch for the backward sweep
+  int f_minv, f_sm, f_am, f_p, f_sginv, f_linv, f_tx, f_tu, f_th, f_stride;
+  // iterate vectors in global scratch (offsets in doubles)
+  long v_z, v_l, v_v, v_y, v_zb, v_lb, v_vb, v_yb, v_dz, v_dl, v_dv, v_adz, v_rz, v_rl,
+      v_wz, v_wl, v_gam, v_rvm, v_fac, ws_doubles;
+  // LDS carve (offsets in doubles)
+  int t_q, t_r, t_s, t_a, t_b, t_e, t_l;                  // data tile
+  int s_z, s_l, s_ln, s_v;                                // vector slices of the stage
+  int w_sb, w_rb, w_linv, w_m, w_minv, w_am, w_sm, w_sg, w_sginv, w_pp, w_p, w_ln;
+  int w_gam, w_rvm, w_r1, w_r2, w_th, w_thp, w_h, w_tx, w_tu, w_t1, w_t2, w_lp, w_out;
+  int w_red, lds_doubles;
+
+#if !defined(FB_HOSTSIM)
+  __host__ __device__
+#endif
+  void init(int N_, int nx_, int nu_, int nc_, int nthreads) {
+    N = N_; nx = nx_; nu = nu_; nc = nc_;
+    ns = nx + nu;
+    nz = (N + 1) * ns;
+    nl = (N + 1) * nx;
+    nv = (N + 1) * nc;
+    int o = 0;
+    f_minv = o; o += nx * nx;
+    f_sm = o; o += nu * nx;
+    f_am = o; o += nx * nx;
+    f_p = o; o += nx * nu;
+    f_sginv = o; o += nu * nu;
+    f_linv = o; o += nx * nx;
+    f_tx = o; o += nx;
+    f_tu = o; o += nu;
+    f_th = o; o += nx;
+    f_stride = (o + 1) & ~1;
+    long g = 0;
+    v_z = g; g += nz;  v_l = g; g += nl;  v_v = g; g += nv;  v_y = g; g += nv;
+    v_zb = g; g += nz; v_lb = g; g += nl; v_vb = g; g += nv; v_yb = g; g += nv;
+    v_dz = g; g += nz; v_dl = g; g += nl; v_dv = g; g += nv; v_adz = g; g += nv;
+    v_rz = g; g += nz; v_rl = g; g += nl; v_wz = g; g += nz; v_wl = g; g += nl;
+    v_gam = g; g += nv; v_rvm = g; g += nv;
+    g = (g + 1) & ~1L;
+    v_fac = g; g += (long)f_stride * (N + 1);
+    ws_doubles = (g + 15) & ~15L;  // 128-byte multiple per workgroup slot
+    int s = 0;
+    t_q = s; s += nx * nx;  t_r = s; s += nu * nu;  t_s = s; s += nu * nx;
+    t_a = s; s += nx * nx;  t_b = s; s += nx * nu;  t_e = s; s += nc * nx;
+    t_l = s; s += nc * nu;
+    s_z = s; s += ns;  s_l = s; s += nx;  s_ln = s; s += nx;  s_v = s; s += nc;
+    w_sb = s; s += nu * nx;  w_rb = s; s += nu * nu;
+    w_linv = s; s += nx * nx;  w_m = s; s += nx * nx;  w_minv = s; s += nx * nx;
+    w_am = s; s += nx * nx;  w_sm = s; s += nu * nx;  w_sg = s; s += nu * nu;
+    w_sginv = s; s += nu * nu;  w_pp = s; s += nx * nu;  w_p = s; s += nx * nu;
+    w_ln = s; s += nx * nx;
+    w_gam = s; s += nc;  w_rvm = s; s += nc;  w_r1 = s; s += ns;  w_r2 = s; s += nx;
+    w_th = s; s += nx;  w_thp = s; s += nx;  w_h = s; s += nx;  w_tx = s; s += nx;
+    w_tu = s; s += nu;  w_t1 = s; s += ns;  w_t2 = s; s += ns;  w_lp = s; s += nx;
+    w_out = s; s += ns + nx + nc;
+    w_red = s; s += kMaxReduce * ((nthreads + 63) / 64);
+    lds_doubles = (s + 1) & ~1;
+  }
+};
+
+template <class C>
+struct MpcProblem {
+  MpcLayout lay;
+  MpcData D;
+  double *uz, *ul, *uv, *uy;  // caller's (z,l,v,y) for this QP
+  lds_ptr lds;
+  double* ws;  // this workgroup's global scratch
+  int nz, nl, nv;
+  double *z, *l, *v, *y, *zb, *lb, *vb, *yb, *dz, *dl, *dv, *adz, *rz, *rl, *wz, *wl;
+  double *gam, *rvm, *fac;
+
+  FB_DEV void bind(const MpcLayout& L_, const MpcData& D_, double* uz_, double* ul_,
+                   double* uv_, double* uy_, lds_ptr lds_, double* ws_) {
+    lay = L_; D = D_; uz = uz_; ul = ul_; uv = uv_; uy = uy_; lds = lds_; ws = ws_;
+    nz = lay.nz; nl = lay.nl; nv = lay.nv;
+    z = ws + lay.v_z; l = ws + lay.v_l; v = ws + lay.v_v; y = ws + lay.v_y;
+    zb = ws + lay.v_zb; lb = ws + lay.v_lb; vb = ws + lay.v_vb; yb = ws + lay.v_yb;
+    dz = ws + lay.v_dz; dl = ws + lay.v_dl; dv = ws + lay.v_dv; adz = ws + lay.v_adz;
+    rz = ws + lay.v_rz; rl = ws + lay.v_rl; wz = ws + lay.v_wz; wl = ws + lay.v_wl;
+    gam = ws + lay.v_gam; rvm = ws + lay.v_rvm; fac = ws + lay.v_fac;
+  }
+
+  // ---- small helpers -------------------------------------------------------
+  template <class Src>
+  FB_DEV void copy_in(const C& c, lds_ptr dst, Src src, int n) const {
+    for (int i = c.tid; i < n; i += C::nt) dst[i] = src[i];
+  }
+
+  // Load stage i's matrices into the LDS tile (coalesced, stage-contiguous).
+  FB_DEV void load_tile(const C& c, int i) const {
+    const int nx = lay.nx, nu = lay.nu, nc = lay.nc;
+    copy_in(c, lds + lay.t_q, D.Q + (long)i * nx * nx, nx * nx);
+    copy_in(c, lds + lay.t_r, D.R + (long)i * nu * nu, nu * nu);
+    copy_in(c, lds + lay.t_s, D.S + (long)i * nu * nx, nu * nx);
+    copy_in(c, lds + lay.t_e, D.E + (long)i * nc * nx, nc * nx);
+    copy_in(c, lds + lay.t_l, D.L + (long)i * nc * nu, nc * nu);
+    if (i < lay.N) {
+      copy_in(c, lds + lay.t_a, D.A + (long)i * nx * nx, nx * nx);
+      copy_in(c, lds + lay.t_b, D.B + (long)i * nx * nu, nx * nu);
+    }
+  }
+
+  // Stage slices of a (z,l,v)-shaped vector triple into LDS.
+  FB_DEV void load_slices(const C& c, int i, const double* zz, const double* ll,
+                          const double* vv) const {
+    copy_in(c, lds + lay.s_z, zz + (long)i * lay.ns, lay.ns);
+    if (ll) {
+      copy_in(c, lds + lay.s_l, ll + (long)i * lay.nx, lay.nx);
+      if (i < lay.N) copy_in(c, lds + lay.s_ln, ll + (long)(i + 1) * lay.nx, lay.nx);
+    }
+    if (vv) copy_in(c, lds + lay.s_v, vv + (long)i * lay.nc, lay.nc);
+  }
+
+  // (H zz)_i[r] from the tile (mpc_data.cc:28-63); r in [0, ns).
+  FB_DEV double tile_Hz(int r) const {
+    const int nx = lay.nx, nu = lay.nu;
+    lds_ptr zx = lds + lay.s_z;
+    lds_ptr zu = zx + nx;
+    double s = 0.0;
+    if (r < nx) {
+      lds_ptr Q = lds + lay.t_q;
+      lds_ptr S = lds + lay.t_s;
+      for (int k = 0; k < nx; k++) s += Q[r + k * nx] * zx[k];
+      for (int k = 0; k < nu; k++) s += S[k + r * nu] * zu[k];
+    } else {
+      const int ru = r - nx;
+      lds_ptr S = lds + lay.t_s;
+      lds_ptr R = lds + lay.t_r;
+      for (int k = 0; k < nx; k++) s += S[ru + k * nu] * zx[k];
+      for (int k = 0; k < nu; k++) s += R[ru + k * nu] * zu[k];
+    }
+    return s;
+  }
+  // (G' ll)_i[r] (mpc_data.cc:171-198).
+  FB_DEV double tile_GTl(int i, int r) const {
+    const int nx = lay.nx;
+    lds_ptr li = lds + lay.s_l;
+    lds_ptr ln = lds + lay.s_ln;
+    double s = 0.0;
+    if (r < nx) {
+      s = -li[r];
+      if (i < lay.N) {
+        lds_ptr A = lds + lay.t_a;
+        for (int k = 0; k < nx; k++) s += A[k + r * nx] * ln[k];
+      }
+    } else if (i < lay.N) {
+      lds_ptr B = lds + lay.t_b;
+      const int ru = r - nx;
+      for (int k = 0; k < nx; k++) s += B[k + ru * nx] * ln[k];
+    }
+    return s;
+  }
+  // (A' vv)_i[r] (mpc_data.cc:217-237).
+  FB_DEV double tile_ATv(int r) const {
+    const int nx = lay.nx, nc = lay.nc;
+    lds_ptr vi = lds + lay.s_v;
+    double s = 0.0;
+    if (r < nx) {
+      lds_ptr E = lds + lay.t_e + r * nc;
+      for (int k = 0; k < nc; k++) s += E[k] * vi[k];
+    } else {
+      lds_ptr L = lds + lay.t_l + (r - nx) * nc;
+      for (int k = 0; k < nc; k++) s += L[k] * vi[k];
+    }
+    return s;
+  }
+  // (A zz)_i[k] = E x + L u (mpc_data.cc:84-104).
+  FB_DEV double tile_Az(int k) const {
+    const int nx = lay.nx, nu = lay.nu, nc = lay.nc;
+    lds_ptr zx = lds + lay.s_z;
+    lds_ptr E = lds + lay.t_e;
+    lds_ptr L = lds + lay.t_l;
+    double s = 0.0;
+    for (int j = 0; j < nx; j++) s += E[k + j * nc] * zx[j];
+    for (int j = 0; j < nu; j++) s += L[k + j * nc] * zx[nx + j];
+    return s;
+  }
+  // A_i x_i + B_i u_i, row r (the stage-(i+1) block of G z before "- x(i+1)",
+  // mpc_data.cc:127-152).
+  FB_DEV double tile_ABz(int r) const {
+    const int nx = lay.nx, nu = lay.nu;
+    lds_ptr zx = lds + lay.s_z;
+    lds_ptr A = lds + lay.t_a;
+    lds_ptr B = lds + lay.t_b;
+    double s = 0.0;
+    for (int j = 0; j < nx; j++) s += A[r + j * nx] * zx[j];
+    for (int j = 0; j < nu; j++) s += B[r + j * nx] * zx[nx + j];
+    return s;
+  }
+
+  // ---- policy interface ------------------------------------------------------
+  // ||(f,h,b)||_2 (mpc_data.h:88-97).
+  FB_DEV double forcing_norm(const C& c) const {
+    double s[1] = {0.0};
+    for (int i = c.tid; i < (lay.N + 1) * lay.nx; i += C::nt) s[0] += D.q[i] * D.q[i];
+    for (int i = c.tid; i < (lay.N + 1) * lay.nu; i += C::nt) s[0] += D.r[i] * D.r[i];
+    for (int i = c.tid; i < (lay.N + 1) * lay.nc; i += C::nt) s[0] += D.d[i] * D.d[i];
+    for (int i = c.tid; i < lay.nx; i += C::nt) s[0] += D.x0[i] * D.x0[i];
+    for (int i = c.tid; i < lay.N * lay.nx; i += C::nt) s[0] += D.c[i] * D.c[i];
+    c.sum(s);
+    return sqrt(s[0]);
+  }
+
+  FB_DEV double bvec(int i) const { return -D.d[i]; }  // b = -d (mpc_data.cc:276-289)
+
+  // x <- caller's guess; y = b - A z (impl:334-347, full_variable.cc:47-53).
+  FB_DEV void load_guess(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) z[i] = uz[i];
+    for (int i = c.tid; i < nl; i += C::nt) l[i] = ul[i];
+    for (int i = c.tid; i < nv; i += C::nt) v[i] = uv[i];
+    c.sync();
+    for (int i = 0; i <= lay.N; i++) {
+      load_tile(c, i);
+      load_slices(c, i, z, nullptr, nullptr);
+      c.sync();
+      for (int k = c.tid; k < lay.nc; k += C::nt)
+        y[(long)i * lay.nc + k] = bvec(i * lay.nc + k) - tile_Az(k);
+      c.sync();
+    }
+  }
+
+  // Natural residual blocks at x: rz = Hz + f + G'l + A'v, rl = h - Gz
+  // (full_residual.cc:79-91).
+  FB_DEV void residual(const C& c) const {
+    const int nx = lay.nx, ns = lay.ns;
+    for (int i = 0; i <= lay.N; i++) {
+      load_tile(c, i);
+      load_slices(c, i, z, l, v);
+      c.sync();
+      for (int r = c.tid; r < ns + nx; r += C::nt) {
+        if (r < ns) {
+          const double f = r < nx ? D.q[(long)i * nx + r] : D.r[(long)i * lay.nu + (r - nx)];
+          rz[(long)i * ns + r] = f + tile_Hz(r) + tile_GTl(i, r) + tile_ATv(r);
+        } else {
+          const int rr = r - ns;
+          // block 0: h0 - (Gz)0 = -x0 + x(0); block i+1: -c(i) - (A x + B u - x(i+1))
+          if (i == 0) rl[rr] = -D.x0[rr] + (lds + lay.s_z)[rr];
+          if (i < lay.N)
+            rl[(long)(i + 1) * nx + rr] =
+                -D.c[(long)i * nx + rr] - (tile_ABz(rr) - z[(long)(i + 1) * ns + rr]);
+        }
+      }
+      c.sync();
+    }
+  }
+
+  // Infeasibility certificates for dx = (dz,dl,dv) (full_feasibility.cc:25-88).
+  FB_DEV int feasibility(const C& c, double tol) const {
+    const int nx = lay.nx, ns = lay.ns, nc = lay.nc;
+    double mx[5] = {-1e300, 0.0, 0.0, 0.0, 0.0};  // max(A dz), |G dz|, |H dz|, |dz|, |A'dv+G'dl|
+    double sm[2] = {0.0, 0.0};                    // f'dz, b'dv + h'dl
+    double ul[1] = {0.0};                         // max(|dv|,|dl|)
+    for (int i = 0; i <= lay.N; i++) {
+      load_tile(c, i);
+      load_slices(c, i, dz, dl, dv);
+      c.sync();
+      for (int r = c.tid; r < ns + nx + nc; r += C::nt) {
+        if (r < ns) {
+          const double dzr = (lds + lay.s_z)[r];
+          const double f = r < nx ? D.q[(long)i * nx + r] : D.r[(long)i * lay.nu + (r - nx)];
+          mx[2] = fmax(mx[2], fabs(tile_Hz(r)));
+          mx[3] = fmax(mx[3], fabs(dzr));
+          mx[4] = fmax(mx[4], fabs(tile_ATv(r) + tile_GTl(i, r)));
+          sm[0] += f * dzr;
+        } else if (r < ns + nx) {
+          const int rr = r - ns;
+          const double dli = (lds + lay.s_l)[rr];
+          ul[0] = fmax(ul[0], fabs(dli));
+          if (i == 0) {
+            mx[1] = fmax(mx[1], fabs((lds + lay.s_z)[rr]));  // (G dz)_0 = -dx(0)
+            sm[1] += -D.x0[rr] * dli;
+          } else {
+            sm[1] += -D.c[(long)(i - 1) * nx + rr] * dli;
+          }
+          if (i < lay.N)
+            mx[1] = fmax(mx[1], fabs(tile_ABz(rr) - dz[(long)(i + 1) * ns + rr]));
+        } else {
+          const int k = r - ns - nx;
+          const double dvk = (lds + lay.s_v)[k];
+          mx[0] = fmax(mx[0], tile_Az(k));
+          ul[0] = fmax(ul[0], fabs(dvk));
+          sm[1] += bvec(i * nc + k) * dvk;
+        }
+      }
+      c.sync();
+    }
+    c.max(mx);
+    c.sum(sm);
+    c.max(ul);
+    const double d1 = mx[0], d2 = mx[1], d3 = mx[2], w = mx[3], p1 = mx[4];
+    const double d4 = sm[0], p2 = sm[1], u = ul[0];
+    bool dual_feasible = true, primal_feasible = true;
+    if ((d1 <= w * tol) && (d2 <= tol * w) && (d3 <= tol * w) && (d4 < 0) && (w > 1e-14))
+      dual_feasible = false;
+    if ((p1 <= tol * u) && (p2 < 0)) primal_feasible = false;
+    if (primal_feasible && dual_feasible) return kFeasible;
+    if (primal_feasible && !dual_feasible) return kDualInfeasible;
+    if (!primal_feasible && dual_feasible) return kPrimalInfeasible;
+    return kBothInfeasible;
+  }
+
+  // ---- dense micro-kernels on LDS matrices (n <= 64 <= NT) -------------------
+  // In-place lower Cholesky, one thread per row (left-looking: column j is
+  // finished from the already final columns < j).  Workgroup-uniform result.
+  FB_DEV bool chol(const C& c, lds_ptr A, int n) const {
+    for (int j = 0; j < n; j++) {
+      for (int r = j + c.tid; r < n; r += C::nt) {
+        double t = A[r + j * n];
+        for (int k = 0; k < j; k++) t -= A[r + k * n] * A[j + k * n];
+        A[r + j * n] = t;
+      }
+      c.sync();
+      const double d = A[j + j * n];
+      if (!(d > 0.0)) return false;
+      const double sd = sqrt(d);
+      c.sync();
+      for (int r = j + c.tid; r < n; r += C::nt) A[r + j * n] = (r == j) ? sd : A[r + j * n] / sd;
+      c.sync();
+    }
+    return true;
+  }
+  // X = inv(Lo) for lower-triangular Lo (column c by thread c); the strict
+  // upper triangle of X is zeroed.  Caller syncs afterwards.
+  FB_DEV void tri_inv(const C& c, lds_ptr Lo, lds_ptr X, int n) const {
+    for (int cc = c.tid; cc < n; cc += C::nt) {
+      for (int r = 0; r < cc; r++) X[r + cc * n] = 0.0;
+      X[cc + cc * n] = 1.0 / Lo[cc + cc * n];
+      for (int r = cc + 1; r < n; r++) {
+        double s = 0.0;
+        for (int k = cc; k < r; k++) s += Lo[r + k * n] * X[k + cc * n];
+        X[r + cc * n] = -s / Lo[r + r * n];
+      }
+    }
+  }
+
+  // ---- the Newton step --------------------------------------------------------
+  // Solves V(x,xbar,sigma) dx = -R(x,xbar,sigma) (abstract_components.h:276-288)
+  // and produces dz, dl, dv, adz = A dz, wz = H dz + G'dl + A'dv, wl = -G dz.
+  // Returns false iff a Cholesky pivot was not positive
+  // (riccati_linear_solver.cc:131-136).
+  FB_DEV bool newton_step(const C& c, double sigma, double alpha) const {
+    const int N = lay.N, nx = lay.nx, nu = lay.nu, nc = lay.nc, ns = lay.ns;
+    lds_ptr tQ = lds + lay.t_q; lds_ptr tR = lds + lay.t_r; lds_ptr tS = lds + lay.t_s;
+    lds_ptr tA = lds + lay.t_a; lds_ptr tB = lds + lay.t_b; lds_ptr tE = lds + lay.t_e;
+    lds_ptr tL = lds + lay.t_l;
+    lds_ptr Sb = lds + lay.w_sb; lds_ptr Rb = lds + lay.w_rb;
+    lds_ptr Linv = lds + lay.w_linv; lds_ptr M = lds + lay.w_m; lds_ptr Minv = lds + lay.w_minv;
+    lds_ptr AM = lds + lay.w_am; lds_ptr SM = lds + lay.w_sm; lds_ptr SG = lds + lay.w_sg;
+    lds_ptr SGinv = lds + lay.w_sginv; lds_ptr PP = lds + lay.w_pp; lds_ptr P = lds + lay.w_p;
+    lds_ptr Ln = lds + lay.w_ln;
+    lds_ptr Gam = lds + lay.w_gam; lds_ptr Rvm = lds + lay.w_rvm;
+    lds_ptr r1 = lds + lay.w_r1; lds_ptr r2 = lds + lay.w_r2;
+    lds_ptr th = lds + lay.w_th; lds_ptr thp = lds + lay.w_thp; lds_ptr hh = lds + lay.w_h;
+    lds_ptr tx = lds + lay.w_tx; lds_ptr tu = lds + lay.w_tu;
+    lds_ptr t1 = lds + lay.w_t1; lds_ptr t2 = lds + lay.w_t2; lds_ptr lp = lds + lay.w_lp;
+
+    // Base case L(0) = sqrt(sigma) I  =>  inv(L(0)) = I / sqrt(sigma)
+    // (riccati_linear_solver.cc:127).
+    {
+      const double is = 1.0 / sqrt(sigma);
+      for (int idx = c.tid; idx < nx * nx; idx += C::nt)
+        Linv[idx] = (idx % nx == idx / nx) ? is : 0.0;
+      for (int r = c.tid; r < nx; r += C::nt) thp[r] = 0.0;
+    }
+    c.sync();
+
+    // ============ forward sweep: factor + forward substitution ==============
+    for (int i = 0; i <= N; i++) {
+      double* F = fac + (long)i * lay.f_stride;
+      load_tile(c, i);
+      // PFB gradient of the stage's constraints (riccati_linear_solver.cc:91-99)
+      for (int k = c.tid; k < nc; k += C::nt) {
+        const long g = (long)i * nc + k;
+        const double vk = v[g];
+        const double ys = y[g] + sigma * (vk - vb[g]);
+        double g0, g1;
+        pfb_gradient(ys, vk, alpha, &g0, &g1);
+        const double mu = g1 + sigma * g0;
+        const double G_ = g0 / mu;
+        const double rm = -pfb(ys, vk, alpha) / mu;  // (-rv)/mus
+        Gam[k] = G_;
+        Rvm[k] = rm;
+        gam[g] = G_;
+        rvm[g] = rm;
+      }
+      c.sync();
+      // Barrier-augmented Hessians (lower triangles; :101-123), the matrix to
+      // factor QQ = Qbar + inv(L L') (:142-145), and the eliminated right-hand
+      // sides r1 = -rz_inner - A'(rv/mus), r2 = rl_inner (:222-225).
+      {
+        const int nq = nx * nx, nr = nu * nu, nsx = nu * nx;
+        for (int idx = c.tid; idx < nq + nr + nsx + ns + nx; idx += C::nt) {
+          if (idx < nq) {
+            const int r = idx % nx, cc = idx / nx;
+            if (r >= cc) {
+              double s = tQ[idx] + (r == cc ? sigma : 0.0);
+              for (int k = 0; k < nc; k++) s += Gam[k] * tE[k + r * nc] * tE[k + cc * nc];
+              for (int k = r; k < nx; k++) s += Linv[k + r * nx] * Linv[k + cc * nx];
+              M[idx] = s;
+            }
+          } else if (idx < nq + nr) {
+            const int e = idx - nq;
+            const int r = e % nu, cc = e / nu;
+            if (r >= cc) {
+              double s = tR[e] + (r == cc ? sigma : 0.0);
+              for (int k = 0; k < nc; k++) s += Gam[k] * tL[k + r * nc] * tL[k + cc * nc];
+              Rb[e] = s;
+            }
+          } else if (idx < nq + nr + nsx) {
+            const int e = idx - nq - nr;
+            const int r = e % nu, cc = e / nu;
+            double s = tS[e];
+            for (int k = 0; k < nc; k++) s += Gam[k] * tL[k + r * nc] * tE[k + cc * nc];
+            Sb[e] = s;
+          } else if (idx < nq + nr + nsx + ns) {
+            const int r = idx - nq - nr - nsx;
+            const long g = (long)i * ns + r;
+            double s = -(rz[g] + sigma * (z[g] - zb[g]));
+            lds_ptr col = r < nx ? tE + r * nc : tL + (r - nx) * nc;
+            for (int k = 0; k < nc; k++) s -= col[k] * Rvm[k];
+            r1[r] = s;
+          } else {
+            const int r = idx - nq - nr - nsx - ns;
+            const long g = (long)i * nx + r;
+            const double r2v = rl[g] + sigma * (l[g] - lb[g]);
+            r2[r] = r2v;
+            th[r] = thp[r] + r2v;  // theta(i) (:231, :252-254)
+          }
+        }
+      }
+      c.sync();
+      if (!chol(c, M, nx)) return false;
+      tri_inv(c, M, Minv, nx);
+      // w = inv(L) theta  (first half of h = inv(L L') theta - rx, :233-236,:257-261)
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = 0.0;
+        for (int k = 0; k <= r; k++) s += Linv[r + k * nx] * th[k];
+        t1[r] = s;
+      }
+      c.sync();
+      // AM = A inv(M)', SM = Sbar inv(M)' (:149-161); h = inv(L)' w - rx.
+      {
+        const int na = (i < N) ? nx * nx : 0;
+        for (int idx = c.tid; idx < na + nu * nx + nx; idx += C::nt) {
+          if (idx < na) {
+            const int r = idx % nx, cc = idx / nx;
+            double s = 0.0;
+            for (int k = 0; k <= cc; k++) s += tA[r + k * nx] * Minv[cc + k * nx];
+            AM[idx] = s;
+          } else if (idx < na + nu * nx) {
+            const int e = idx - na;
+            const int r = e % nu, cc = e / nu;
+            double s = 0.0;
+            for (int k = 0; k <= cc; k++) s += Sb[r + k * nu] * Minv[cc + k * nx];
+            SM[e] = s;
+          } else {
+            const int r = idx - na - nu * nx;
+            double s = -r1[r];
+            for (int k = r; k < nx; k++) s += Linv[k + r * nx] * t1[k];
+            hh[r] = s;
+          }
+        }
+      }
+      c.sync();
+      // SG = chol(Rbar - SM SM') (:163-165); tx = inv(M) h (:241-243).
+      for (int idx = c.tid; idx < nu * nu + nx; idx += C::nt) {
+        if (idx < nu * nu) {
+          const int r = idx % nu, cc = idx / nu;
+          if (r >= cc) {
+            double s = Rb[idx];
+            for (int k = 0; k < nx; k++) s -= SM[r + k * nu] * SM[cc + k * nu];
+            SG[idx] = s;
+          }
+        } else {
+          const int r = idx - nu * nu;
+          double s = 0.0;
+          for (int k = 0; k <= r; k++) s += Minv[r + k * nx] * hh[k];
+          tx[r] = s;
+        }
+      }
+      c.sync();
+      if (!chol(c, SG, nu)) return false;
+      tri_inv(c, SG, SGinv, nu);
+      // PP = AM SM' - B (:169-170); t2 = SM tx + ru (:247-248)
+      {
+        const int np = (i < N) ? nx * nu : 0;
+        for (int idx = c.tid; idx < np + nu; idx += C::nt) {
+          if (idx < np) {
+            const int r = idx % nx, cc = idx / nx;
+            double s = -tB[idx];
+            for (int k = 0; k < nx; k++) s += AM[r + k * nx] * SM[cc + k * nu];
+            PP[idx] = s;
+          } else {
+            const int r = idx - np;
+            double s = r1[nx + r];
+            for (int k = 0; k < nx; k++) s += SM[r + k * nu] * tx[k];
+            t2[r] = s;
+          }
+        }
+      }
+      c.sync();
+      // P = PP inv(SG)' (:171-175); tu = inv(SG) t2 (:249)
+      {
+        const int np = (i < N) ? nx * nu : 0;
+        for (int idx = c.tid; idx < np + nu; idx += C::nt) {
+          if (idx < np) {
+            const int r = idx % nx, cc = idx / nx;
+            double s = 0.0;
+            for (int k = 0; k <= cc; k++) s += PP[r + k * nx] * SGinv[cc + k * nu];
+            P[idx] = s;
+          } else {
+            const int r = idx - np;
+            double s = 0.0;
+            for (int k = 0; k <= r; k++) s += SGinv[r + k * nu] * t2[k];
+            tu[r] = s;
+          }
+        }
+      }
+      c.sync();
+      // Save what the backward sweep needs.
+      for (int idx = c.tid; idx < nx * nx; idx += C::nt) {
+        F[lay.f_minv + idx] = Minv[idx];
+        F[lay.f_linv + idx] = Linv[idx];
+        if (i < N) F[lay.f_am + idx] = AM[idx];
+      }
+      for (int idx = c.tid; idx < nu * nx; idx += C::nt) {
+        F[lay.f_sm + idx] = SM[idx];
+        if (i < N) F[lay.f_p + idx] = P[idx];
+      }
+      for (int idx = c.tid; idx < nu * nu; idx += C::nt) F[lay.f_sginv + idx] = SGinv[idx];
+      for (int r = c.tid; r < nx; r += C::nt) {
+        F[lay.f_tx + r] = tx[r];
+        F[lay.f_th + r] = th[r];
+      }
+      for (int r = c.tid; r < nu; r += C::nt) F[lay.f_tu + r] = tu[r];
+      if (i < N) {
+        // L(i+1) = chol(sigma I + P P' + AM AM') (:177-183);
+        // theta(i+1) partial = P tu + AM tx (:252-253).
+        for (int idx = c.tid; idx < nx * nx + nx; idx += C::nt) {
+          if (idx < nx * nx) {
+            const int r = idx % nx, cc = idx / nx;
+            if (r >= cc) {
+              double s = (r == cc) ? sigma : 0.0;
+              for (int k = 0; k < nu; k++) s += P[r + k * nx] * P[cc + k * nx];
+              for (int k = 0; k < nx; k++) s += AM[r + k * nx] * AM[cc + k * nx];
+              Ln[idx] = s;
+            }
+          } else {
+            const int r = idx - nx * nx;
+            double s = 0.0;
+            for (int k = 0; k < nu; k++) s += P[r + k * nx] * tu[k];
+            for (int k = 0; k < nx; k++) s += AM[r + k * nx] * tx[k];
+            thp[r] = s;
+          }
+        }
+        c.sync();
+        if (!chol(c, Ln, nx)) return false;
+        tri_inv(c, Ln, Linv, nx);  // becomes inv(L(i+1)) for the next stage
+        c.sync();
+      }
+    }
+
+    // ============ backward sweep (:267-327) =================================
+    // Stage N is still resident in LDS.
+    for (int i = N; i >= 0; i--) {
+      if (i < N) {
+        const double* F = fac + (long)i * lay.f_stride;
+        copy_in(c, Minv, F + lay.f_minv, nx * nx);
+        copy_in(c, Linv, F + lay.f_linv, nx * nx);
+        copy_in(c, AM, F + lay.f_am, nx * nx);
+        copy_in(c, SM, F + lay.f_sm, nu * nx);
+        copy_in(c, P, F + lay.f_p, nu * nx);
+        copy_in(c, SGinv, F + lay.f_sginv, nu * nu);
+        copy_in(c, tx, F + lay.f_tx, nx);
+        copy_in(c, tu, F + lay.f_tu, nu);
+        copy_in(c, th, F + lay.f_th, nx);
+        c.sync();
+      }
+      // a = tu + P' l(i+1)   (a = tu at the terminal stage)
+      for (int r = c.tid; r < nu; r += C::nt) {
+        double s = tu[r];
+        if (i < N)
+          for (int k = 0; k < nx; k++) s += P[k + r * nx] * lp[k];
+        t2[r] = s;
+      }
+      c.sync();
+      // u = inv(SG)' a
+      for (int r = c.tid; r < nu; r += C::nt) {
+        double s = 0.0;
+        for (int k = r; k < nu; k++) s += SGinv[k + r * nu] * t2[k];
+        t1[nx + r] = s;
+      }
+      c.sync();
+      // b = tx + SM' u + AM' l(i+1)
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = tx[r];
+        for (int k = 0; k < nu; k++) s += SM[k + r * nu] * t1[nx + k];
+        if (i < N)
+          for (int k = 0; k < nx; k++) s += AM[k + r * nx] * lp[k];
+        t2[r] = s;
+      }
+      c.sync();
+      // x = -inv(M)' b
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = 0.0;
+        for (int k = r; k < nx; k++) s += Minv[k + r * nx] * t2[k];
+        t1[r] = -s;
+      }
+      c.sync();
+      // w = inv(L)(theta + x);  l = -inv(L)' w
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = 0.0;
+        for (int k = 0; k <= r; k++) s += Linv[r + k * nx] * (th[k] + t1[k]);
+        t2[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < ns + nx; r += C::nt) {
+        if (r < ns) {
+          dz[(long)i * ns + r] = t1[r];
+        } else {
+          const int rr = r - ns;
+          double s = 0.0;
+          for (int k = rr; k < nx; k++) s += Linv[k + rr * nx] * t2[k];
+          lp[rr] = -s;
+          dl[(long)i * nx + rr] = -s;
+        }
+      }
+      c.sync();
+    }
+
+    // ============ post sweep: dv, A dz and W (:329-341 + the residual
+    // increment of fb_algorithm.h) ========================================
+    for (int i = 0; i <= N; i++) {
+      load_tile(c, i);
+      load_slices(c, i, dz, dl, nullptr);
+      c.sync();
+      for (int k = c.tid; k < nc; k += C::nt) {
+        const long g = (long)i * nc + k;
+        const double a = tile_Az(k);
+        const double d = rvm[g] + gam[g] * a;
+        adz[g] = a;
+        dv[g] = d;
+        (lds + lay.s_v)[k] = d;
+      }
+      c.sync();
+      for (int r = c.tid; r < ns + nx; r += C::nt) {
+        if (r < ns) {
+          wz[(long)i * ns + r] = tile_Hz(r) + tile_GTl(i, r) + tile_ATv(r);
+        } else {
+          const int rr = r - ns;
+          if (i == 0) wl[rr] = (lds + lay.s_z)[rr];  // -(G dz)_0 = dx(0)
+          if (i < N)
+            wl[(long)(i + 1) * nx + rr] = -(tile_ABz(rr) - dz[(long)(i + 1) * ns + rr]);
+        }
+      }
+      c.sync();
+    }
+    return true;
+  }
+
+  // ---- results ---------------------------------------------------------------
+  FB_DEV void write_x(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) uz[i] = z[i];
+    for (int i = c.tid; i < nl; i += C::nt) ul[i] = l[i];
+    for (int i = c.tid; i < nv; i += C::nt) { uv[i] = v[i]; uy[i] = y[i]; }
+  }
+  FB_DEV void write_xbar(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) uz[i] = zb[i];
+    for (int i = c.tid; i < nl; i += C::nt) ul[i] = lb[i];
+    for (int i = c.tid; i < nv; i += C::nt) { uv[i] = vb[i]; uy[i] = yb[i]; }
+  }
+  // x <- dx = xi - xk with dx.y = xi.y - xk.y + b (impl:202-210,
+  // full_variable.cc:55-65).
+  FB_DEV void write_certificate(const C& c) const {
+    for (int i = c.tid; i < nz; i += C::nt) uz[i] = dz[i];
+    for (int i = c.tid; i < nl; i += C::nt) ul[i] = dl[i];
+    for (int i = c.tid; i < nv; i += C::nt) {
+      uv[i] = dv[i];
+      uy[i] = (y[i] - yb[i]) + bvec(i);
+    }
+  }
+};
+
+}  // namespace fbk

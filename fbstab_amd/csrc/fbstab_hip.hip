@@ -1,0 +1,575 @@
+// libfbstab_hip.so: gfx950 kernels and the C-ABI of include/fbstab_hip.h.
+//
+// Execution model: a persistent grid of workgroups, one QP per workgroup at a
+// time.  Workgroups pull QP indices from a device-side counter (iteration
+// counts differ per QP by 5-10x, so a static assignment would leave CUs idle at
+// the tail).  The whole FBstab solve of a QP (proximal loop, Newton loop,
+// factorisation, line search) runs inside the kernel; the host only launches.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fbstab_hip.h"
+#include "fb_algorithm.h"
+#include "fb_dense.h"
+#include "fb_mpc.h"
+
+namespace {
+
+using namespace fbk;
+
+constexpr int kMpcThreads = 64;     // one wavefront per MPC QP
+constexpr int kDenseThreads = 256;  // four wavefronts per dense QP
+constexpr int kLdsLimitBytes = 160 * 1024;
+
+struct MpcBatchArgs {
+  const double* base[FBSTAB_MPC_NSEQ];
+  long long stride[FBSTAB_MPC_NSEQ];
+};
+struct DenseBatchArgs {
+  const double* base[FBSTAB_DENSE_NARR];
+  long long stride[FBSTAB_DENSE_NARR];
+};
+struct VarBatchArgs {
+  double* base[4];
+  long long stride[4];
+};
+
+// Next QP index for this workgroup (workgroup-uniform).
+template <int NT>
+__device__ __forceinline__ int next_qp(int* counter, lds_ptr slot) {
+  if (NT <= 64) {
+    int q = 0;
+    if (threadIdx.x == 0) q = atomicAdd(counter, 1);
+    return __shfl(q, 0, 64);
+  } else {
+    __syncthreads();
+    if (threadIdx.x == 0) *((FB_LDS int*)slot) = atomicAdd(counter, 1);
+    __syncthreads();
+    return *((FB_LDS int*)slot);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void fbstab_mpc_kernel(MpcLayout lay, MpcBatchArgs data,
+                                                        VarBatchArgs x,
+                                                        fbstab_solver_out_t* out,
+                                                        fbstab_options_t opts, double* scratch,
+                                                        int* counter, int batch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  lds_ptr lds = (lds_ptr)smem;
+  typedef Ctx<NT> C;
+  C ctx;
+  ctx.tid = threadIdx.x;
+  ctx.red = lds + lay.w_red;
+  double* ws = scratch + (long)blockIdx.x * lay.ws_doubles;
+  for (;;) {
+    const int q = next_qp<NT>(counter, lds + lay.w_out);
+    if (q >= batch) break;
+    MpcData D;
+    D.Q = data.base[FBSTAB_MPC_Q] + q * data.stride[FBSTAB_MPC_Q];
+    D.R = data.base[FBSTAB_MPC_R] + q * data.stride[FBSTAB_MPC_R];
+    D.S = data.base[FBSTAB_MPC_S] + q * data.stride[FBSTAB_MPC_S];
+    D.q = data.base[FBSTAB_MPC_q] + q * data.stride[FBSTAB_MPC_q];
+    D.r = data.base[FBSTAB_MPC_r] + q * data.stride[FBSTAB_MPC_r];
+    D.A = data.base[FBSTAB_MPC_A] + q * data.stride[FBSTAB_MPC_A];
+    D.B = data.base[FBSTAB_MPC_B] + q * data.stride[FBSTAB_MPC_B];
+    D.c = data.base[FBSTAB_MPC_c] + q * data.stride[FBSTAB_MPC_c];
+    D.E = data.base[FBSTAB_MPC_E] + q * data.stride[FBSTAB_MPC_E];
+    D.L = data.base[FBSTAB_MPC_L] + q * data.stride[FBSTAB_MPC_L];
+    D.d = data.base[FBSTAB_MPC_d] + q * data.stride[FBSTAB_MPC_d];
+    D.x0 = data.base[FBSTAB_MPC_x0] + q * data.stride[FBSTAB_MPC_x0];
+    MpcProblem<C> p;
+    p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
+           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
+    Solver<MpcProblem<C>, C> solver(p, ctx, opts);
+    solver.solve(out + q);
+    ctx.sync();
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, DenseBatchArgs data,
+                                                          VarBatchArgs x,
+                                                          fbstab_solver_out_t* out,
+                                                          fbstab_options_t opts, int* counter,
+                                                          int batch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  lds_ptr lds = (lds_ptr)smem;
+  typedef Ctx<NT> C;
+  C ctx;
+  ctx.tid = threadIdx.x;
+  ctx.red = lds + lay.o_red;
+  for (;;) {
+    const int q = next_qp<NT>(counter, lds + lay.o_rhs);
+    if (q >= batch) break;
+    DenseData D;
+    D.H = data.base[FBSTAB_DENSE_H] + q * data.stride[FBSTAB_DENSE_H];
+    D.f = data.base[FBSTAB_DENSE_f] + q * data.stride[FBSTAB_DENSE_f];
+    D.G = data.base[FBSTAB_DENSE_G] + q * data.stride[FBSTAB_DENSE_G];
+    D.h = data.base[FBSTAB_DENSE_h] + q * data.stride[FBSTAB_DENSE_h];
+    D.A = data.base[FBSTAB_DENSE_A] + q * data.stride[FBSTAB_DENSE_A];
+    D.b = data.base[FBSTAB_DENSE_b] + q * data.stride[FBSTAB_DENSE_b];
+    DenseProblem<C> p;
+    p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
+           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds);
+    Solver<DenseProblem<C>, C> solver(p, ctx, opts);
+    solver.solve(out + q);
+    ctx.sync();
+  }
+}
+
+// ---------------------------------------------------------------------------
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(FBSTAB_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// State shared by both solver kinds.
+struct SolverBase {
+  int device = 0;
+  int max_batch = 0;
+  int threads = 0;
+  int lds_bytes = 0;
+  int workgroups = 0;
+  long long scratch_bytes = 0;
+  fbstab_options_t opts;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int* counter = nullptr;
+  double* scratch = nullptr;
+  // staging for host-pointer calls
+  std::vector<double*> d_arr;  // problem arrays
+  std::vector<long long> arr_len;
+  double* d_var[4] = {nullptr, nullptr, nullptr, nullptr};
+  long long var_len[4] = {0, 0, 0, 0};
+  fbstab_solver_out_t* d_out = nullptr;
+
+  int release() {
+    (void)hipSetDevice(device);
+    for (double* p : d_arr)
+      if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; i++)
+      if (d_var[i]) (void)hipFree(d_var[i]);
+    if (d_out) (void)hipFree(d_out);
+    if (scratch) (void)hipFree(scratch);
+    if (counter) (void)hipFree(counter);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+    return FBSTAB_HIP_OK;
+  }
+
+  int common_init(int dev, int maxb) {
+    device = dev;
+    max_batch = maxb;
+    fbstab_options_default(&opts);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      return fail(FBSTAB_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (dev < 0 || dev >= ndev) return fail(FBSTAB_HIP_ERR_ARGUMENT, "bad device index");
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipMalloc(&counter, sizeof(int)));
+    return FBSTAB_HIP_OK;
+  }
+
+  // Lazily allocated staging for host-pointer calls.
+  int ensure_staging() {
+    if (d_out) return FBSTAB_HIP_OK;
+    d_arr.assign(arr_len.size(), nullptr);
+    for (size_t i = 0; i < arr_len.size(); i++)
+      HIP_TRY(hipMalloc(&d_arr[i], sizeof(double) * (size_t)(arr_len[i] > 0 ? arr_len[i] : 1) * max_batch));
+    for (int i = 0; i < 4; i++)
+      HIP_TRY(hipMalloc(&d_var[i], sizeof(double) * (size_t)(var_len[i] > 0 ? var_len[i] : 1) * max_batch));
+    HIP_TRY(hipMalloc(&d_out, sizeof(fbstab_solver_out_t) * (size_t)max_batch));
+    return FBSTAB_HIP_OK;
+  }
+
+  // Host batch array -> packed device array (stride = len); stride 0 is kept.
+  int upload(const double* host, long long stride, long long len, int batch, double* dev,
+             long long* dev_stride, hipStream_t s) {
+    if (len == 0) {
+      *dev_stride = 0;
+      return FBSTAB_HIP_OK;
+    }
+    if (stride == 0) {
+      HIP_TRY(hipMemcpyAsync(dev, host, sizeof(double) * len, hipMemcpyHostToDevice, s));
+      *dev_stride = 0;
+    } else if (stride == len) {
+      HIP_TRY(hipMemcpyAsync(dev, host, sizeof(double) * len * batch, hipMemcpyHostToDevice, s));
+      *dev_stride = len;
+    } else {
+      HIP_TRY(hipMemcpy2DAsync(dev, sizeof(double) * len, host, sizeof(double) * stride,
+                               sizeof(double) * len, batch, hipMemcpyHostToDevice, s));
+      *dev_stride = len;
+    }
+    return FBSTAB_HIP_OK;
+  }
+  int download(double* host, long long stride, long long len, int batch, const double* dev,
+               hipStream_t s) {
+    if (len == 0) return FBSTAB_HIP_OK;
+    if (stride == len) {
+      HIP_TRY(hipMemcpyAsync(host, dev, sizeof(double) * len * batch, hipMemcpyDeviceToHost, s));
+    } else {
+      HIP_TRY(hipMemcpy2DAsync(host, sizeof(double) * stride, dev, sizeof(double) * len,
+                               sizeof(double) * len, batch, hipMemcpyDeviceToHost, s));
+    }
+    return FBSTAB_HIP_OK;
+  }
+
+  double last_kernel_ms() {
+    if (!timed) return -1.0;
+    (void)hipSetDevice(device);
+    float ms = -1.f;
+    if (hipEventSynchronize(ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+  }
+};
+
+int check_common(const void* handle, int batch, const void* data, const fbstab_var_batch_t* x,
+                 const void* out, int max_batch) {
+  if (!handle) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  if (!data || !x || !out) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  if (batch < 0 || batch > max_batch)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "batch exceeds the max_batch the handle was created with");
+  return FBSTAB_HIP_OK;
+}
+
+}  // namespace
+
+struct fbstab_mpc_solver : SolverBase {
+  fbk::MpcLayout lay;
+};
+struct fbstab_dense_solver : SolverBase {
+  fbk::DenseLayout lay;
+};
+
+extern "C" {
+
+const char* fbstab_hip_last_error(void) { return g_error.c_str(); }
+
+int fbstab_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---------------------------------------------------------------------------
+int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int device,
+                          fbstab_mpc_handle_t* handle) {
+  if (!handle) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null handle pointer");
+  *handle = nullptr;
+  // fbstab_mpc.cc:62-65
+  if (N < 1 || nx < 1 || nu < 1 || nc < 1)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "In FBstabMpc::FBstabMpc: problem sizes must be positive.");
+  if (max_batch < 1) return fail(FBSTAB_HIP_ERR_ARGUMENT, "max_batch must be positive");
+  fbstab_mpc_solver* s = new (std::nothrow) fbstab_mpc_solver();
+  if (!s) return fail(FBSTAB_HIP_ERR_DEVICE, "out of host memory");
+  s->threads = kMpcThreads;
+  s->lay.init(N, nx, nu, nc, s->threads);
+  s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
+  if (nx > s->threads || s->lds_bytes > kLdsLimitBytes) {
+    delete s;
+    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "stage matrices do not fit the 160 KiB LDS budget");
+  }
+  int rc = s->common_init(device, max_batch);
+  if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
+  auto kern = fbstab_mpc_kernel<kMpcThreads>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  int per_cu = 0, cus = 0;
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern),
+                                                     s->threads, s->lds_bytes);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    s->release(); delete s;
+    return fail(FBSTAB_HIP_ERR_DEVICE, std::string("occupancy query: ") + hipGetErrorString(e));
+  }
+  cus = prop.multiProcessorCount;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  const char* env = getenv("FBSTAB_HIP_WGS_PER_CU");
+  if (env && atoi(env) > 0) per_cu = atoi(env);
+  s->workgroups = cus * per_cu;
+  if (s->workgroups > max_batch) s->workgroups = max_batch;
+  s->scratch_bytes = (long long)s->lay.ws_doubles * sizeof(double) * s->workgroups;
+  e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
+  if (e != hipSuccess) {
+    s->release(); delete s;
+    return fail(FBSTAB_HIP_ERR_DEVICE, std::string("scratch allocation: ") + hipGetErrorString(e));
+  }
+  const fbk::MpcLayout& L = s->lay;
+  s->arr_len = {(long long)(N + 1) * nx * nx, (long long)(N + 1) * nu * nu,
+                (long long)(N + 1) * nu * nx, (long long)(N + 1) * nx, (long long)(N + 1) * nu,
+                (long long)N * nx * nx, (long long)N * nx * nu, (long long)N * nx,
+                (long long)(N + 1) * nc * nx, (long long)(N + 1) * nc * nu,
+                (long long)(N + 1) * nc, (long long)nx};
+  s->var_len[0] = L.nz; s->var_len[1] = L.nl; s->var_len[2] = L.nv; s->var_len[3] = L.nv;
+  *handle = s;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_mpc_destroy(fbstab_mpc_handle_t h) {
+  if (!h) return FBSTAB_HIP_OK;
+  h->release();
+  delete h;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_mpc_set_options(fbstab_mpc_handle_t h, const fbstab_options_t* o) {
+  if (!h || !o) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  h->opts = *o;
+  fbstab_options_validate(&h->opts);  // UpdateParameters -> ValidateOptions
+  return FBSTAB_HIP_OK;
+}
+int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t h, fbstab_options_t* o) {
+  if (!h || !o) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  *o = h->opts;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
+                               const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
+                               void* stream) {
+  int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
+  if (rc != FBSTAB_HIP_OK) return rc;
+  for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
+    if (!data->base[i]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer");
+  for (int i = 0; i < 4; i++)
+    if (!x->base[i] && h->var_len[i] > 0) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer");
+  if (batch == 0) return FBSTAB_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const bool dev_ptrs = (flags & FBSTAB_HIP_DEVICE_POINTERS) != 0;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  MpcBatchArgs a;
+  VarBatchArgs v;
+  fbstab_solver_out_t* d_out = out;
+  if (dev_ptrs) {
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { a.base[i] = data->base[i]; a.stride[i] = data->stride[i]; }
+    for (int i = 0; i < 4; i++) { v.base[i] = x->base[i]; v.stride[i] = x->stride[i]; }
+  } else {
+    rc = h->ensure_staging();
+    if (rc != FBSTAB_HIP_OK) return rc;
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) {
+      rc = h->upload(data->base[i], data->stride[i], h->arr_len[i], batch, h->d_arr[i], &a.stride[i], s);
+      if (rc != FBSTAB_HIP_OK) return rc;
+      a.base[i] = h->d_arr[i];
+    }
+    for (int i = 0; i < 4; i++) {
+      if (x->stride[i] < h->var_len[i] && batch > 1)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "variable stride smaller than the vector length");
+      if (i < 3) {
+        long long st;
+        rc = h->upload(x->base[i], x->stride[i] ? x->stride[i] : h->var_len[i], h->var_len[i], batch,
+                       h->d_var[i], &st, s);
+        if (rc != FBSTAB_HIP_OK) return rc;
+      }
+      v.base[i] = h->d_var[i];
+      v.stride[i] = h->var_len[i];
+    }
+    d_out = h->d_out;
+  }
+  HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
+  int grid = h->workgroups < batch ? h->workgroups : batch;
+  HIP_TRY(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(fbstab_mpc_kernel<kMpcThreads>, dim3(grid), dim3(h->threads), h->lds_bytes, s,
+                     h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  if (!dev_ptrs) {
+    for (int i = 0; i < 4; i++) {
+      rc = h->download(x->base[i], x->stride[i] ? x->stride[i] : h->var_len[i], h->var_len[i], batch,
+                       h->d_var[i], s);
+      if (rc != FBSTAB_HIP_OK) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(out, h->d_out, sizeof(fbstab_solver_out_t) * batch, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    for (int i = 0; i < batch; i++) out[i].solve_time = dt;
+  } else if (!(flags & FBSTAB_HIP_ASYNC)) {
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return FBSTAB_HIP_OK;
+}
+
+double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t h) { return h ? h->last_kernel_ms() : -1.0; }
+
+int fbstab_hip_mpc_query(fbstab_mpc_handle_t h, long long* scratch_bytes, int* lds_bytes,
+                         int* workgroups, int* threads) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  if (scratch_bytes) *scratch_bytes = h->scratch_bytes;
+  if (lds_bytes) *lds_bytes = h->lds_bytes;
+  if (workgroups) *workgroups = h->workgroups;
+  if (threads) *threads = h->threads;
+  return FBSTAB_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
+                            fbstab_dense_handle_t* handle) {
+  if (!handle) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null handle pointer");
+  *handle = nullptr;
+  // fbstab_dense.cc:19-23
+  if (nz < 1 || nv < 1 || nl < 0)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "In FBstabDense::FBstabDense: nz and nv must be positive, nl nonnegative.");
+  if (max_batch < 1) return fail(FBSTAB_HIP_ERR_ARGUMENT, "max_batch must be positive");
+  fbstab_dense_solver* s = new (std::nothrow) fbstab_dense_solver();
+  if (!s) return fail(FBSTAB_HIP_ERR_DEVICE, "out of host memory");
+  s->threads = kDenseThreads;
+  s->lay.init(nz, nl, nv, s->threads);
+  s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
+  if (s->lds_bytes > kLdsLimitBytes) {
+    delete s;
+    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "KKT matrix and iterates do not fit the 160 KiB LDS budget");
+  }
+  int rc = s->common_init(device, max_batch);
+  if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
+  auto kern = fbstab_dense_kernel<kDenseThreads>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  int per_cu = 0;
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern),
+                                                     s->threads, s->lds_bytes);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    s->release(); delete s;
+    return fail(FBSTAB_HIP_ERR_DEVICE, std::string("occupancy query: ") + hipGetErrorString(e));
+  }
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  const char* env = getenv("FBSTAB_HIP_WGS_PER_CU");
+  if (env && atoi(env) > 0) per_cu = atoi(env);
+  s->workgroups = prop.multiProcessorCount * per_cu;
+  if (s->workgroups > max_batch) s->workgroups = max_batch;
+  s->scratch_bytes = 0;
+  s->arr_len = {(long long)nz * nz, (long long)nz, (long long)nl * nz, (long long)nl,
+                (long long)nv * nz, (long long)nv};
+  s->var_len[0] = nz; s->var_len[1] = nl; s->var_len[2] = nv; s->var_len[3] = nv;
+  *handle = s;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_dense_destroy(fbstab_dense_handle_t h) {
+  if (!h) return FBSTAB_HIP_OK;
+  h->release();
+  delete h;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_dense_set_options(fbstab_dense_handle_t h, const fbstab_options_t* o) {
+  if (!h || !o) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  h->opts = *o;
+  fbstab_options_validate(&h->opts);
+  return FBSTAB_HIP_OK;
+}
+int fbstab_hip_dense_get_options(fbstab_dense_handle_t h, fbstab_options_t* o) {
+  if (!h || !o) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  *o = h->opts;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t h, int batch,
+                                 const fbstab_dense_batch_t* data, const fbstab_var_batch_t* x,
+                                 fbstab_solver_out_t* out, int flags, void* stream) {
+  int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
+  if (rc != FBSTAB_HIP_OK) return rc;
+  for (int i = 0; i < FBSTAB_DENSE_NARR; i++)
+    if (!data->base[i] && h->arr_len[i] > 0)
+      return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer");
+  for (int i = 0; i < 4; i++)
+    if (!x->base[i] && h->var_len[i] > 0) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer");
+  if (batch == 0) return FBSTAB_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const bool dev_ptrs = (flags & FBSTAB_HIP_DEVICE_POINTERS) != 0;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  DenseBatchArgs a;
+  VarBatchArgs v;
+  fbstab_solver_out_t* d_out = out;
+  if (dev_ptrs) {
+    for (int i = 0; i < FBSTAB_DENSE_NARR; i++) { a.base[i] = data->base[i]; a.stride[i] = data->stride[i]; }
+    for (int i = 0; i < 4; i++) { v.base[i] = x->base[i]; v.stride[i] = x->stride[i]; }
+  } else {
+    rc = h->ensure_staging();
+    if (rc != FBSTAB_HIP_OK) return rc;
+    for (int i = 0; i < FBSTAB_DENSE_NARR; i++) {
+      rc = h->upload(data->base[i], data->stride[i], h->arr_len[i], batch, h->d_arr[i], &a.stride[i], s);
+      if (rc != FBSTAB_HIP_OK) return rc;
+      a.base[i] = h->d_arr[i];
+    }
+    for (int i = 0; i < 4; i++) {
+      if (x->stride[i] < h->var_len[i] && batch > 1)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "variable stride smaller than the vector length");
+      if (i < 3) {
+        long long st;
+        rc = h->upload(x->base[i], x->stride[i] ? x->stride[i] : h->var_len[i], h->var_len[i], batch,
+                       h->d_var[i], &st, s);
+        if (rc != FBSTAB_HIP_OK) return rc;
+      }
+      v.base[i] = h->d_var[i];
+      v.stride[i] = h->var_len[i];
+    }
+    d_out = h->d_out;
+  }
+  HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
+  int grid = h->workgroups < batch ? h->workgroups : batch;
+  HIP_TRY(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(fbstab_dense_kernel<kDenseThreads>, dim3(grid), dim3(h->threads), h->lds_bytes, s,
+                     h->lay, a, v, d_out, h->opts, h->counter, batch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  if (!dev_ptrs) {
+    for (int i = 0; i < 4; i++) {
+      rc = h->download(x->base[i], x->stride[i] ? x->stride[i] : h->var_len[i], h->var_len[i], batch,
+                       h->d_var[i], s);
+      if (rc != FBSTAB_HIP_OK) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(out, h->d_out, sizeof(fbstab_solver_out_t) * batch, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    for (int i = 0; i < batch; i++) out[i].solve_time = dt;
+  } else if (!(flags & FBSTAB_HIP_ASYNC)) {
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return FBSTAB_HIP_OK;
+}
+
+double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t h) { return h ? h->last_kernel_ms() : -1.0; }
+
+int fbstab_hip_dense_query(fbstab_dense_handle_t h, long long* scratch_bytes, int* lds_bytes,
+                           int* workgroups, int* threads) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  if (scratch_bytes) *scratch_bytes = h->scratch_bytes;
+  if (lds_bytes) *lds_bytes = h->lds_bytes;
+  if (workgroups) *workgroups = h->workgroups;
+  if (threads) *threads = h->threads;
+  return FBSTAB_HIP_OK;
+}
+
+}  // extern "C"

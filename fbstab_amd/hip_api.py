@@ -1,0 +1,285 @@
+"""ctypes binding of libfbstab_hip.so (the C-ABI in include/fbstab_hip.h).
+
+This is plumbing for the Python tests and ``bench.py``: it passes raw pointers
+(numpy host arrays or torch CUDA tensors) to the C entry points and adds no
+computation of its own.  There is no fallback: if the shared library is missing
+or no HIP device is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfbstab_hip.so")
+
+MPC_SEQ = ("Q", "R", "S", "q", "r", "A", "B", "c", "E", "L", "d", "x0")
+DENSE_ARR = ("H", "f", "G", "h", "A", "b")
+
+HOST_POINTERS = 0
+DEVICE_POINTERS = 1
+ASYNC = 2
+
+EXIT_FLAGS = {0: "SUCCESS", 1: "DIVERGENCE", 2: "MAXITERATIONS", 3: "PRIMAL_INFEASIBLE",
+              4: "DUAL_INFEASIBLE", 5: "PRIMAL_DUAL_INFEASIBLE", 6: "SATURATE_ERROR"}
+
+
+class Options(C.Structure):
+    """fbstab_options_t (include/fbstab_types.h) == AlgorithmParameters
+    (fbstab/fbstab_algorithm.h:48-82)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "sigma0", "sigma_max", "sigma_min", "alpha", "beta", "eta", "delta",
+        "gamma", "abs_tol", "rel_tol", "stall_tol", "infeas_tol",
+        "inner_tol_max", "inner_tol_min")] + [(n, C.c_int) for n in (
+            "max_newton_iters", "max_prox_iters", "max_inner_iters",
+            "max_linesearch_iters", "check_feasibility",
+            "nonmonotone_linesearch", "display_level", "reserved")]
+
+
+def DefaultOptions(**kw) -> Options:
+    """FBstabMpc::DefaultOptions / FBstabDense::DefaultOptions
+    (fbstab_algorithm-impl.h:33-59); display is FINAL there, the batch path
+    never prints so the field is carried but unused."""
+    o = Options(1e-8, 1e-6, 1e-12, 0.95, 0.75, 1e-8, 0.2, 0.1, 1e-6, 1e-12, 1e-10,
+                1e-8, 1e-2, 1e-12, 200, 30, 50, 20, 1, 1, 1, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def ReliableOptions(**kw) -> Options:
+    """ReliableOptions (fbstab_algorithm-impl.h:61-74)."""
+    o = DefaultOptions(sigma0=1e-4, sigma_max=1e-2, sigma_min=1e-10, beta=0.9,
+                       abs_tol=1e-4, rel_tol=1e-6, max_linesearch_iters=40,
+                       max_newton_iters=500, max_prox_iters=100,
+                       nonmonotone_linesearch=0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+OUT_DTYPE = np.dtype([("eflag", np.int32), ("pad_", np.int32),
+                      ("residual", np.float64), ("newton_iters", np.int32),
+                      ("prox_iters", np.int32), ("solve_time", np.float64),
+                      ("initial_residual", np.float64)])
+assert OUT_DTYPE.itemsize == 40
+
+
+class _MpcBatch(C.Structure):
+    _fields_ = [("base", C.c_void_p * 12), ("stride", C.c_longlong * 12)]
+
+
+class _DenseBatch(C.Structure):
+    _fields_ = [("base", C.c_void_p * 6), ("stride", C.c_longlong * 6)]
+
+
+class _VarBatch(C.Structure):
+    _fields_ = [("base", C.c_void_p * 4), ("stride", C.c_longlong * 4)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libfbstab_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C fbstab_amd/csrc` "
+            "(__graft_entry__.build()); fbstab_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.fbstab_hip_last_error.restype = C.c_char_p
+    for kind in ("mpc", "dense"):
+        getattr(lib, f"fbstab_hip_{kind}_last_kernel_ms").restype = C.c_double
+        getattr(lib, f"fbstab_hip_{kind}_last_kernel_ms").argtypes = [C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_destroy").argtypes = [C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_set_options").argtypes = [C.c_void_p, C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_get_options").argtypes = [C.c_void_p, C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_solve_batch").argtypes = [
+            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_query").argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
+    lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "fbstab_hip_last_error", "fbstab_hip_device_count",
+    "fbstab_hip_mpc_create", "fbstab_hip_mpc_destroy", "fbstab_hip_mpc_set_options",
+    "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch",
+    "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query",
+    "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
+    "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch",
+    "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
+
+
+class FBstabHipError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws (fbstab_mpc.cc:62-65,
+    fbstab_mpc.h:229-242, ...)."""
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise FBstabHipError(f"[{rc}] {lib.fbstab_hip_last_error().decode()}")
+
+
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr_stride(a, length: int):
+    """(pointer, batch stride in doubles, is_device) of a (batch, length) array."""
+    if _is_torch(a):
+        import torch
+        assert a.dtype == torch.float64 and a.dim() == 2 and a.shape[1] == length, \
+            (a.shape, length)
+        assert a.stride(1) == 1 or length <= 1
+        return a.data_ptr(), (a.stride(0) if a.shape[0] > 1 else length), a.is_cuda
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 2 \
+        and a.shape[1] == length, (getattr(a, "shape", None), length)
+    assert a.strides[1] == 8 or length <= 1
+    return a.ctypes.data, (a.strides[0] // 8 if a.shape[0] > 1 else length), False
+
+
+class _SolverBase:
+    _kind = ""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._lib = load_library()
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            getattr(self._lib, f"fbstab_hip_{self._kind}_destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def UpdateOptions(self, options: Options):
+        _check(self._lib, getattr(self._lib, f"fbstab_hip_{self._kind}_set_options")(
+            self._h, C.byref(options)))
+
+    def CurrentOptions(self) -> Options:
+        o = Options()
+        _check(self._lib, getattr(self._lib, f"fbstab_hip_{self._kind}_get_options")(
+            self._h, C.byref(o)))
+        return o
+
+    def last_kernel_ms(self) -> float:
+        return float(getattr(self._lib, f"fbstab_hip_{self._kind}_last_kernel_ms")(self._h))
+
+    def query(self) -> Dict[str, int]:
+        sb, lds, wg, th = C.c_longlong(), C.c_int(), C.c_int(), C.c_int()
+        _check(self._lib, getattr(self._lib, f"fbstab_hip_{self._kind}_query")(
+            self._h, C.byref(sb), C.byref(lds), C.byref(wg), C.byref(th)))
+        return dict(scratch_bytes=sb.value, lds_bytes=lds.value, workgroups=wg.value,
+                    threads=th.value)
+
+    def _solve(self, batch_struct, names: Sequence[str], lens: Sequence[int], arrays,
+               var_lens, z, l, v, y, out, stream, async_):
+        dev_flags = []
+        B = None
+        for i, (k, n) in enumerate(zip(names, lens)):
+            a = arrays[k]
+            if n == 0:
+                batch_struct.base[i] = None
+                batch_struct.stride[i] = 0
+                continue
+            p, s, d = _ptr_stride(a, n)
+            batch_struct.base[i] = p
+            batch_struct.stride[i] = s
+            dev_flags.append(d)
+            B = a.shape[0] if B is None else B
+        vb = _VarBatch()
+        for i, (a, n) in enumerate(zip((z, l, v, y), var_lens)):
+            if n == 0:
+                vb.base[i] = None
+                vb.stride[i] = 0
+                continue
+            p, s, d = _ptr_stride(a, n)
+            assert a.shape[0] == B
+            vb.base[i] = p
+            vb.stride[i] = s
+            dev_flags.append(d)
+        on_dev = all(dev_flags)
+        assert on_dev or not any(dev_flags), "mix of host and device arrays"
+        if on_dev:
+            import torch
+            if out is None:
+                out = torch.zeros((B, 40), dtype=torch.uint8, device=z.device)
+            out_ptr = out.data_ptr()
+            flags = DEVICE_POINTERS | (ASYNC if async_ else 0)
+        else:
+            if out is None:
+                out = np.zeros(B, dtype=OUT_DTYPE)
+            out_ptr = out.ctypes.data
+            flags = HOST_POINTERS
+        rc = getattr(self._lib, f"fbstab_hip_{self._kind}_solve_batch")(
+            self._h, B, C.byref(batch_struct), C.byref(vb), out_ptr, flags,
+            C.c_void_p(stream) if stream else None)
+        _check(self._lib, rc)
+        return out
+
+
+def out_to_numpy(out) -> np.ndarray:
+    """SolverOut records (numpy structured array) from a solve's ``out``."""
+    if _is_torch(out):
+        return np.frombuffer(out.cpu().numpy().tobytes(), dtype=OUT_DTYPE).copy()
+    return out
+
+
+class FBstabMpcBatch(_SolverBase):
+    """Batched counterpart of ``fbstab::FBstabMpc`` (fbstab/fbstab_mpc.h:56-243):
+    ``FBstabMpcBatch(N, nx, nu, nc, max_batch)`` allocates the device workspace
+    (the reference constructor allocates the CPU workspace, fbstab_mpc.cc:61-89)
+    and ``Solve`` solves a batch in the reference data layout."""
+    _kind = "mpc"
+
+    def __init__(self, N: int, nx: int, nu: int, nc: int, max_batch: int = 1,
+                 device: int = 0):
+        super().__init__()
+        _check(self._lib, self._lib.fbstab_hip_mpc_create(
+            N, nx, nu, nc, max_batch, device, C.byref(self._h)))
+        self.N, self.nx, self.nu, self.nc = N, nx, nu, nc
+        self.nz, self.nl, self.nv = (N + 1) * (nx + nu), (N + 1) * nx, (N + 1) * nc
+        self.seq_len = [(N + 1) * nx * nx, (N + 1) * nu * nu, (N + 1) * nu * nx,
+                        (N + 1) * nx, (N + 1) * nu, N * nx * nx, N * nx * nu, N * nx,
+                        (N + 1) * nc * nx, (N + 1) * nc * nu, (N + 1) * nc, nx]
+
+    def Solve(self, data: Dict[str, object], z, l, v, y, out=None, stream: int = 0,
+              async_: bool = False):
+        """``data``: dict of the 12 sequences, each ``(batch, len)`` float64
+        (all numpy, or all torch CUDA tensors); ``z,l,v``: initial guess,
+        overwritten with the solution, ``y`` overwritten (fbstab_mpc.h:181-195)."""
+        return self._solve(_MpcBatch(), MPC_SEQ, self.seq_len, data,
+                           (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
+                           stream, async_)
+
+
+class FBstabDenseBatch(_SolverBase):
+    """Batched counterpart of ``fbstab::FBstabDense`` (fbstab/fbstab_dense.h:50-194)."""
+    _kind = "dense"
+
+    def __init__(self, nz: int, nl: int, nv: int, max_batch: int = 1, device: int = 0):
+        super().__init__()
+        _check(self._lib, self._lib.fbstab_hip_dense_create(
+            nz, nl, nv, max_batch, device, C.byref(self._h)))
+        self.nz, self.nl, self.nv = nz, nl, nv
+        self.arr_len = [nz * nz, nz, nl * nz, nl, nv * nz, nv]
+
+    def Solve(self, data: Dict[str, object], z, l, v, y, out=None, stream: int = 0,
+              async_: bool = False):
+        return self._solve(_DenseBatch(), DENSE_ARR, self.arr_len, data,
+                           (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
+                           stream, async_)

@@ -1,0 +1,137 @@
+/*
+ * C-ABI of the MI355X-native batched FBstab solver (libfbstab_hip.so).
+ *
+ * This is the drop-in boundary for the reference's inner-loop path: one call
+ * solves a whole batch of QPs with the FBstab algorithm running entirely on
+ * the GPU (one QP per workgroup).  Each entry point names the reference
+ * interface it stands in for (paths relative to dliaomcp/fbstab):
+ *
+ *   fbstab_hip_mpc_create / _destroy    FBstabMpc::FBstabMpc(N,nx,nu,nc) / dtor
+ *                                       fbstab/fbstab_mpc.h:165, fbstab_mpc.cc:61-89
+ *   fbstab_hip_mpc_set_options          FBstabMpc::UpdateOptions, fbstab_mpc.h:202,
+ *                                       fbstab_mpc.cc:96-100 (-> UpdateParameters +
+ *                                       ValidateOptions, fbstab_algorithm-impl.h:307-332)
+ *   fbstab_hip_mpc_solve_batch          FBstabMpc::Solve(qp, &x), fbstab_mpc.h:181-195
+ *                                       (batch == 1 with host pointers is exactly one
+ *                                       reference Solve call)
+ *   fbstab_hip_dense_create / _destroy  FBstabDense::FBstabDense(nz,nl,nv),
+ *                                       fbstab/fbstab_dense.h:122, fbstab_dense.cc:18-42
+ *   fbstab_hip_dense_set_options        FBstabDense::UpdateOptions, fbstab_dense.h:158
+ *   fbstab_hip_dense_solve_batch        FBstabDense::Solve(qp, &x), fbstab_dense.h:136-149
+ *
+ * Data layout is the reference's: every MPC sequence is a MatrixSequence image
+ * data[k*nr*nc + j*nr + i] (tools/matrix_sequence.h:81-83), dense matrices are
+ * column-major (Eigen::MatrixXd).  A batch is described by one base pointer
+ * and one stride (in doubles) per array: QP b lives at base + b*stride, so both
+ * "array of structures" (all sequences of a QP contiguous) and "structure of
+ * arrays" placements work, and a stride of 0 shares an array across the batch.
+ *
+ * Error behaviour: no exception crosses this boundary.  Functions return
+ * FBSTAB_HIP_OK or an error code and fbstab_hip_last_error() describes the
+ * failure (the C++ facade in include/fbstab/ turns these into the
+ * std::runtime_error the reference throws).  Per-QP outcomes are reported in
+ * fbstab_solver_out_t::eflag; a per-QP factorisation failure, where the
+ * reference would throw out of Solve (fbstab_algorithm-impl.h:263-274), is
+ * reported as FBSTAB_DIVERGENCE for that QP only.
+ *
+ * There is no CPU execution path in this library: without a usable HIP device
+ * every create call fails with FBSTAB_HIP_ERR_DEVICE.
+ */
+#ifndef FBSTAB_HIP_H_
+#define FBSTAB_HIP_H_
+
+#include "fbstab_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum fbstab_hip_status {
+  FBSTAB_HIP_OK = 0,
+  FBSTAB_HIP_ERR_ARGUMENT = 1,    /* null pointer, non-positive size, batch > max_batch */
+  FBSTAB_HIP_ERR_DEVICE = 2,      /* HIP runtime error / no device */
+  FBSTAB_HIP_ERR_UNSUPPORTED = 3  /* problem does not fit the on-chip budget */
+};
+
+/* Where the caller's arrays live, and whether the call may return before the
+ * GPU has finished (device memory only; the caller then syncs the stream). */
+enum fbstab_hip_flags {
+  FBSTAB_HIP_HOST_POINTERS = 0,
+  FBSTAB_HIP_DEVICE_POINTERS = 1,
+  FBSTAB_HIP_ASYNC = 2
+};
+
+/* Index of each MPC sequence in fbstab_mpc_batch_t (FBstabMpc::ProblemData
+ * member order, fbstab/fbstab_mpc.h:67-81). */
+enum fbstab_mpc_seq {
+  FBSTAB_MPC_Q = 0, FBSTAB_MPC_R, FBSTAB_MPC_S, FBSTAB_MPC_q, FBSTAB_MPC_r,
+  FBSTAB_MPC_A, FBSTAB_MPC_B, FBSTAB_MPC_c, FBSTAB_MPC_E, FBSTAB_MPC_L,
+  FBSTAB_MPC_d, FBSTAB_MPC_x0, FBSTAB_MPC_NSEQ
+};
+
+/* Index of each dense array (FBstabDense::ProblemData, fbstab_dense.h:55-64). */
+enum fbstab_dense_arr {
+  FBSTAB_DENSE_H = 0, FBSTAB_DENSE_f, FBSTAB_DENSE_G, FBSTAB_DENSE_h,
+  FBSTAB_DENSE_A, FBSTAB_DENSE_b, FBSTAB_DENSE_NARR
+};
+
+typedef struct fbstab_mpc_batch_t {
+  const double* base[FBSTAB_MPC_NSEQ];
+  long long stride[FBSTAB_MPC_NSEQ]; /* doubles between consecutive QPs */
+} fbstab_mpc_batch_t;
+
+typedef struct fbstab_dense_batch_t {
+  const double* base[FBSTAB_DENSE_NARR];
+  long long stride[FBSTAB_DENSE_NARR];
+} fbstab_dense_batch_t;
+
+/* Initial guess in (z, l, v), solution out (z, l, v, y); y is ignored on input
+ * (FBstabMpc::Variable, fbstab_mpc.h:126-136; fbstab_algorithm-impl.h:334-347). */
+typedef struct fbstab_var_batch_t {
+  double* base[4];       /* z, l, v, y */
+  long long stride[4];
+} fbstab_var_batch_t;
+
+typedef struct fbstab_mpc_solver* fbstab_mpc_handle_t;
+typedef struct fbstab_dense_solver* fbstab_dense_handle_t;
+
+const char* fbstab_hip_last_error(void);
+int fbstab_hip_device_count(void);
+
+/* ---- MPC ---------------------------------------------------------------- */
+int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int device,
+                          fbstab_mpc_handle_t* handle);
+int fbstab_hip_mpc_destroy(fbstab_mpc_handle_t handle);
+int fbstab_hip_mpc_set_options(fbstab_mpc_handle_t handle, const fbstab_options_t* options);
+int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t handle, fbstab_options_t* options);
+/* stream: a hipStream_t, or NULL for the handle's own stream. */
+int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t handle, int batch,
+                               const fbstab_mpc_batch_t* data, const fbstab_var_batch_t* x,
+                               fbstab_solver_out_t* out, int flags, void* stream);
+/* Device time of the solver kernel in the most recent solve_batch call on this
+ * handle, measured with HIP events on the stream it ran on (ms; < 0 if none). */
+double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t handle);
+/* Bytes of device scratch and of LDS per workgroup the handle uses, and the
+ * number of resident workgroups it launches (for DESIGN.md / diagnostics). */
+int fbstab_hip_mpc_query(fbstab_mpc_handle_t handle, long long* scratch_bytes,
+                         int* lds_bytes, int* workgroups, int* threads);
+
+/* ---- dense -------------------------------------------------------------- */
+int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
+                            fbstab_dense_handle_t* handle);
+int fbstab_hip_dense_destroy(fbstab_dense_handle_t handle);
+int fbstab_hip_dense_set_options(fbstab_dense_handle_t handle, const fbstab_options_t* options);
+int fbstab_hip_dense_get_options(fbstab_dense_handle_t handle, fbstab_options_t* options);
+int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t handle, int batch,
+                                 const fbstab_dense_batch_t* data,
+                                 const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                 int flags, void* stream);
+double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t handle);
+int fbstab_hip_dense_query(fbstab_dense_handle_t handle, long long* scratch_bytes,
+                           int* lds_bytes, int* workgroups, int* threads);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FBSTAB_HIP_H_ */

@@ -1,0 +1,66 @@
+"""CPU-only checks of the C-ABI library: it is built for gfx950, loads, exports
+every symbol include/fbstab_hip.h declares, and shares its POD layouts with the
+reference structs.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fbstab_amd import hip_api
+    if not os.path.exists(hip_api.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fbstab_amd", "csrc")])
+    return hip_api.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "fbstab_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fbstab_hip_\w+)\s*\(", hdr))
+    from fbstab_amd import hip_api
+    assert declared == set(hip_api.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_pod_layouts_match_reference_structs():
+    from fbstab_amd import hip_api
+    from oracle import oracle_py
+    # SolverOut{ExitFlag; double; int; int; double; double} = 40 bytes on LP64
+    assert C.sizeof(oracle_py.SolverOut) == 40 == hip_api.OUT_DTYPE.itemsize
+    assert hip_api.OUT_DTYPE.fields["residual"][1] == 8
+    assert hip_api.OUT_DTYPE.fields["newton_iters"][1] == 16
+    assert hip_api.OUT_DTYPE.fields["solve_time"][1] == 24
+    assert C.sizeof(hip_api.Options) == 14 * 8 + 8 * 4 == C.sizeof(oracle_py.Options)
+
+
+def test_library_is_gfx950_only_and_has_no_cpu_path(lib):
+    """The code object targets gfx950; with no GPU every create call fails
+    loudly instead of falling back."""
+    from fbstab_amd import hip_api
+    blob = open(hip_api.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    syms = subprocess.run(["nm", "-D", hip_api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "fbo_" not in syms and "hostsim" not in syms  # oracle / host simulation not linked in
+    if lib.fbstab_hip_device_count() == 0:
+        h = C.c_void_p()
+        rc = lib.fbstab_hip_mpc_create(30, 12, 4, 20, 8, 0, C.byref(h))
+        assert rc == 2 and not h.value
+        assert b"no HIP device" in lib.fbstab_hip_last_error()
+        with pytest.raises(hip_api.FBstabHipError):
+            hip_api.FBstabDenseBatch(2, 0, 2)
+
+
+def test_argument_validation_without_gpu(lib):
+    h = C.c_void_p()
+    assert lib.fbstab_hip_mpc_create(0, 2, 1, 6, 1, 0, C.byref(h)) == 1
+    assert b"problem sizes must be positive" in lib.fbstab_hip_last_error()
+    assert lib.fbstab_hip_dense_create(2, -1, 2, 1, 0, C.byref(h)) == 1
+    assert lib.fbstab_hip_mpc_create(30, 12, 4, 20, 0, 0, C.byref(h)) == 1
+    assert lib.fbstab_hip_mpc_create(30, 80, 4, 20, 1, 0, C.byref(h)) == 3  # nx > 64

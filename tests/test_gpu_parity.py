@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path, called through the C-ABI
+(include/fbstab_hip.h), against the CPU oracle on identical inputs.
+
+Parity definition (the reference defines none for
+iteration counts): for every instance the exit flag and the proximal
+iteration count are equal; Newton iteration counts are equal for >= 99 % of
+instances and differ by at most 2 otherwise; both residuals meet the
+tolerance; ||x_gpu - x_cpu||_inf <= 10*abs_tol*(1 + ||x_cpu||_inf).
+All arithmetic is FP64 on both sides."""
+import numpy as np
+import pytest
+
+from fbstab_amd import fixtures as fx
+from oracle.oracle_py import default_options, reliable_options
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from fbstab_amd import hip_api
+    hip_api.load_library()
+    assert hip_api.load_library().fbstab_hip_device_count() >= 1
+    return hip_api
+
+
+def _opts(hip, o):
+    """oracle Options -> hip_api Options (same POD)."""
+    h = hip.Options()
+    for name, _ in h._fields_:
+        setattr(h, name, getattr(o, name))
+    return h
+
+
+def _solve_mpc_host(hip, p, opts, guess=None):
+    s = hip.FBstabMpcBatch(*p.sizes(), max_batch=p.batch)
+    s.UpdateOptions(_opts(hip, opts))
+    B = p.batch
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.full((B, p.nv), 7.0)
+    if guess is not None:
+        z[:], l[:], v[:] = guess
+    data = {k: np.ascontiguousarray(a) for k, a in p.arrays.items()}
+    out = s.Solve(data, z, l, v, y)
+    s.close()
+    return z, l, v, y, out
+
+
+def _solve_dense_host(hip, p, opts, guess=None):
+    s = hip.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=p.batch)
+    s.UpdateOptions(_opts(hip, opts))
+    B = p.batch
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.full((B, p.nv), 7.0)
+    if guess is not None:
+        z[:], l[:], v[:] = guess
+    data = {k: np.ascontiguousarray(a) for k, a in p.arrays.items()}
+    out = s.Solve(data, z, l, v, y)
+    s.close()
+    return z, l, v, y, out
+
+
+def _assert_parity(gpu, cpu, abs_tol, exact_frac=0.99):
+    zg, lg, vg, yg, og = gpu
+    zc, lc, vc, yc, oc = cpu
+    assert np.array_equal(og["eflag"], oc["eflag"])
+    assert np.array_equal(og["prox_iters"], oc["prox_iters"])
+    dn = np.abs(og["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
+    assert dn.max() <= 2, dn.max()
+    assert (dn == 0).mean() >= exact_frac or len(dn) < 100 and (dn != 0).sum() <= 1, (dn != 0).sum()
+    for g, c in ((zg, zc), (lg, lc), (vg, vc), (yg, yc)):
+        if c.size:
+            scale = 1.0 + np.abs(c).max(axis=1, keepdims=True)
+            assert (np.abs(g - c) <= 10 * abs_tol * scale).all(), np.abs(g - c).max()
+    ok = oc["eflag"] == 0
+    np.testing.assert_allclose(og["initial_residual"], oc["initial_residual"], rtol=1e-10)
+    # residuals agree where they are well above rounding
+    big = ok & (oc["residual"] > 1e-9)
+    if big.any():
+        np.testing.assert_allclose(og["residual"][big], oc["residual"][big], rtol=1e-3)
+
+
+# -- reference end-to-end tests through the C-ABI ------------------------------
+@pytest.mark.parametrize("idx", range(5))
+def test_dense_reference_tests(hip, oracle, kats, idx):
+    """fbstab/test/fbstab_dense_unit_tests.cc:28-256."""
+    k = kats["dense_end_to_end"][idx]
+    p = H.dense_from_kat(k)
+    o = default_options(abs_tol=k["abs_tol"])
+    z, l, v, y, out = _solve_dense_host(hip, p, o)
+    assert out["eflag"][0] == k["eflag"]
+    if "zopt" in k:
+        np.testing.assert_allclose(z[0], k["zopt"], atol=k["tol"], rtol=0)
+    if "vopt" in k:
+        np.testing.assert_allclose(v[0], k["vopt"], atol=k["tol"], rtol=0)
+    if "z0" in k:
+        assert abs(z[0, 0] - k["z0"]) <= k["tol"]
+        assert k["z1_range"][0] <= z[0, 1] <= k["z1_range"][1]
+        Hm, f, G, h, A, b = H.dense_explicit(p)
+        assert (np.linalg.norm(Hm @ z[0] + f + A.T @ v[0]) +
+                np.linalg.norm(np.minimum(y[0], v[0]))) <= k["kkt_tol"]
+    cpu = oracle.solve_dense(p, opts=o)
+    assert out["newton_iters"][0] == cpu[4]["newton_iters"][0]
+    assert out["prox_iters"][0] == cpu[4]["prox_iters"][0]
+    if k["eflag"] in (3, 4):  # certificates: same direction up to scale/rounding
+        for g, c in ((z, cpu[0]), (v, cpu[2])):
+            np.testing.assert_allclose(g, c, rtol=1e-6, atol=1e-6 * (1 + np.abs(c).max()))
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_mpc_reference_tests(hip, oracle, kats, idx):
+    """fbstab/test/fbstab_mpc_unit_tests.cc:15-148."""
+    k = kats["mpc_end_to_end"][idx]
+    p = H.mpc_from_kat(k)
+    o = default_options(abs_tol=k["abs_tol"])
+    gpu = _solve_mpc_host(hip, p, o)
+    z, l, v, y, out = gpu
+    assert out["eflag"][0] == k["eflag"]
+    assert out["residual"][0] <= k["residual_max"]
+    if "zopt" in k:
+        np.testing.assert_allclose(z[0], k["zopt"], atol=k["tol"], rtol=0)
+        np.testing.assert_allclose(l[0], k["lopt"], atol=k["tol"], rtol=0)
+        np.testing.assert_allclose(v[0], k["vopt"], atol=k["tol"], rtol=0)
+    Hm, f, G, h, A, b = H.mpc_explicit(p)
+    assert H.natural_residual_norm(Hm, f, G, h, A, b, z[0], l[0], v[0]) <= 1e-6
+    np.testing.assert_allclose(y[0], b - A @ z[0], atol=1e-9)
+    cpu = oracle.solve_mpc(p, opts=o)
+    assert out["prox_iters"][0] == cpu[4]["prox_iters"][0]
+    assert abs(int(out["newton_iters"][0]) - int(cpu[4]["newton_iters"][0])) <= 2
+
+
+# -- BASELINE.json workloads ----------------------------------------------------
+def test_mpc_synthetic_batch_parity(hip, oracle):
+    p = fx.synthetic_mpc_batch(256)
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+    assert (gpu[4]["residual"] <= o.abs_tol + o.rel_tol * 100).all()
+
+
+def test_dense_synthetic_batch_parity(hip, oracle):
+    for (nz, nl, nv, B) in ((20, 5, 40, 64), (50, 10, 100, 256)):
+        p = fx.synthetic_dense_batch(B, nz, nl, nv)
+        o = default_options()
+        gpu = _solve_dense_host(hip, p, o)
+        cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+        _assert_parity(gpu, cpu, o.abs_tol)
+        assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
+
+
+def test_mpc_device_pointers_match_host_pointers(hip):
+    import torch
+    p = fx.synthetic_mpc_batch(64, first_id=1000)
+    o = default_options()
+    host = _solve_mpc_host(hip, p, o)
+    dev = torch.device("cuda:0")
+    s = hip.FBstabMpcBatch(*p.sizes(), max_batch=64)
+    # one packed record per QP (array-of-structures): strides differ from lengths
+    rec = np.concatenate([p.arrays[k] for k in hip.MPC_SEQ], axis=1)
+    rec_t = torch.from_numpy(rec).to(dev)
+    data, off = {}, 0
+    for k in hip.MPC_SEQ:
+        n = p.arrays[k].shape[1]
+        data[k] = rec_t[:, off:off + n]
+        off += n
+    z = torch.zeros((64, p.nz), dtype=torch.float64, device=dev)
+    l = torch.zeros((64, p.nl), dtype=torch.float64, device=dev)
+    v = torch.zeros((64, p.nv), dtype=torch.float64, device=dev)
+    y = torch.zeros((64, p.nv), dtype=torch.float64, device=dev)
+    out = hip.out_to_numpy(s.Solve(data, z, l, v, y))
+    assert s.last_kernel_ms() > 0
+    assert np.array_equal(out["newton_iters"], host[4]["newton_iters"])
+    assert np.array_equal(z.cpu().numpy(), host[0])
+    assert np.array_equal(v.cpu().numpy(), host[2])
+
+
+# -- edge cases -----------------------------------------------------------------
+def test_warm_start_and_iteration_limits(hip, oracle):
+    p = fx.synthetic_mpc_batch(8, first_id=77)
+    o = default_options()
+    cold = _solve_mpc_host(hip, p, o)
+    warm = _solve_mpc_host(hip, p, o, guess=(cold[0], cold[1], cold[2]))
+    cpu_warm = oracle.solve_mpc(p, (cold[0], cold[1], cold[2]), opts=o)
+    assert (warm[4]["newton_iters"] <= 2).all()
+    assert np.array_equal(warm[4]["newton_iters"], cpu_warm[4]["newton_iters"])
+    assert np.array_equal(warm[4]["eflag"], cpu_warm[4]["eflag"])
+    # iteration limit: MAXITERATIONS, returns the better of xi/xk
+    o2 = default_options(max_newton_iters=3)
+    g = _solve_mpc_host(hip, p, o2)
+    c = oracle.solve_mpc(p, opts=o2)
+    assert (g[4]["eflag"] == 2).all() and np.array_equal(g[4]["eflag"], c[4]["eflag"])
+    assert np.array_equal(g[4]["newton_iters"], c[4]["newton_iters"])
+    np.testing.assert_allclose(g[0], c[0], atol=1e-7 * (1 + np.abs(c[0]).max()))
+    np.testing.assert_allclose(g[4]["residual"], c[4]["residual"], rtol=1e-6)
+    # prox limit
+    o3 = default_options(max_prox_iters=1)
+    g = _solve_mpc_host(hip, p, o3)
+    c = oracle.solve_mpc(p, opts=o3)
+    assert np.array_equal(g[4]["eflag"], c[4]["eflag"])
+    np.testing.assert_allclose(g[4]["residual"], c[4]["residual"], rtol=1e-5, atol=1e-12)
+
+
+def test_reliable_options_and_no_feasibility_check(hip, oracle):
+    p = fx.synthetic_dense_batch(32, 20, 5, 40, first_id=9)
+    for o in (reliable_options(), default_options(check_feasibility=0),
+              default_options(nonmonotone_linesearch=0, abs_tol=1e-9)):
+        gpu = _solve_dense_host(hip, p, o)
+        cpu = oracle.solve_dense(p, opts=o)
+        _assert_parity(gpu, cpu, max(o.abs_tol, 1e-8))
+
+
+def test_mixed_outcome_batch(hip, oracle, kats):
+    """A batch mixing solvable, primal-infeasible and unbounded QPs keeps
+    per-QP outcomes independent (2 variables, 5 constraints each)."""
+    ks = kats["dense_end_to_end"]
+    deg, inf = H.dense_from_kat(ks[2]), H.dense_from_kat(ks[3])
+    p = fx.DenseProblem(2, 0, 5)
+    p.arrays = {k: np.concatenate([deg.arrays[k], inf.arrays[k], deg.arrays[k], inf.arrays[k]])
+                for k in deg.arrays}
+    o = default_options(abs_tol=1e-8)
+    gpu = _solve_dense_host(hip, p, o)
+    cpu = oracle.solve_dense(p, opts=o)
+    assert gpu[4]["eflag"].tolist() == [0, 3, 0, 3] == cpu[4]["eflag"].tolist()
+    assert np.array_equal(gpu[4]["newton_iters"], cpu[4]["newton_iters"])
+
+
+def test_error_behaviour(hip):
+    """Constructor / size validation errors of the reference
+    (fbstab_mpc.cc:62-65, fbstab_dense.cc:19-23, fbstab_mpc.h:229-242)."""
+    with pytest.raises(hip.FBstabHipError):
+        hip.FBstabMpcBatch(0, 2, 1, 6)
+    with pytest.raises(hip.FBstabHipError):
+        hip.FBstabDenseBatch(2, -1, 2)
+    s = hip.FBstabDenseBatch(2, 0, 2, max_batch=1)
+    p = fx.synthetic_dense_batch(2, 2, 0, 2)
+    z = np.zeros((2, 2)); l = np.zeros((2, 0)); v = np.zeros((2, 2)); y = np.zeros((2, 2))
+    with pytest.raises(hip.FBstabHipError):  # batch > max_batch
+        s.Solve(p.arrays, z, l, v, y)
+    o = hip.DefaultOptions(alpha=7.0, max_newton_iters=-4)
+    s.UpdateOptions(o)
+    cur = s.CurrentOptions()
+    assert cur.alpha == 0.999 and cur.max_newton_iters == 1  # ValidateOptions clamps
+
+
+def test_full_size_properties(hip):
+    """BASELINE config 3 at full batch (8192): every QP converges to the
+    tolerance; KKT conditions verified independently on a sample; solving the
+    same batch twice is bitwise reproducible; instance ids key the data."""
+    import torch
+    B = 8192
+    p = fx.synthetic_mpc_batch(B)
+    dev = torch.device("cuda:0")
+    s = hip.FBstabMpcBatch(*p.sizes(), max_batch=B)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+    z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    out = hip.out_to_numpy(s.Solve(data, z, l, v, y))
+    assert (out["eflag"] == 0).all()
+    assert (out["residual"] <= 1e-6 + 1e-10).all()
+    assert 5 <= out["newton_iters"].min() and out["newton_iters"].max() <= 60
+    zc, lc, vc = z.cpu().numpy(), l.cpu().numpy(), v.cpu().numpy()
+    for b in (0, 1, 4095, 8191):
+        Hm, f, G, h, A, bb = H.mpc_explicit(p, b)
+        assert H.natural_residual_norm(Hm, f, G, h, A, bb, zc[b], lc[b], vc[b]) <= 2e-6
+        assert (vc[b] >= 0).all() and (bb - A @ zc[b] >= -1e-6).all()
+    z2, l2, v2, y2 = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    out2 = hip.out_to_numpy(s.Solve(data, z2, l2, v2, y2))
+    assert torch.equal(z, z2) and torch.equal(v, v2)
+    assert np.array_equal(out["newton_iters"], out2["newton_iters"])
