@@ -47,8 +47,20 @@ struct Ctx {
 
   static constexpr int nt = NT;
 
+  // Workgroup barrier.  A single-wavefront workgroup only needs its LDS
+  // traffic ordered (lanes run in lockstep and the wave's global-memory
+  // operations stay in program order), so it waits on lgkmcnt alone and leaves
+  // global loads/stores in flight; __syncthreads() would drain vmcnt too.
   FB_DEV void sync() const {
 #if !defined(FB_HOSTSIM)
+#if !defined(FB_NO_WAVE_SYNC)
+    if (NT <= 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      return;
+    }
+#endif
     __syncthreads();
 #endif
   }

@@ -55,8 +55,11 @@ __device__ __forceinline__ int next_qp(int* counter, lds_ptr slot) {
   }
 }
 
+#ifndef FB_MPC_MIN_WAVES
+#define FB_MPC_MIN_WAVES 1
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void fbstab_mpc_kernel(MpcLayout lay, MpcBatchArgs data,
+__global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLayout lay, MpcBatchArgs data,
                                                         VarBatchArgs x,
                                                         fbstab_solver_out_t* out,
                                                         fbstab_options_t opts, double* scratch,

@@ -14,7 +14,7 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfbstab_hip.so")
+LIB_PATH = os.environ.get("FBSTAB_HIP_LIB", os.path.join(_HERE, "libfbstab_hip.so"))
 
 MPC_SEQ = ("Q", "R", "S", "q", "r", "A", "B", "c", "E", "L", "d", "x0")
 DENSE_ARR = ("H", "f", "G", "h", "A", "b")
@@ -92,6 +92,13 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C fbstab_amd/csrc` "
             "(__graft_entry__.build()); fbstab_amd has no CPU fallback")
+    # torch (device memory / streams / torch.distributed plumbing) bundles its
+    # own HIP runtime: import it first so this process ends up with ONE
+    # libamdhip64 (loading ours first makes torch see "No HIP GPUs").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.fbstab_hip_last_error.restype = C.c_char_p
     for kind in ("mpc", "dense"):

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Developer tool: time the MPC kernel of one build variant
+(FBSTAB_HIP_LIB=<so>, FBSTAB_HIP_WGS_PER_CU=<n>) on the BASELINE workload and
+print kernel ms, QPs/s and a checksum of the iteration counts."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from fbstab_amd import fixtures as fx, hip_api  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+p = fx.synthetic_mpc_batch(B)
+dev = torch.device("cuda:0")
+s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B)
+data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+ms = []
+for r in range(reps + 1):
+    z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    out = hip_api.out_to_numpy(s.Solve(data, z, l, v, y))
+    ms.append(s.last_kernel_ms())
+q = s.query()
+print(f"{os.environ.get('FBSTAB_HIP_LIB', 'default'):>40s} wgs/cu={os.environ.get('FBSTAB_HIP_WGS_PER_CU', 'auto'):>4s} "
+      f"wgs={q['workgroups']:5d} lds={q['lds_bytes']:6d} kernel_ms={min(ms[1:]):9.2f} "
+      f"QP/s={B / (min(ms[1:]) * 1e-3):10.0f} ok={(out['eflag'] == 0).all()} "
+      f"newton_sum={int(out['newton_iters'].sum())} zsum={float(z.abs().sum()):.9e}")
