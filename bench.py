@@ -9,7 +9,11 @@ One "step" = one fbstab_hip_mpc_solve_batch call over the rank's whole shard
 (cold start, zero initial guess), problem data already resident in HBM.  For
 N > 1 the batch is sharded by global instance id (weak scaling, 8192 QPs per
 GPU) and each step ends with one RCCL gather of the solutions to rank 0.
-Rank 0 prints ONE JSON line.
+Consecutive steps are issued on --pipeline (default 2) alternating HIP streams,
+each with its own solver handle and output buffers, the way a stream of
+batches is served: iteration counts differ 10x between QPs, so the tail of
+one batch (a few slow QPs) overlaps the bulk of the next.  --pipeline 1
+serialises the steps.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -62,6 +66,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8192, help="QPs per GPU")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="steps in flight (alternating streams/handles); 1 = serial")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="QPs for the CPU baseline (0 disables; default sized for ~15 s)")
     args = ap.parse_args()
@@ -85,46 +91,68 @@ def main():
     torch.cuda.set_device(dev)
 
     B = args.batch
+    P = max(1, args.pipeline)
     p = fx.synthetic_mpc_batch(B, first_id=rank * B)  # shard by global instance id
-    solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B, device=local_rank)
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
     nvar = p.nz + p.nl + 2 * p.nv
-    # z, l, v, y side by side in one record per QP so the gather is one buffer
-    x = torch.zeros((B, nvar), dtype=torch.float64, device=dev)
-    z, l = x[:, :p.nz], x[:, p.nz:p.nz + p.nl]
-    v, y = x[:, p.nz + p.nl:p.nz + p.nl + p.nv], x[:, p.nz + p.nl + p.nv:]
-    out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
-    gx = go = None
-    if world > 1 and rank == 0:
-        gx = [torch.empty_like(x) for _ in range(world)]
-        go = [torch.empty_like(out) for _ in range(world)]
-    stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        x.zero_()
-        solver.Solve(data, z, l, v, y, out=out, stream=stream)
-        ms = solver.last_kernel_ms()
-        if world > 1:
-            dist.gather(x, gx, dst=0)
-            dist.gather(out, go, dst=0)
-        return ms
+    class Lane:
+        """One pipeline lane: solver handle (own device scratch), stream, outputs."""
+
+        def __init__(self):
+            self.solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B, device=local_rank)
+            self.stream = torch.cuda.Stream(device=dev)
+            # z, l, v, y side by side in one record per QP so the gather is one buffer
+            self.x = torch.zeros((B, nvar), dtype=torch.float64, device=dev)
+            self.z, self.l = self.x[:, :p.nz], self.x[:, p.nz:p.nz + p.nl]
+            self.v = self.x[:, p.nz + p.nl:p.nz + p.nl + p.nv]
+            self.y = self.x[:, p.nz + p.nl + p.nv:]
+            self.out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
+            self.gx = self.go = None
+            if world > 1 and rank == 0:
+                self.gx = [torch.empty_like(self.x) for _ in range(world)]
+                self.go = [torch.empty_like(self.out) for _ in range(world)]
+            self.events = []
+
+    lanes = [Lane() for _ in range(P)]
+
+    def step(k, timed):
+        ln = lanes[k % P]
+        with torch.cuda.stream(ln.stream):
+            ln.x.zero_()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(ln.stream)
+            ln.solver.Solve(data, ln.z, ln.l, ln.v, ln.y, out=ln.out,
+                            stream=ln.stream.cuda_stream, async_=True)
+            e1.record(ln.stream)
+            if timed:
+                ln.events.append((e0, e1))
+            if world > 1:
+                dist.gather(ln.x, ln.gx, dst=0)
+                dist.gather(ln.out, ln.go, dst=0)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k, False)
     fence()
     t0 = time.perf_counter()
-    kernel_ms = [step() for _ in range(args.steps)]
+    for k in range(args.steps):
+        step(k, True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    kernel_ms = [e0.elapsed_time(e1) for ln in lanes for (e0, e1) in ln.events]
+    solver = lanes[0].solver
+    out = lanes[(args.steps - 1) % P].out
 
     o = hip_api.out_to_numpy(out)
     ok = bool((o["eflag"] == 0).all())
@@ -141,7 +169,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: batched FBstabMpc, batch=8192 per GPU, "
                                    "N=30 nx=12 nu=4 nc=20, cold start, default options",
-                       "batch_per_gpu": B, "global_batch": world * B,
+                       "batch_per_gpu": B, "global_batch": world * B, "steps_in_flight": P,
                        "parallelism": f"batch sharded over {world} GPU(s)" +
                                       (", RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -114,19 +114,80 @@ struct Solver {
   // the linear solver could not factor (the reference throws, impl:263-274).
   FB_DEV double subproblem(double tol, double sigma, double Ek, int* newton_iters,
                            double* rk_last, bool* fail) const {
+    if constexpr (P::kFusedTrial) {
+      return subproblem_fused(tol, sigma, Ek, newton_iters, rk_last, fail);
+    } else {
+      double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      double Eo = 0.0;
+      FB_STAMP_DECL;
+      for (int i = 0; i < o.max_inner_iters; i++) {
+        double Ei;
+        norms_at(0.0, sigma, true, &Ei, &Eo);
+        *rk_last = Eo;
+        if ((Ei <= tol && Eo < Ek) || (Ei <= o.inner_tol_min)) break;
+        if (*newton_iters >= o.max_newton_iters) break;
+        FB_STAMP_LAP(16);
+        if (!p.newton_step(c, sigma, o.alpha)) {
+          *fail = true;
+          return Eo;
+        }
+        (*newton_iters)++;
+        FB_STAMP_LAP(17);
+        const double cm = 0.5 * Ei * Ei;
+        merit[4] = merit[3];
+        merit[3] = merit[2];
+        merit[2] = merit[1];
+        merit[1] = merit[0];
+        merit[0] = cm;
+        double m0 = cm;
+        if (o.nonmonotone_linesearch) {
+          for (int k = 1; k < 5; k++) m0 = merit[k] > m0 ? merit[k] : m0;
+        }
+        double t = 1.0;
+        for (int j = 0; j < o.max_linesearch_iters; j++) {
+          double Et, unused;
+          norms_at(t, sigma, false, &Et, &unused);
+          const double mp = 0.5 * Et * Et;
+          if (mp <= m0 - 2.0 * t * o.eta * cm) break;
+          t *= o.beta;
+        }
+        accept(t);
+        FB_STAMP_LAP(18);
+      }
+      // ProjectDuals (impl:301, full_variable.cc:75)
+      for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
+      c.sync();
+      return Eo;
+    }
+  }
+
+  // The same loop for policies whose newton_step also returns the residual
+  // norms of the full step (the first line-search trial) and applies an
+  // accepted step lazily (P::pend_t / P::flush): in the common case, t = 1
+  // accepted, a Newton iteration costs no pass over the iterate vectors beyond
+  // the two stage sweeps of newton_step, and the loop-top norms of the next
+  // iteration are the accepted trial's norms.
+  FB_DEV double subproblem_fused(double tol, double sigma, double Ek, int* newton_iters,
+                                 double* rk_last, bool* fail) const {
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    double Eo = 0.0;
+    double Ei, Eo;
+    FB_STAMP_DECL;
+    norms_at(0.0, sigma, true, &Ei, &Eo);
+    double Eo_top = Eo;
     for (int i = 0; i < o.max_inner_iters; i++) {
-      double Ei;
-      norms_at(0.0, sigma, true, &Ei, &Eo);
+      Eo_top = Eo;
       *rk_last = Eo;
       if ((Ei <= tol && Eo < Ek) || (Ei <= o.inner_tol_min)) break;
       if (*newton_iters >= o.max_newton_iters) break;
-      if (!p.newton_step(c, sigma, o.alpha)) {
+      FB_STAMP_LAP(16);
+      double ti2, to2;
+      if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2)) {
         *fail = true;
         return Eo;
       }
       (*newton_iters)++;
+      FB_STAMP_LAP(17);
+      FB_STAMP_COUNT(31);
       const double cm = 0.5 * Ei * Ei;
       merit[4] = merit[3];
       merit[3] = merit[2];
@@ -137,20 +198,31 @@ struct Solver {
       if (o.nonmonotone_linesearch) {
         for (int k = 1; k < 5; k++) m0 = merit[k] > m0 ? merit[k] : m0;
       }
+      // impl:283-297: trial j = 0 at t = 1 came with the Newton step
       double t = 1.0;
+      double Et = sqrt(ti2), Eot = sqrt(to2);
+      bool known = true;  // (Et, Eot) belong to the current t
       for (int j = 0; j < o.max_linesearch_iters; j++) {
-        double Et, unused;
-        norms_at(t, sigma, false, &Et, &unused);
+        if (j > 0) {
+          FB_STAMP_COUNT(30);
+          norms_at(t, sigma, true, &Et, &Eot);
+          known = true;
+        }
         const double mp = 0.5 * Et * Et;
         if (mp <= m0 - 2.0 * t * o.eta * cm) break;
         t *= o.beta;
+        known = false;
       }
-      accept(t);
+      if (!known) norms_at(t, sigma, true, &Et, &Eot);  // t = beta^max_ls is applied untested
+      p.pend_t = t;
+      Ei = Et;
+      Eo = Eot;
+      FB_STAMP_LAP(18);
     }
-    // ProjectDuals (impl:301, full_variable.cc:75)
+    p.flush(c);
     for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
     c.sync();
-    return Eo;
+    return Eo_top;
   }
 
   // FBstabAlgorithm::Solve (impl:113-224).

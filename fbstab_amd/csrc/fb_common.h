@@ -29,6 +29,34 @@ namespace fbk {
 
 typedef FB_LDS double* lds_ptr;
 
+// In-kernel phase timing for diagnostic builds (-DFB_STAMP): per-phase shader
+// cycles summed over all waves into g_stamps (read with
+// fbstab_hip_debug_stamps).  Production builds compile the macro away.
+#if defined(FB_STAMP) && !defined(FB_HOSTSIM)
+extern __device__ unsigned long long g_stamps[32];
+struct StampClock {
+  unsigned long long t0;
+  __device__ __forceinline__ void start() { t0 = now(); }
+  static __device__ __forceinline__ unsigned long long now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  }
+  __device__ __forceinline__ void lap(int k) {
+    const unsigned long long t = now();
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], t - t0);
+    t0 = now();
+  }
+};
+#define FB_STAMP_DECL StampClock fb_clk_; fb_clk_.start()
+#define FB_STAMP_LAP(k) fb_clk_.lap(k)
+#define FB_STAMP_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], 1ull); } while (0)
+#else
+#define FB_STAMP_DECL
+#define FB_STAMP_LAP(k)
+#define FB_STAMP_COUNT(k)
+#endif
+
 // Maximum number of values reduced together by one block_reduce call.
 constexpr int kMaxReduce = 12;
 

@@ -54,6 +54,7 @@ struct DenseLayout {
 
 template <class C>
 struct DenseProblem {
+  static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   DenseLayout lay;
   DenseData D;
   double *uz, *ul, *uv, *uy;

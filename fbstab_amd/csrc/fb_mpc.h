@@ -71,6 +71,11 @@ struct MpcLayout {
     f_tu = o; o += nu;
     f_th = o; o += nx;
     f_stride = (o + 1) & ~1;
+    // the 16-lane register kernel (fb_mpc_g16.h) keeps a larger record
+    if (nx + nu <= 16) {
+      const int g16 = 512 + 16 * nx + 32;
+      if (g16 > f_stride) f_stride = g16;
+    }
     long g = 0;
     v_z = g; g += nz;  v_l = g; g += nl;  v_v = g; g += nv;  v_y = g; g += nv;
     v_zb = g; g += nz; v_lb = g; g += nl; v_vb = g; g += nv; v_yb = g; g += nv;
@@ -101,6 +106,7 @@ struct MpcLayout {
 
 template <class C>
 struct MpcProblem {
+  static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   MpcLayout lay;
   MpcData D;
   double *uz, *ul, *uv, *uy;  // caller's (z,l,v,y) for this QP

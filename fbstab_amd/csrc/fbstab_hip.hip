@@ -18,6 +18,11 @@
 #include "fb_algorithm.h"
 #include "fb_dense.h"
 #include "fb_mpc.h"
+#include "fb_mpc_g16.h"
+
+#if defined(FB_STAMP)
+namespace fbk { __device__ unsigned long long g_stamps[32]; }
+#endif
 
 namespace {
 
@@ -55,15 +60,72 @@ __device__ __forceinline__ int next_qp(int* counter, lds_ptr slot) {
   }
 }
 
+// Diagnostic probe (tests only): one Newton step at (x, xbar, sigma) instead of
+// a solve.  dbg holds [zb, lb, vb] on input and receives
+// [dz, dl, dv, adz, wz, wl, rz, rl, ok].
+template <class P, class C>
+__device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_options_t& opts, double* dbg) {
+  p.load_guess(ctx);
+  const int nz = p.nz, nl = p.nl, nv = p.nv;
+  for (int i = ctx.tid; i < nz; i += C::nt) p.zb[i] = dbg[i];
+  for (int i = ctx.tid; i < nl; i += C::nt) p.lb[i] = dbg[nz + i];
+  for (int i = ctx.tid; i < nv; i += C::nt) p.vb[i] = dbg[nz + nl + i];
+  ctx.sync();
+  p.residual(ctx);
+  bool ok;
+  if constexpr (P::kFusedTrial) {
+    double a, b;
+    ok = p.newton_step(ctx, opts.sigma0, opts.alpha, &a, &b);
+  } else {
+    ok = p.newton_step(ctx, opts.sigma0, opts.alpha);
+  }
+  ctx.sync();
+  double* o = dbg;
+  for (int i = ctx.tid; i < nz; i += C::nt) o[i] = p.dz[i];
+  o += nz;
+  for (int i = ctx.tid; i < nl; i += C::nt) o[i] = p.dl[i];
+  o += nl;
+  for (int i = ctx.tid; i < nv; i += C::nt) o[i] = p.dv[i];
+  o += nv;
+  for (int i = ctx.tid; i < nv; i += C::nt) o[i] = p.adz[i];
+  o += nv;
+  for (int i = ctx.tid; i < nz; i += C::nt) o[i] = p.wz[i];
+  o += nz;
+  for (int i = ctx.tid; i < nl; i += C::nt) o[i] = p.wl[i];
+  o += nl;
+  for (int i = ctx.tid; i < nz; i += C::nt) o[i] = p.rz[i];
+  o += nz;
+  for (int i = ctx.tid; i < nl; i += C::nt) o[i] = p.rl[i];
+  o += nl;
+  if (ctx.tid == 0) o[0] = ok ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ MpcData mpc_data_of(const MpcBatchArgs& data, long q) {
+  MpcData D;
+  D.Q = data.base[FBSTAB_MPC_Q] + q * data.stride[FBSTAB_MPC_Q];
+  D.R = data.base[FBSTAB_MPC_R] + q * data.stride[FBSTAB_MPC_R];
+  D.S = data.base[FBSTAB_MPC_S] + q * data.stride[FBSTAB_MPC_S];
+  D.q = data.base[FBSTAB_MPC_q] + q * data.stride[FBSTAB_MPC_q];
+  D.r = data.base[FBSTAB_MPC_r] + q * data.stride[FBSTAB_MPC_r];
+  D.A = data.base[FBSTAB_MPC_A] + q * data.stride[FBSTAB_MPC_A];
+  D.B = data.base[FBSTAB_MPC_B] + q * data.stride[FBSTAB_MPC_B];
+  D.c = data.base[FBSTAB_MPC_c] + q * data.stride[FBSTAB_MPC_c];
+  D.E = data.base[FBSTAB_MPC_E] + q * data.stride[FBSTAB_MPC_E];
+  D.L = data.base[FBSTAB_MPC_L] + q * data.stride[FBSTAB_MPC_L];
+  D.d = data.base[FBSTAB_MPC_d] + q * data.stride[FBSTAB_MPC_d];
+  D.x0 = data.base[FBSTAB_MPC_x0] + q * data.stride[FBSTAB_MPC_x0];
+  return D;
+}
+
 #ifndef FB_MPC_MIN_WAVES
 #define FB_MPC_MIN_WAVES 1
 #endif
-template <int NT>
+template <int NT, bool DBG>
 __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLayout lay, MpcBatchArgs data,
                                                         VarBatchArgs x,
                                                         fbstab_solver_out_t* out,
                                                         fbstab_options_t opts, double* scratch,
-                                                        int* counter, int batch) {
+                                                        int* counter, int batch, double* dbg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   lds_ptr lds = (lds_ptr)smem;
   typedef Ctx<NT> C;
@@ -74,24 +136,50 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
   for (;;) {
     const int q = next_qp<NT>(counter, lds + lay.w_out);
     if (q >= batch) break;
-    MpcData D;
-    D.Q = data.base[FBSTAB_MPC_Q] + q * data.stride[FBSTAB_MPC_Q];
-    D.R = data.base[FBSTAB_MPC_R] + q * data.stride[FBSTAB_MPC_R];
-    D.S = data.base[FBSTAB_MPC_S] + q * data.stride[FBSTAB_MPC_S];
-    D.q = data.base[FBSTAB_MPC_q] + q * data.stride[FBSTAB_MPC_q];
-    D.r = data.base[FBSTAB_MPC_r] + q * data.stride[FBSTAB_MPC_r];
-    D.A = data.base[FBSTAB_MPC_A] + q * data.stride[FBSTAB_MPC_A];
-    D.B = data.base[FBSTAB_MPC_B] + q * data.stride[FBSTAB_MPC_B];
-    D.c = data.base[FBSTAB_MPC_c] + q * data.stride[FBSTAB_MPC_c];
-    D.E = data.base[FBSTAB_MPC_E] + q * data.stride[FBSTAB_MPC_E];
-    D.L = data.base[FBSTAB_MPC_L] + q * data.stride[FBSTAB_MPC_L];
-    D.d = data.base[FBSTAB_MPC_d] + q * data.stride[FBSTAB_MPC_d];
-    D.x0 = data.base[FBSTAB_MPC_x0] + q * data.stride[FBSTAB_MPC_x0];
     MpcProblem<C> p;
-    p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
+    p.bind(lay, mpc_data_of(data, q), x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
            x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
-    Solver<MpcProblem<C>, C> solver(p, ctx, opts);
-    solver.solve(out + q);
+    if constexpr (DBG) {
+      newton_probe(p, ctx, opts, dbg);
+    } else {
+      Solver<MpcProblem<C>, C> solver(p, ctx, opts);
+      solver.solve(out + q);
+    }
+    ctx.sync();
+  }
+}
+
+
+#ifndef FB_G16_MIN_WAVES
+#define FB_G16_MIN_WAVES 2
+#endif
+// Four QPs per wavefront, one per 16-lane DPP row (fb_mpc_g16.h).  Rows run
+// the solver loop independently (SIMT divergence between rows) and pull QP
+// indices from the shared counter.
+template <int NX, int NU, int NC, bool DBG>
+__global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
+    MpcLayout lay, MpcBatchArgs data, VarBatchArgs x, fbstab_solver_out_t* out,
+    fbstab_options_t opts, double* scratch, int* counter, int batch, int lds_per_row, double* dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x, row = lane >> 4;
+  lds_ptr lds = (lds_ptr)smem + row * lds_per_row;
+  Ctx16 ctx;
+  ctx.tid = lane & 15;
+  double* ws = scratch + ((long)blockIdx.x * 4 + row) * lay.ws_doubles;
+  for (;;) {
+    int q = 0;
+    if (ctx.tid == 0) q = atomicAdd(counter, 1);
+    q = bci<0>(q);
+    if (q >= batch) break;
+    MpcProblemG16<NX, NU, NC> p;
+    p.bind(lay, mpc_data_of(data, q), x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
+           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
+    if constexpr (DBG) {
+      newton_probe(p, ctx, opts, dbg);
+    } else {
+      Solver<MpcProblemG16<NX, NU, NC>, Ctx16> solver(p, ctx, opts);
+      solver.solve(out + q);
+    }
     ctx.sync();
   }
 }
@@ -261,7 +349,26 @@ int check_common(const void* handle, int batch, const void* data, const fbstab_v
 
 struct fbstab_mpc_solver : SolverBase {
   fbk::MpcLayout lay;
+  bool g16 = false;       // 16-lane register kernel (four QPs per wavefront)
+  int lds_per_row = 0;
+  int qps_per_wg = 1;
 };
+
+namespace {
+// The specialised shapes compiled into the library.
+bool g16_shape(int nx, int nu, int nc) { return nx == 12 && nu == 4 && nc == 20; }
+
+template <class... A>
+void launch_mpc(fbstab_mpc_solver* h, int grid, hipStream_t s, A... args) {
+  if (h->g16) {
+    hipLaunchKernelGGL((fbstab_mpc_g16_kernel<12, 4, 20, false>), dim3(grid), dim3(64), h->lds_bytes, s,
+                       args..., h->lds_per_row, (double*)nullptr);
+  } else {
+    hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, false>), dim3(grid), dim3(h->threads), h->lds_bytes, s,
+                       args..., (double*)nullptr);
+  }
+}
+}  // namespace
 struct fbstab_dense_solver : SolverBase {
   fbk::DenseLayout lay;
 };
@@ -290,19 +397,31 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   s->threads = kMpcThreads;
   s->lay.init(N, nx, nu, nc, s->threads);
   s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
+  const char* force_generic = getenv("FBSTAB_HIP_GENERIC");
+  s->g16 = g16_shape(nx, nu, nc) && !(force_generic && atoi(force_generic) > 0);
+  if (s->g16) {
+    int d = s->lay.w_sb;  // tile + stage slices of the generic passes
+    if (d < fbk::MpcProblemG16<12, 4, 20>::kLdsDoubles) d = fbk::MpcProblemG16<12, 4, 20>::kLdsDoubles;
+    // region stride == 16 doubles mod 32 (bank placement, see fb_mpc_g16.h)
+    s->lds_per_row = ((d + 31) & ~31) + 16;
+    s->qps_per_wg = 4;
+    s->lds_bytes = 4 * s->lds_per_row * (int)sizeof(double);
+  }
   if (nx > s->threads || s->lds_bytes > kLdsLimitBytes) {
     delete s;
     return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "stage matrices do not fit the 160 KiB LDS budget");
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  auto kern = fbstab_mpc_kernel<kMpcThreads>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  const void* kern = s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, false>)
+                           : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>);
+  const void* kern_dbg = s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, true>)
+                               : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>);
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute(kern_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0, cus = 0;
   if (e == hipSuccess)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern),
-                                                     s->threads, s->lds_bytes);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, s->threads, s->lds_bytes);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -315,8 +434,11 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   const char* env = getenv("FBSTAB_HIP_WGS_PER_CU");
   if (env && atoi(env) > 0) per_cu = atoi(env);
   s->workgroups = cus * per_cu;
-  if (s->workgroups > max_batch) s->workgroups = max_batch;
-  s->scratch_bytes = (long long)s->lay.ws_doubles * sizeof(double) * s->workgroups;
+  {
+    const int need = (max_batch + s->qps_per_wg - 1) / s->qps_per_wg;
+    if (s->workgroups > need) s->workgroups = need;
+  }
+  s->scratch_bytes = (long long)s->lay.ws_doubles * sizeof(double) * s->workgroups * s->qps_per_wg;
   e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
   if (e != hipSuccess) {
     s->release(); delete s;
@@ -395,10 +517,10 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mp
     d_out = h->d_out;
   }
   HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
-  int grid = h->workgroups < batch ? h->workgroups : batch;
+  int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
+  if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(fbstab_mpc_kernel<kMpcThreads>, dim3(grid), dim3(h->threads), h->lds_bytes, s,
-                     h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
+  launch_mpc(h, grid, s, h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
@@ -415,6 +537,70 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mp
   } else if (!(flags & FBSTAB_HIP_ASYNC)) {
     HIP_TRY(hipStreamSynchronize(s));
   }
+  return FBSTAB_HIP_OK;
+}
+
+// Diagnostics for the tests: one Newton step of the device path at (x, xbar,
+// sigma0) for ONE QP given by host pointers.  io holds [zb, lb, vb] on input
+// and [dz, dl, dv, adz, wz, wl, rz, rl, ok] on output
+// (2*nz + 2*nl + 2*nv + nz + nl + 1 doubles).
+int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t* data,
+                                const fbstab_var_batch_t* x, double* io) {
+  if (!h || !data || !x || !io) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = h->ensure_staging();
+  if (rc != FBSTAB_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  MpcBatchArgs a;
+  VarBatchArgs v;
+  for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) {
+    rc = h->upload(data->base[i], h->arr_len[i], h->arr_len[i], 1, h->d_arr[i], &a.stride[i], s);
+    if (rc != FBSTAB_HIP_OK) return rc;
+    a.base[i] = h->d_arr[i];
+  }
+  for (int i = 0; i < 4; i++) {
+    long long st;
+    if (i < 3) {
+      rc = h->upload(x->base[i], h->var_len[i], h->var_len[i], 1, h->d_var[i], &st, s);
+      if (rc != FBSTAB_HIP_OK) return rc;
+    }
+    v.base[i] = h->d_var[i];
+    v.stride[i] = h->var_len[i];
+  }
+  const fbk::MpcLayout& L = h->lay;
+  const size_t n_io = (size_t)(3 * L.nz + 3 * L.nl + 2 * L.nv + 1);
+  double* d_io = nullptr;
+  HIP_TRY(hipMalloc(&d_io, n_io * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(d_io, io, sizeof(double) * (L.nz + L.nl + L.nv), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
+  if (h->g16) {
+    hipLaunchKernelGGL((fbstab_mpc_g16_kernel<12, 4, 20, true>), dim3(1), dim3(64), h->lds_bytes, s, h->lay, a, v,
+                       h->d_out, h->opts, h->scratch, h->counter, 1, h->lds_per_row, d_io);
+  } else {
+    hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, true>), dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a,
+                       v, h->d_out, h->opts, h->scratch, h->counter, 1, d_io);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(io, d_io, sizeof(double) * n_io, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipFree(d_io));
+  return FBSTAB_HIP_OK;
+}
+
+// Diagnostic builds (-DFB_STAMP): per-phase shader cycles summed over waves;
+// zeros otherwise.  reset != 0 clears the counters after reading.
+int fbstab_hip_debug_stamps(unsigned long long* out32, int reset) {
+  if (!out32) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  memset(out32, 0, 32 * sizeof(unsigned long long));
+#if defined(FB_STAMP)
+  HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(fbk::g_stamps), 32 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[32] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(fbk::g_stamps), z, sizeof(z)));
+  }
+#else
+  (void)reset;
+#endif
   return FBSTAB_HIP_OK;
 }
 

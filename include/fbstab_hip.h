@@ -116,6 +116,16 @@ double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t handle);
 int fbstab_hip_mpc_query(fbstab_mpc_handle_t handle, long long* scratch_bytes,
                          int* lds_bytes, int* workgroups, int* threads);
 
+/* Diagnostics used by the parity tests: runs ONE Newton step of the device path
+ * (LinearSolver::Initialize + Solve of the reference, abstract_components.h:291-338)
+ * for a single QP given by host pointers.  io: [zbar, lbar, vbar] in,
+ * [dz, dl, dv, A*dz, W_z, W_l, r_z, r_l, ok] out. */
+int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t handle, const fbstab_mpc_batch_t* data,
+                                const fbstab_var_batch_t* x, double* io);
+
+/* Diagnostic builds only (-DFB_STAMP): in-kernel per-phase cycle counters. */
+int fbstab_hip_debug_stamps(unsigned long long* out32, int reset);
+
 /* ---- dense -------------------------------------------------------------- */
 int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
                             fbstab_dense_handle_t* handle);

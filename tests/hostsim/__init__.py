@@ -18,7 +18,7 @@ def build():
                     for f in ("fb_common.h", "fb_algorithm.h", "fb_mpc.h", "fb_dense.h")]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared",
                            "-ffp-contract=off", "-o", _SO, src])
 
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Developer tool: per-phase cycle shares of the MPC kernel from a -DFB_STAMP
+build (FBSTAB_HIP_LIB=fbstab_amd/var_stamp.so).  argv: batch [wgs_per_cu]."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from fbstab_amd import fixtures as fx, hip_api  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+p = fx.synthetic_mpc_batch(B)
+dev = torch.device("cuda:0")
+s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=max(B, 8192))
+data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+lib = hip_api.load_library()
+st = (C.c_ulonglong * 32)()
+for rep in range(2):
+    z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    lib.fbstab_hip_debug_stamps(st, 1)
+    out = hip_api.out_to_numpy(s.Solve(data, z, l, v, y))
+    ms = s.last_kernel_ms()
+lib.fbstab_hip_debug_stamps(st, 1)
+newton = max(int(st[31]), 1)   # newton steps executed by row 0 of each wave
+stages = newton * 31
+print("backtracking trials per newton step (row 0):", st[30] / newton)
+names = {0: "fwd loads+pfb", 1: "K build", 2: "rhs/h", 3: "chol16", 4: "tri_inv16", 5: "transpose+t+stores",
+         6: "AB load + W", 7: "WW'", 8: "chol12+T+Pinv", 9: "bwd solve", 10: "bwd post+trial",
+         16: "loop top", 17: "newton_step total", 18: "linesearch"}
+print(f"batch={B} kernel_ms={ms:.2f} newton_total={newton} q={s.query()}")
+for k in sorted(names):
+    per = st[k] / stages if k < 16 else st[k] / newton
+    unit = "cyc/stage" if k < 16 else "cyc/newton-iter"
+    print(f"   [{k:2d}] {names[k]:22s} {per:12.0f} {unit}")

@@ -28,3 +28,13 @@ print(f"{os.environ.get('FBSTAB_HIP_LIB', 'default'):>40s} wgs/cu={os.environ.ge
       f"wgs={q['workgroups']:5d} lds={q['lds_bytes']:6d} kernel_ms={min(ms[1:]):9.2f} "
       f"QP/s={B / (min(ms[1:]) * 1e-3):10.0f} ok={(out['eflag'] == 0).all()} "
       f"newton_sum={int(out['newton_iters'].sum())} zsum={float(z.abs().sum()):.9e}")
+import ctypes as C
+st = (C.c_ulonglong * 32)()
+hip_api.load_library().fbstab_hip_debug_stamps(st, 1)
+if any(st):
+    tot = sum(st[:11])
+    names = {0: "loads+pfb", 1: "K build", 2: "rhs/h", 3: "chol16", 4: "tri_inv16", 5: "transpose+t+stores",
+             6: "AB load + W", 7: "WW'", 8: "chol12+T+Pinv", 9: "bwd stage", 10: "post stage",
+             16: "norms(top)", 17: "newton_step total", 18: "linesearch+accept"}
+    for k in sorted(names):
+        print(f"   stamp[{k:2d}] {names[k]:22s} {st[k]:16d}  {100.0 * st[k] / max(tot, 1):6.2f}% of newton_step")
