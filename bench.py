@@ -26,6 +26,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# One hardware queue per pipeline stream (HIP maps streams onto a small pool of
+# queues; two streams on one queue cannot overlap their kernels).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ALG_BYTES_PER_QP = 217736      # data 188,928 + guess 11,904 + solution 16,864 + SolverOut 40
 FLOP_PER_NEWTON = 0.94e6       # SURVEY.md 8(d), survey-derived flop model
@@ -92,7 +95,9 @@ def main():
 
     B = args.batch
     P = max(1, args.pipeline)
-    p = fx.synthetic_mpc_batch(B, first_id=rank * B)  # shard by global instance id
+    from fbstab_amd import sharding
+    first_id, _ = sharding.shard_range(rank, world, B)
+    p = fx.synthetic_mpc_batch(B, first_id=first_id)  # shard by global instance id
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
     nvar = p.nz + p.nl + 2 * p.nv
 

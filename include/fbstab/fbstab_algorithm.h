@@ -1,0 +1,155 @@
+// ExitFlag, SolverOut, Display and AlgorithmParameters with the reference's
+// names, members and defaults (fbstab/fbstab_algorithm.h:17-82,
+// fbstab_algorithm-impl.h:7-74), bridging to the plain-C types of the C-ABI.
+#pragma once
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "../fbstab_types.h"
+
+namespace fbstab {
+
+enum class ExitFlag {
+  SUCCESS = 0,
+  DIVERGENCE = 1,
+  MAXITERATIONS = 2,
+  PRIMAL_INFEASIBLE = 3,
+  DUAL_INFEASIBLE = 4,
+  PRIMAL_DUAL_INFEASIBLE = 5
+};
+
+struct SolverOut {
+  ExitFlag eflag = ExitFlag::MAXITERATIONS;
+  double residual = 0.0;
+  int newton_iters = 0;
+  int prox_iters = 0;
+  double solve_time = 0.0;  // seconds
+  double initial_residual = 0.0;
+};
+
+enum class Display { OFF = 0, FINAL = 1, ITER = 2, ITER_DETAILED = 3 };
+
+// In-class initialisers are the reference header's (fbstab_algorithm.h:49-74);
+// the effective defaults are DefaultParameters() (impl:33-59), which every
+// solver constructor applies, exactly as in the reference.
+struct AlgorithmParameters {
+  double sigma0 = 1e-8;
+  double sigma_max = 1e-8;
+  double sigma_min = 1e-10;
+  double alpha = 0.95;
+  double beta = 0.7;
+  double eta = 1e-8;
+  double delta = 1.0 / 5.0;
+  double gamma = 1.0 / 10.0;
+  double abs_tol = 1e-6;
+  double rel_tol = 1e-12;
+  double stall_tol = 1e-10;
+  double infeas_tol = 1e-8;
+  double inner_tol_max = 1e-1;
+  double inner_tol_min = 1e-12;
+  int max_newton_iters = 500;
+  int max_prox_iters = 100;
+  int max_inner_iters = 100;
+  int max_linesearch_iters = 20;
+  bool check_feasibility = true;
+  bool nonmonotone_linesearch = true;
+  Display display_level = Display::FINAL;
+
+  fbstab_options_t ToC() const {
+    fbstab_options_t o;
+    o.sigma0 = sigma0; o.sigma_max = sigma_max; o.sigma_min = sigma_min; o.alpha = alpha;
+    o.beta = beta; o.eta = eta; o.delta = delta; o.gamma = gamma; o.abs_tol = abs_tol;
+    o.rel_tol = rel_tol; o.stall_tol = stall_tol; o.infeas_tol = infeas_tol;
+    o.inner_tol_max = inner_tol_max; o.inner_tol_min = inner_tol_min;
+    o.max_newton_iters = max_newton_iters; o.max_prox_iters = max_prox_iters;
+    o.max_inner_iters = max_inner_iters; o.max_linesearch_iters = max_linesearch_iters;
+    o.check_feasibility = check_feasibility ? 1 : 0;
+    o.nonmonotone_linesearch = nonmonotone_linesearch ? 1 : 0;
+    o.display_level = static_cast<int>(display_level);
+    o.reserved = 0;
+    return o;
+  }
+  void FromC(const fbstab_options_t& o) {
+    sigma0 = o.sigma0; sigma_max = o.sigma_max; sigma_min = o.sigma_min; alpha = o.alpha;
+    beta = o.beta; eta = o.eta; delta = o.delta; gamma = o.gamma; abs_tol = o.abs_tol;
+    rel_tol = o.rel_tol; stall_tol = o.stall_tol; infeas_tol = o.infeas_tol;
+    inner_tol_max = o.inner_tol_max; inner_tol_min = o.inner_tol_min;
+    max_newton_iters = o.max_newton_iters; max_prox_iters = o.max_prox_iters;
+    max_inner_iters = o.max_inner_iters; max_linesearch_iters = o.max_linesearch_iters;
+    check_feasibility = o.check_feasibility != 0;
+    nonmonotone_linesearch = o.nonmonotone_linesearch != 0;
+    display_level = static_cast<Display>(o.display_level);
+  }
+  void ValidateOptions() { fbstab_options_t o = ToC(); fbstab_options_validate(&o); FromC(o); }
+  void DefaultParameters() { fbstab_options_t o; fbstab_options_default(&o); FromC(o); }
+  void ReliableParameters() { fbstab_options_t o; fbstab_options_reliable(&o); FromC(o); }
+};
+
+namespace detail {
+
+// SolverOut of the C-ABI -> reference SolverOut.  Two outcomes that the
+// reference signals by throwing out of Solve are re-thrown here:
+// FBSTAB_DIVERGENCE (factorisation failure, impl:263-274) and
+// FBSTAB_SATURATE_ERROR (tools::saturate, utilities.h:19-28).
+inline SolverOut FromC(const fbstab_solver_out_t& c) {
+  if (c.eflag == FBSTAB_DIVERGENCE)
+    throw std::runtime_error("In FBstabAlgorithm::Solve: LinearSolver::Initialize failed.");
+  if (c.eflag == FBSTAB_SATURATE_ERROR)
+    throw std::runtime_error(
+        "In tools::saturate: upper bound must be larger than the lower bound");
+  SolverOut o;
+  o.eflag = static_cast<ExitFlag>(c.eflag);
+  o.residual = c.residual;
+  o.newton_iters = c.newton_iters;
+  o.prox_iters = c.prox_iters;
+  o.solve_time = c.solve_time;
+  o.initial_residual = c.initial_residual;
+  return o;
+}
+
+// PrintFinal (impl:485-541) for Display::FINAL and above; the per-iteration
+// levels are not produced by the device path.
+template <class OutStream>
+void PrintFinal(const SolverOut& s, const AlgorithmParameters& p, const OutStream& os) {
+  if (p.display_level < Display::FINAL) return;
+  char buff[100];
+  const char* msg = " Undefined\n";
+  switch (s.eflag) {
+    case ExitFlag::SUCCESS: msg = " Success\n"; break;
+    case ExitFlag::DIVERGENCE: msg = " Divergence\n"; break;
+    case ExitFlag::MAXITERATIONS: msg = " Iteration limit exceeded\n"; break;
+    case ExitFlag::PRIMAL_INFEASIBLE: msg = " Primal Infeasibility\n"; break;
+    case ExitFlag::DUAL_INFEASIBLE: msg = " Dual Infeasibility\n"; break;
+    case ExitFlag::PRIMAL_DUAL_INFEASIBLE: msg = " Primal-Dual Infeasibility\n"; break;
+  }
+  os.Print("\nOptimization completed!  Exit code:");
+  os.Print(msg);
+  snprintf(buff, 100, "Time elapsed: %f ms (-1.0 indicates timing disabled)\n", 1000.0 * s.solve_time);
+  os.Print(buff);
+  snprintf(buff, 100, "Proximal iterations: %d out of %d\n", s.prox_iters, p.max_prox_iters);
+  os.Print(buff);
+  snprintf(buff, 100, "Newton iterations: %d out of %d\n", s.newton_iters, p.max_newton_iters);
+  os.Print(buff);
+  snprintf(buff, 100, "%10s  %10s\n", "|r|", "Tolerance");
+  os.Print(buff);
+  snprintf(buff, 100, "%10.4e  %10.4e\n\n", s.residual, p.abs_tol);
+  os.Print(buff);
+}
+
+}  // namespace detail
+
+// OutputStream / StandardOutput (tools/output_stream.h:15-37).
+template <class T>
+class OutputStream {
+ public:
+  void Print(const char* message) const { static_cast<const T*>(this)->PrintImplementation(message); }
+};
+class StandardOutput : public OutputStream<StandardOutput> {
+ protected:
+  void PrintImplementation(const char* message) const { printf("%s", message); }
+  friend class OutputStream<StandardOutput>;
+};
+
+}  // namespace fbstab

@@ -1,0 +1,162 @@
+// fbstab::FBstabDense with the reference's interface
+// (fbstab/fbstab_dense.h:50-194), backed by the MI355X library through the
+// C-ABI.  See fbstab_mpc.h for the conventions.
+#pragma once
+
+#include <stdexcept>
+#include <string>
+
+#include "../fbstab_hip.h"
+#include "dense_types.h"
+#include "fbstab_algorithm.h"
+
+namespace fbstab {
+
+class FBstabDense {
+ public:
+  FBstabDense(const FBstabDense&) = delete;
+  void operator=(const FBstabDense&) = delete;
+
+  // fbstab_dense.h:55-64, fbstab_dense.cc:44-52
+  struct ProblemData {
+    ProblemData() = default;
+    ProblemData(int nz, int nl, int nv) : H(nz, nz), G(nl, nz), A(nv, nz), f(nz), h(nl), b(nv) {}
+    MatrixXd H, G, A;
+    VectorXd f, h, b;
+  };
+  // Non-owning column-major views (the reference uses Eigen::Map).
+  struct MatRef {
+    MatRef(const double* p, int r, int c) : ptr(p), r_(r), c_(c) {}
+    const double* data() const { return ptr; }
+    int rows() const { return r_; }
+    int cols() const { return c_; }
+    double operator()(int i, int j) const { return ptr[i + static_cast<size_t>(j) * r_]; }
+    const double* ptr;
+    int r_, c_;
+  };
+  struct VecRef {
+    VecRef(double* p, int n_) : ptr(p), n(n_) {}
+    double* data() const { return ptr; }
+    int size() const { return n; }
+    double& operator()(int i) const { return ptr[i]; }
+    void fill(double a) const { for (int i = 0; i < n; i++) ptr[i] = a; }
+    double* ptr;
+    int n;
+  };
+  // fbstab_dense.h:67-82
+  struct ProblemDataRef {
+    ProblemDataRef() = delete;
+    ProblemDataRef(const MatRef* H_, const VecRef* f_, const MatRef* G_, const VecRef* h_,
+                   const MatRef* A_, const VecRef* b_)
+        : H(*H_), G(*G_), A(*A_), f(*f_), h(*h_), b(*b_) {}
+    MatRef H, G, A;
+    VecRef f, h, b;
+  };
+  // fbstab_dense.h:85-92
+  struct Variable {
+    Variable(int nz, int nl, int nv)
+        : z(VectorXd::Zero(nz)), l(VectorXd::Zero(nl)), v(VectorXd::Zero(nv)), y(VectorXd::Zero(nv)) {}
+    VectorXd z, l, v, y;
+  };
+  // fbstab_dense.h:95-107
+  struct VariableRef {
+    VariableRef() = delete;
+    VariableRef(VecRef* z_, VecRef* l_, VecRef* v_, VecRef* y_) : z(*z_), l(*l_), v(*v_), y(*y_) {}
+    void fill(double a) { z.fill(a); l.fill(a); v.fill(a); y.fill(a); }
+    VecRef z, l, v, y;
+  };
+
+  struct Options : public AlgorithmParameters {};
+
+  // fbstab_dense.cc:18-42
+  FBstabDense(int nz, int nl, int nv, int device = 0) : nz_(nz), nl_(nl), nv_(nv) {
+    if (nz < 1 || nv < 1 || nl < 0)
+      throw std::runtime_error(
+          "In FBstabDense::FBstabDense: nz and nv must be positive, nl nonnegative.");
+    if (fbstab_hip_dense_create(nz, nl, nv, 1, device, &h_) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabDense::FBstabDense: ") + fbstab_hip_last_error());
+    opts_ = DefaultOptions();
+  }
+  ~FBstabDense() { fbstab_hip_dense_destroy(h_); }
+
+  // fbstab_dense.h:136-149 (DenseData validation dense_data.h:53-66,
+  // ValidateInputs fbstab_dense.h:167-180)
+  template <class InputData, class InputVariable, class OutStream>
+  SolverOut Solve(const InputData& qp, InputVariable* x, const OutStream& os) {
+    const int fz = static_cast<int>(qp.f.size()), hz = static_cast<int>(qp.h.size()),
+              bz = static_cast<int>(qp.b.size());
+    if (qp.H.rows() != qp.H.cols() || qp.H.rows() != fz)
+      throw std::runtime_error("In DenseData::DenseData: H must be square and the same size as f");
+    if (qp.A.cols() != qp.H.rows() || qp.A.rows() != bz)
+      throw std::runtime_error("In DenseData::DenseData: Sizing of data defining Az <= b is inconsistent.");
+    if ((hz > 0 && qp.G.cols() != qp.H.rows()) || qp.G.rows() != hz)
+      throw std::runtime_error("In DenseData::DenseData: Sizing of Gz = h is inconsistent.");
+    if (nz_ != fz || nv_ != bz || nl_ != hz)
+      throw std::runtime_error("In FBstabDense::Solve: mismatch between *this and data dimensions.");
+    if (nz_ != static_cast<int>(x->z.size()) || static_cast<int>(x->l.size()) != nl_ ||
+        nv_ != static_cast<int>(x->v.size()))
+      throw std::runtime_error(
+          "In FBstabDense::Solve: mismatch between *this and initial guess dimensions.");
+    fbstab_dense_batch_t b;
+    const double* p[FBSTAB_DENSE_NARR] = {qp.H.data(), qp.f.data(), qp.G.data(),
+                                          qp.h.data(), qp.A.data(), qp.b.data()};
+    const long long len[FBSTAB_DENSE_NARR] = {(long long)nz_ * nz_, nz_, (long long)nl_ * nz_, nl_,
+                                              (long long)nv_ * nz_, nv_};
+    for (int i = 0; i < FBSTAB_DENSE_NARR; i++) { b.base[i] = p[i]; b.stride[i] = len[i]; }
+    fbstab_var_batch_t v;
+    v.base[0] = x->z.data(); v.base[1] = x->l.data(); v.base[2] = x->v.data(); v.base[3] = x->y.data();
+    v.stride[0] = nz_; v.stride[1] = nl_; v.stride[2] = nv_; v.stride[3] = nv_;
+    fbstab_solver_out_t out;
+    if (fbstab_hip_dense_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_HOST_POINTERS, nullptr) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabDense::Solve: ") + fbstab_hip_last_error());
+    SolverOut s = detail::FromC(out);
+    detail::PrintFinal(s, opts_, os);
+    return s;
+  }
+  template <class InputData, class InputVariable>
+  SolverOut Solve(const InputData& qp, InputVariable* x) {
+    StandardOutput os;
+    return Solve(qp, x, os);
+  }
+
+  void UpdateOptions(const Options& options) {
+    opts_ = options;
+    opts_.ValidateOptions();
+    fbstab_options_t o = opts_.ToC();
+    fbstab_hip_dense_set_options(h_, &o);
+  }
+  static Options DefaultOptions() { Options o; o.DefaultParameters(); return o; }
+  static Options ReliableOptions() { Options o; o.ReliableParameters(); return o; }
+
+ private:
+  int nz_, nl_, nv_;
+  Options opts_;
+  fbstab_dense_handle_t h_ = nullptr;
+};
+
+class FBstabDenseBatch {
+ public:
+  FBstabDenseBatch(const FBstabDenseBatch&) = delete;
+  void operator=(const FBstabDenseBatch&) = delete;
+  FBstabDenseBatch(int nz, int nl, int nv, int max_batch, int device = 0) {
+    if (fbstab_hip_dense_create(nz, nl, nv, max_batch, device, &h_) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabDenseBatch: ") + fbstab_hip_last_error());
+  }
+  ~FBstabDenseBatch() { fbstab_hip_dense_destroy(h_); }
+  void UpdateOptions(const FBstabDense::Options& options) {
+    FBstabDense::Options o = options;
+    o.ValidateOptions();
+    fbstab_options_t c = o.ToC();
+    fbstab_hip_dense_set_options(h_, &c);
+  }
+  void Solve(int batch, const fbstab_dense_batch_t& data, const fbstab_var_batch_t& x,
+             fbstab_solver_out_t* out, int flags = FBSTAB_HIP_HOST_POINTERS, void* stream = nullptr) {
+    if (fbstab_hip_dense_solve_batch(h_, batch, &data, &x, out, flags, stream) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabDenseBatch::Solve: ") + fbstab_hip_last_error());
+  }
+
+ private:
+  fbstab_dense_handle_t h_ = nullptr;
+};
+
+}  // namespace fbstab

@@ -1,0 +1,206 @@
+// fbstab::FBstabMpc with the reference's interface (fbstab/fbstab_mpc.h:56-243),
+// backed by the MI355X library through the C-ABI (include/fbstab_hip.h).  A
+// reference user switches by including this header instead of the reference's
+// and linking libfbstab_hip.so; ProblemData / ProblemDataRef / Variable /
+// VariableRef / Options / Solve / UpdateOptions keep their names, argument
+// meaning and error behaviour.  FBstabMpcBatch is the batched entry point this
+// library adds (one call, many QPs, host or device memory).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+
+#include "../fbstab_hip.h"
+#include "dense_types.h"
+#include "fbstab_algorithm.h"
+#include "matrix_sequence.h"
+
+namespace fbstab {
+
+class FBstabMpc {
+ public:
+  FBstabMpc(const FBstabMpc&) = delete;
+  void operator=(const FBstabMpc&) = delete;
+
+  // fbstab_mpc.h:67-81
+  struct ProblemData {
+    ProblemData() = default;
+    MatrixSequence Q, R, S, q, r, A, B, c, E, L, d;
+    VectorXd x0;
+  };
+
+  // Non-owning view of x0 (the reference uses Eigen::Map<const VectorXd>).
+  struct ConstVectorRef {
+    ConstVectorRef() : ptr(nullptr), n(0) {}
+    ConstVectorRef(const double* p, int n_) : ptr(p), n(n_) {}
+    const double* data() const { return ptr; }
+    int size() const { return n; }
+    const double* ptr;
+    int n;
+  };
+  struct VectorRef {
+    VectorRef(double* p, int n_) : ptr(p), n(n_) {}
+    double* data() const { return ptr; }
+    int size() const { return n; }
+    double& operator()(int i) const { return ptr[i]; }
+    void fill(double a) const { for (int i = 0; i < n; i++) ptr[i] = a; }
+    double* ptr;
+    int n;
+  };
+
+  // fbstab_mpc.h:90-120
+  struct ProblemDataRef {
+    ProblemDataRef() {}
+    template <class Vector>
+    void SetX0(const Vector& x0_) { x0 = ConstVectorRef(x0_.data(), static_cast<int>(x0_.size())); }
+    ProblemDataRef(const MatrixSequence* Q_, const MatrixSequence* R_, const MatrixSequence* S_,
+                   const MatrixSequence* q_, const MatrixSequence* r_, const MatrixSequence* A_,
+                   const MatrixSequence* B_, const MatrixSequence* c_, const MatrixSequence* E_,
+                   const MatrixSequence* L_, const MatrixSequence* d_, const VectorXd* x0_)
+        : Q(*Q_), R(*R_), S(*S_), q(*q_), r(*r_), A(*A_), B(*B_), c(*c_), E(*E_), L(*L_), d(*d_),
+          x0(x0_->data(), static_cast<int>(x0_->size())) {}
+    MapMatrixSequence Q, R, S, q, r, A, B, c, E, L, d;
+    ConstVectorRef x0;
+  };
+
+  // fbstab_mpc.h:126-136, fbstab_mpc.cc:38-46
+  struct Variable {
+    Variable(int N, int nx, int nu, int nc)
+        : z(VectorXd::Zero((N + 1) * (nx + nu))), l(VectorXd::Zero((N + 1) * nx)),
+          v(VectorXd::Zero((N + 1) * nc)), y(VectorXd::Zero((N + 1) * nc)) {}
+    VectorXd z, l, v, y;
+  };
+  // fbstab_mpc.h:139-150
+  struct VariableRef {
+    VariableRef(VectorRef z_, VectorRef l_, VectorRef v_, VectorRef y_) : z(z_), l(l_), v(v_), y(y_) {}
+    void fill(double a) { z.fill(a); l.fill(a); v.fill(a); y.fill(a); }
+    VectorRef z, l, v, y;
+  };
+
+  struct Options : public AlgorithmParameters {};
+
+  // fbstab_mpc.cc:61-89: allocates the (device) workspace.
+  FBstabMpc(int N, int nx, int nu, int nc, int device = 0) : N_(N), nx_(nx), nu_(nu), nc_(nc) {
+    if (N < 1 || nx < 1 || nu < 1 || nc < 1)
+      throw std::runtime_error("In FBstabMpc::FBstabMpc: problem sizes must be positive.");
+    nz_ = (nx + nu) * (N + 1);
+    nl_ = nx * (N + 1);
+    nv_ = nc * (N + 1);
+    if (fbstab_hip_mpc_create(N, nx, nu, nc, 1, device, &h_) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpc::FBstabMpc: ") + fbstab_hip_last_error());
+    opts_ = DefaultOptions();
+  }
+  ~FBstabMpc() { fbstab_hip_mpc_destroy(h_); }
+
+  // fbstab_mpc.h:181-195
+  template <class InputData, class InputVariable, class OutStream>
+  SolverOut Solve(const InputData& qp, InputVariable* x, const OutStream& os) {
+    ValidateData(qp);
+    if (x->z.size() != nz_ || x->l.size() != nl_ || x->v.size() != nv_ || x->y.size() != nv_)
+      throw std::runtime_error(
+          "In FBstabMpc::Solve: mismatch between *this and initial guess dimensions.");
+    fbstab_mpc_batch_t b;
+    const double* p[FBSTAB_MPC_NSEQ] = {qp.Q.data(), qp.R.data(), qp.S.data(), qp.q.data(),
+                                        qp.r.data(), qp.A.data(), qp.B.data(), qp.c.data(),
+                                        qp.E.data(), qp.L.data(), qp.d.data(), qp.x0.data()};
+    const int len[FBSTAB_MPC_NSEQ] = {qp.Q.size(), qp.R.size(), qp.S.size(), qp.q.size(),
+                                      qp.r.size(), qp.A.size(), qp.B.size(), qp.c.size(),
+                                      qp.E.size(), qp.L.size(), qp.d.size(),
+                                      static_cast<int>(qp.x0.size())};
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { b.base[i] = p[i]; b.stride[i] = len[i]; }
+    fbstab_var_batch_t v;
+    v.base[0] = x->z.data(); v.base[1] = x->l.data(); v.base[2] = x->v.data(); v.base[3] = x->y.data();
+    v.stride[0] = nz_; v.stride[1] = nl_; v.stride[2] = nv_; v.stride[3] = nv_;
+    fbstab_solver_out_t out;
+    if (fbstab_hip_mpc_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_HOST_POINTERS, nullptr) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpc::Solve: ") + fbstab_hip_last_error());
+    SolverOut s = detail::FromC(out);
+    detail::PrintFinal(s, opts_, os);
+    return s;
+  }
+  template <class InputData, class InputVariable>
+  SolverOut Solve(const InputData& qp, InputVariable* x) {
+    StandardOutput os;
+    return Solve(qp, x, os);
+  }
+
+  // fbstab_mpc.cc:96-100 -> UpdateParameters + ValidateOptions
+  void UpdateOptions(const Options& options) {
+    opts_ = options;
+    opts_.ValidateOptions();
+    fbstab_options_t o = opts_.ToC();
+    fbstab_hip_mpc_set_options(h_, &o);
+  }
+  static Options DefaultOptions() { Options o; o.DefaultParameters(); return o; }
+  static Options ReliableOptions() { Options o; o.ReliableParameters(); return o; }
+
+ private:
+  // MpcData::ValidateInputs (mpc_data.cc:291-363) + ValidateInputSizes
+  // (fbstab_mpc.h:229-242).
+  template <class InputData>
+  void ValidateData(const InputData& qp) const {
+    const int N = qp.Q.length();
+    if (N <= 0) throw std::runtime_error("Horizon length must be at least 1.");
+    bool OK = N == qp.R.length() && N == qp.S.length() && N == qp.q.length() && N == qp.r.length() &&
+              (N - 1) == qp.A.length() && (N - 1) == qp.B.length() && (N - 1) == qp.c.length() &&
+              N == qp.E.length() && N == qp.L.length() && N == qp.d.length();
+    if (!OK) throw std::runtime_error("Sequence length mismatch in input data to MpcData.");
+    const int nx = qp.Q.rows();
+    if (static_cast<int>(qp.x0.size()) != nx) throw std::runtime_error("Size mismatch in x0 input to MpcData.");
+    if (qp.Q.cols() != nx) throw std::runtime_error("Size mismatch in Q input to MpcData.");
+    if (qp.S.cols() != nx) throw std::runtime_error("Size mismatch in S input to MpcData.");
+    if (qp.q.rows() != nx) throw std::runtime_error("Size mismatch in q input to MpcData.");
+    if (qp.E.cols() != nx) throw std::runtime_error("Size mismatch in E input to MpcData.");
+    if (qp.A.rows() != nx || qp.A.cols() != nx) throw std::runtime_error("Size mismatch in A input to MpcData.");
+    if (qp.B.rows() != nx) throw std::runtime_error("Size mismatch in B input to MpcData.");
+    if (qp.c.rows() != nx) throw std::runtime_error("Size mismatch in c input to MpcData.");
+    const int nu = qp.R.rows();
+    if (qp.R.cols() != nu) throw std::runtime_error("Size mismatch in R input to MpcData.");
+    if (qp.S.rows() != nu) throw std::runtime_error("Size mismatch in S input to MpcData.");
+    if (qp.r.rows() != nu) throw std::runtime_error("Size mismatch in r input to MpcData.");
+    if (qp.L.cols() != nu) throw std::runtime_error("Size mismatch in L input to MpcData.");
+    if (qp.B.cols() != nu) throw std::runtime_error("Size mismatch in B input to MpcData.");
+    const int nc = qp.E.rows();
+    if (qp.L.rows() != nc) throw std::runtime_error("Size mismatch in L input to MpcData.");
+    if (qp.d.rows() != nc) throw std::runtime_error("Size mismatch in d input to MpcData.");
+    if (qp.B.length() != N_ || nx != nx_ || nu != nu_ || nc != nc_)
+      throw std::runtime_error("In FBstabMpc::Solve: mismatch between *this and data dimensions.");
+  }
+
+  int N_, nx_, nu_, nc_, nz_, nl_, nv_;
+  Options opts_;
+  fbstab_mpc_handle_t h_ = nullptr;
+};
+
+// Batched solves (new in this library): `batch` QPs of one size in one call.
+// Arrays follow fbstab_mpc_batch_t (include/fbstab_hip.h): base pointer +
+// stride per sequence, host or device memory.
+class FBstabMpcBatch {
+ public:
+  FBstabMpcBatch(const FBstabMpcBatch&) = delete;
+  void operator=(const FBstabMpcBatch&) = delete;
+  FBstabMpcBatch(int N, int nx, int nu, int nc, int max_batch, int device = 0) {
+    if (N < 1 || nx < 1 || nu < 1 || nc < 1)
+      throw std::runtime_error("In FBstabMpc::FBstabMpc: problem sizes must be positive.");
+    if (fbstab_hip_mpc_create(N, nx, nu, nc, max_batch, device, &h_) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpcBatch: ") + fbstab_hip_last_error());
+  }
+  ~FBstabMpcBatch() { fbstab_hip_mpc_destroy(h_); }
+  void UpdateOptions(const FBstabMpc::Options& options) {
+    FBstabMpc::Options o = options;
+    o.ValidateOptions();
+    fbstab_options_t c = o.ToC();
+    fbstab_hip_mpc_set_options(h_, &c);
+  }
+  // flags: FBSTAB_HIP_HOST_POINTERS or FBSTAB_HIP_DEVICE_POINTERS [| FBSTAB_HIP_ASYNC]
+  void Solve(int batch, const fbstab_mpc_batch_t& data, const fbstab_var_batch_t& x,
+             fbstab_solver_out_t* out, int flags = FBSTAB_HIP_HOST_POINTERS, void* stream = nullptr) {
+    if (fbstab_hip_mpc_solve_batch(h_, batch, &data, &x, out, flags, stream) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpcBatch::Solve: ") + fbstab_hip_last_error());
+  }
+
+ private:
+  fbstab_mpc_handle_t h_ = nullptr;
+};
+
+}  // namespace fbstab

@@ -1,0 +1,259 @@
+// End-to-end tests of the C++ facade (include/fbstab/), written to read like
+// the reference's own gtest files:
+//   fbstab/test/fbstab_dense_unit_tests.cc  (FeasibleQP, FeasibleQPwithEQ,
+//       DegenerateQP via ProblemDataRef/VariableRef, InfeasibleQP, UnboundedQP)
+//   fbstab/test/fbstab_mpc_unit_tests.cc    (DoubleIntegrator + quadprog golden,
+//       DoubleIntegratorLongHorizon via ProblemDataRef, ServoMotor)
+// plus the error behaviour of the constructors / Solve.  C++11, no gtest
+// (absent from the image): a failed expectation prints and counts.
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+
+#include "fbstab/fbstab_dense.h"
+#include "fbstab/fbstab_mpc.h"
+
+using namespace fbstab;
+
+static int g_fail = 0;
+#define EXPECT_TRUE(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); g_fail++; } } while (0)
+#define EXPECT_NEAR(a, b, tol) EXPECT_TRUE(std::fabs((a) - (b)) <= (tol))
+#define EXPECT_THROW(stmt) do { bool t_ = false; try { stmt; } catch (const std::runtime_error&) { t_ = true; } EXPECT_TRUE(t_); } while (0)
+
+static FBstabDense::Options DenseOpts() {
+  FBstabDense::Options o = FBstabDense::DefaultOptions();
+  o.abs_tol = 1e-8;
+  o.display_level = Display::OFF;
+  return o;
+}
+
+static void FeasibleQP() {
+  const int n = 2, m = 0, q = 2;
+  FBstabDense::Variable x0(n, m, q);
+  FBstabDense::ProblemData data(n, m, q);
+  data.H = {3, 1, 1, 1};
+  data.f = {10, 5};
+  data.A = {-1, 0, 0, 1};
+  data.b = {0, 0};
+  FBstabDense solver(n, m, q);
+  solver.UpdateOptions(DenseOpts());
+  SolverOut out = solver.Solve(data, &x0);
+  EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+  const double zopt[2] = {0, -5}, vopt[2] = {5, 0};
+  for (int i = 0; i < n; i++) EXPECT_NEAR(x0.z(i), zopt[i], 1e-8);
+  for (int i = 0; i < q; i++) EXPECT_NEAR(x0.v(i), vopt[i], 1e-8);
+}
+
+static void FeasibleQPwithEQ() {
+  const int n = 2, m = 1, q = 2;
+  FBstabDense::Variable x0(n, m, q);
+  FBstabDense::ProblemData data(n, m, q);
+  data.H = {4, 1, 1, 2};
+  data.f = {1, 1};
+  data.G = {1, 1};
+  data.h = {1};
+  data.A = {-1, 0, 0, -1};
+  data.b = {0, 0};
+  FBstabDense solver(n, m, q);
+  solver.UpdateOptions(DenseOpts());
+  SolverOut out = solver.Solve(data, &x0);
+  EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+  EXPECT_NEAR(x0.z(0), 0.25, 1e-8);
+  EXPECT_NEAR(x0.z(1), 0.75, 1e-8);
+}
+
+static void DegenerateQP() {
+  const int n = 2, m = 0, q = 5;
+  std::unique_ptr<double[]> zmem(new double[n]), lmem(new double[1]), vmem(new double[q]), ymem(new double[q]);
+  FBstabDense::VecRef z(zmem.get(), n), l(lmem.get(), m), v(vmem.get(), q), y(ymem.get(), q);
+  FBstabDense::VariableRef x0(&z, &l, &v, &y);
+  x0.fill(0.0);
+  // column-major images of H = [1 0; 0 0], A = [0 0; 1 0; 0 1; -1 0; 0 -1]
+  double Hmem[4] = {1, 0, 0, 0}, fmem[2] = {1, 0}, Gmem[1] = {0}, hmem[1] = {0};
+  double Amem[10] = {0, 1, 0, -1, 0, 0, 0, 1, 0, -1}, bmem[5] = {0, 3, 3, -1, -1};
+  FBstabDense::MatRef H(Hmem, n, n), G(Gmem, m, n), A(Amem, q, n);
+  FBstabDense::VecRef f(fmem, n), h(hmem, m), b(bmem, q);
+  FBstabDense::ProblemDataRef data(&H, &f, &G, &h, &A, &b);
+  FBstabDense solver(n, m, q);
+  solver.UpdateOptions(DenseOpts());
+  SolverOut out = solver.Solve(data, &x0);
+  EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+  EXPECT_NEAR(x0.z(0), 1, 1e-8);
+  EXPECT_TRUE(x0.z(1) >= 1 && x0.z(1) <= 3);
+  double r1 = 0, r2 = 0;
+  for (int i = 0; i < n; i++) {
+    double s = fmem[i];
+    for (int j = 0; j < n; j++) s += H(i, j) * x0.z(j);
+    for (int k = 0; k < q; k++) s += A(k, i) * x0.v(k);
+    r1 += s * s;
+  }
+  for (int k = 0; k < q; k++) { const double mn = std::fmin(x0.y(k), x0.v(k)); r2 += mn * mn; }
+  EXPECT_NEAR(std::sqrt(r1) + std::sqrt(r2), 0, 1e-6);
+}
+
+static void InfeasibleAndUnboundedQP() {
+  {
+    FBstabDense::ProblemData data(2, 0, 5);
+    data.H = {1, 0, 0, 0};
+    data.f = {1, -1};
+    data.A = {1, 1, 1, 0, 0, 1, -1, 0, 0, -1};
+    data.b = {0, 3, 3, -1, -1};
+    FBstabDense::Variable x0(2, 0, 5);
+    FBstabDense solver(2, 0, 5);
+    solver.UpdateOptions(DenseOpts());
+    EXPECT_TRUE(solver.Solve(data, &x0).eflag == ExitFlag::PRIMAL_INFEASIBLE);
+  }
+  {
+    FBstabDense::ProblemData data(2, 0, 4);
+    data.H = {1, 0, 0, 0};
+    data.f = {1, -1};
+    data.A = {0, 0, 1, 0, -1, 0, 0, -1};
+    data.b = {0, 3, -1, -1};
+    FBstabDense::Variable x0(2, 0, 4);
+    FBstabDense solver(2, 0, 4);
+    solver.UpdateOptions(DenseOpts());
+    EXPECT_TRUE(solver.Solve(data, &x0).eflag == ExitFlag::DUAL_INFEASIBLE);
+  }
+}
+
+// The double-integrator and servo-motor problems of
+// fbstab/test/ocp_generator.cc:253-371 (CopyOverHorizon zeroes E(0), :403-408).
+struct Ocp {
+  FBstabMpc::ProblemData data;
+  int N, nx, nu, nc;
+  void Fill(const MatrixXd& Q, const MatrixXd& R, const MatrixXd& S, const VectorXd& q, const VectorXd& r,
+            const MatrixXd& A, const MatrixXd& B, const VectorXd& c, const MatrixXd& E, const MatrixXd& L,
+            const VectorXd& d, const VectorXd& x0, int N_) {
+    N = N_; nx = Q.rows(); nu = R.rows(); nc = E.rows();
+    data.Q = MatrixSequence(N + 1, nx, nx); data.R = MatrixSequence(N + 1, nu, nu);
+    data.S = MatrixSequence(N + 1, nu, nx); data.q = MatrixSequence(N + 1, nx);
+    data.r = MatrixSequence(N + 1, nu); data.A = MatrixSequence(N, nx, nx);
+    data.B = MatrixSequence(N, nx, nu); data.c = MatrixSequence(N, nx);
+    data.E = MatrixSequence(N + 1, nc, nx); data.L = MatrixSequence(N + 1, nc, nu);
+    data.d = MatrixSequence(N + 1, nc); data.x0 = x0;
+    MatrixXd E0(nc, nx);
+    struct Col { const VectorXd& v; int rows() const { return v.size(); } int cols() const { return 1; }
+                 double operator()(int i, int) const { return v(i); } };
+    for (int i = 0; i < N + 1; i++) {
+      data.Q(i) = Q; data.R(i) = R; data.S(i) = S; data.q(i) = Col{q}; data.r(i) = Col{r};
+      if (i == 0) data.E(i) = E0; else data.E(i) = E;
+      data.L(i) = L; data.d(i) = Col{d};
+    }
+    for (int i = 0; i < N; i++) { data.A(i) = A; data.B(i) = B; data.c(i) = Col{c}; }
+  }
+  void DoubleIntegrator(int N_) {
+    MatrixXd Q(2, 2), R(1, 1), S(1, 2), A(2, 2), B(2, 1), E(6, 2), L(6, 1);
+    VectorXd q(2), r(1), c(2), d(6), x0(2);
+    Q = {2, 0, 0, 1}; S = {1, 0}; R = {3}; q = {-2, 0}; r = {0};
+    A = {1, 1, 0, 1}; B = {0, 1}; c = {0, 0};
+    E = {-1, 0, 0, -1, 1, 0, 0, 1, 0, 0, 0, 0}; L = {0, 0, 0, 0, -1, 1}; d = {0, 0, -2, -2, -1, -1};
+    x0 = {0, 0};
+    Fill(Q, R, S, q, r, A, B, c, E, L, d, x0, N_);
+  }
+  void ServoMotor(int N_) {
+    const double kt = 10.0, bl = 25.0, Jm = 0.5, bm = 0.1, ktheta = 1280.2, RR = 20.0, rho = 20.0;
+    const double Jl = 20 * Jm, umax = 220.0, ymax = 78.5358, ts = 0.05;
+    MatrixXd Ac(4, 4), A(4, 4), B(4, 1), C(2, 4), Q(4, 4), R(1, 1), S(1, 4), E(4, 4), L(4, 1);
+    Ac = {0, 1, 0, 0, -ktheta / Jl, -bl / Jl, ktheta / (rho * Jl), 0, 0, 0, 0, 1,
+          ktheta / (rho * Jm), 0, -ktheta / (rho * rho * Jm), -(bm + kt * kt / RR) / Jm};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) A(i, j) = (i == j ? 1.0 : 0.0) + ts * Ac(i, j);
+    B = {0, 0, 0, ts * kt / (RR * Jm)};
+    C = {1, 0, 0, 0, ktheta, 0, -ktheta / rho, 0};
+    Q(0, 0) = 1000; R(0, 0) = 1e-4;
+    const double pi = 3.1415926535897;
+    VectorXd q(4), r(1), c(4), d(4), x0(4);
+    q = {-1000 * 30 * pi / 180, 0, 0, 0}; r = {-0.0};
+    for (int j = 0; j < 4; j++) { E(0, j) = C(1, j); E(1, j) = -C(1, j); }
+    L = {0, 0, 1, -1}; d = {-ymax, -ymax, -umax, -umax};
+    Fill(Q, R, S, q, r, A, B, c, E, L, d, x0, N_);
+  }
+};
+
+static FBstabMpc::Options MpcOpts() {
+  FBstabMpc::Options o = FBstabMpc::DefaultOptions();
+  o.abs_tol = 1e-8;
+  o.display_level = Display::OFF;
+  return o;
+}
+
+static void DoubleIntegrator() {
+  Ocp ocp;
+  ocp.DoubleIntegrator(2);
+  FBstabMpc::Variable x(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+  FBstabMpc solver(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+  solver.UpdateOptions(MpcOpts());
+  SolverOut out = solver.Solve(ocp.data, &x);
+  EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+  EXPECT_TRUE(out.residual <= 1e-6);
+  // MATLAB quadprog solution, fbstab_mpc_unit_tests.cc:37-47
+  const double zopt[9] = {-5.31028204670497e-14, 5.02854354118183e-13, 0.311688311338095,
+                          5.35637944798588e-13, 0.311688311339015, -0.0779220779990502,
+                          0.311688311339667, 0.233766233340057, -0.103896103779874};
+  const double lopt[6] = {-5.24675324688535, -4.49350649223710, -3.55844155822323,
+                          -0.935064934014372, -1.48051948022526, 0.233766233996585};
+  const double vopt[18] = {1.06213597221667e-13, -1.41190425869539e-21, 0, 0, 0, 0,
+                           -1.50393600622818e-21, -8.75144622575045e-10, 0, 0, 0, 0,
+                           -8.75144611157041e-10, -6.56358459377444e-10, 0, 0, 0, 0};
+  for (int i = 0; i < 9; i++) EXPECT_NEAR(x.z(i), zopt[i], 1e-8);
+  for (int i = 0; i < 6; i++) EXPECT_NEAR(x.l(i), lopt[i], 1e-8);
+  for (int i = 0; i < 18; i++) EXPECT_NEAR(x.v(i), vopt[i], 1e-8);
+}
+
+static void LongHorizonRefAndServo() {
+  {
+    Ocp ocp;
+    ocp.DoubleIntegrator(20);
+    FBstabMpc::ProblemDataRef ref(&ocp.data.Q, &ocp.data.R, &ocp.data.S, &ocp.data.q, &ocp.data.r,
+                                  &ocp.data.A, &ocp.data.B, &ocp.data.c, &ocp.data.E, &ocp.data.L,
+                                  &ocp.data.d, &ocp.data.x0);
+    FBstabMpc::Variable x(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+    FBstabMpc solver(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+    solver.UpdateOptions(MpcOpts());
+    SolverOut out = solver.Solve(ref, &x);
+    EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+    EXPECT_TRUE(out.residual <= 1e-6);
+    EXPECT_TRUE(out.newton_iters == 9 && out.prox_iters == 4);  // oracle / reference loop
+  }
+  {
+    Ocp ocp;
+    ocp.ServoMotor(25);
+    FBstabMpc::Variable x(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+    FBstabMpc solver(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+    solver.UpdateOptions(MpcOpts());
+    SolverOut out = solver.Solve(ocp.data, &x);
+    EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+    EXPECT_TRUE(out.residual <= 1e-6);
+    EXPECT_TRUE(out.newton_iters == 27 && out.prox_iters == 4);
+  }
+}
+
+static void ErrorBehaviour() {
+  EXPECT_THROW(FBstabMpc(0, 2, 1, 6));     // fbstab_mpc.cc:62-65
+  EXPECT_THROW(FBstabDense(2, -1, 2));     // fbstab_dense.cc:19-23
+  EXPECT_THROW(MatrixSequence(-1, 2, 2));  // matrix_sequence.h:31-33
+  EXPECT_THROW(MapMatrixSequence(nullptr, 1, 2, 2));
+  Ocp ocp;
+  ocp.DoubleIntegrator(2);
+  FBstabMpc solver(3, ocp.nx, ocp.nu, ocp.nc);  // horizon mismatch
+  FBstabMpc::Variable x(3, ocp.nx, ocp.nu, ocp.nc);
+  EXPECT_THROW(solver.Solve(ocp.data, &x));     // fbstab_mpc.h:229-236
+  FBstabMpc solver2(2, ocp.nx, ocp.nu, ocp.nc);
+  EXPECT_THROW(solver2.Solve(ocp.data, &x));    // fbstab_mpc.h:237-241 (guess size)
+  FBstabMpc::Options o = FBstabMpc::DefaultOptions();
+  EXPECT_TRUE(o.sigma_max == 1e-6 && o.beta == 0.75 && o.max_newton_iters == 200);  // impl:33-59
+  AlgorithmParameters raw;
+  EXPECT_TRUE(raw.beta == 0.7 && raw.max_newton_iters == 500);  // header initialisers differ
+}
+
+int main() {
+  FeasibleQP();
+  FeasibleQPwithEQ();
+  DegenerateQP();
+  InfeasibleAndUnboundedQP();
+  DoubleIntegrator();
+  LongHorizonRefAndServo();
+  ErrorBehaviour();
+  printf(g_fail ? "%d FAILED\n" : "ALL FACADE TESTS PASSED\n", g_fail);
+  return g_fail ? 1 : 0;
+}
