@@ -63,6 +63,22 @@ def cpu_baseline(sample_qps: int):
     }
 
 
+def pmc_traffic(batch: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary
+    (FETCH_SIZE and WRITE_SIZE, separate passes; see the note in the file).
+    bench.py cannot run the profiler on itself, so this is the figure of the
+    last profiled build for the same batch, or None."""
+    path = os.path.join(ROOT, "profiles", "r01_b_g16_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("batch") == batch:
+            return t["hbm_bytes_per_launch_raw"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +194,8 @@ def main():
                        "parallelism": f"batch sharded over {world} GPU(s)" +
                                       (", RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(B),
                          "kernel": "fbstab_mpc_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B},
             "fp64": {"model_flop_per_newton_iter": FLOP_PER_NEWTON,
