@@ -92,6 +92,60 @@ struct Solver {
     *Eo = sqrt(s[1]);
   }
 
+  // The norms of norms_at() for K step lengths t0*beta^k in ONE pass over the
+  // iterate vectors (a backtracking line search usually needs several trials,
+  // impl:283-297; the pass is bound by the loads, not by the arithmetic).
+  template <int K>
+  FB_DEV void norms_at_multi(double t0, double beta, double sigma, double (&Ei)[K],
+                             double (&Eo)[K]) const {
+    double tt[K];
+    tt[0] = t0;
+#pragma unroll
+    for (int k = 1; k < K; k++) tt[k] = tt[k - 1] * beta;
+    double s[2 * K];
+#pragma unroll
+    for (int k = 0; k < 2 * K; k++) s[k] = 0.0;
+    for (int i = c.tid; i < p.nz; i += C::nt) {
+      const double r0 = p.rz[i], w = p.wz[i], z0 = p.z[i], d = p.dz[i], zb = p.zb[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const double r = fma(tt[k], w, r0);
+        const double ri = r + sigma * (fma(tt[k], d, z0) - zb);
+        s[k] = fma(ri, ri, s[k]);
+        s[K + k] = fma(r, r, s[K + k]);
+      }
+    }
+    for (int i = c.tid; i < p.nl; i += C::nt) {
+      const double r0 = p.rl[i], w = p.wl[i], l0 = p.l[i], d = p.dl[i], lb = p.lb[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const double r = fma(tt[k], w, r0);
+        const double ri = r + sigma * (fma(tt[k], d, l0) - lb);
+        s[k] = fma(ri, ri, s[k]);
+        s[K + k] = fma(r, r, s[K + k]);
+      }
+    }
+    for (int i = c.tid; i < p.nv; i += C::nt) {
+      const double v0 = p.v[i], dv = p.dv[i], y0 = p.y[i], ad = p.adz[i], vb = p.vb[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const double vi = fma(tt[k], dv, v0);
+        const double yi = fma(-tt[k], ad, y0);
+        const double ys = yi + sigma * (vi - vb);
+        const double r = pfb(ys, vi, o.alpha);
+        const double q = pnr(yi, vi, o.alpha);
+        s[k] = fma(r, r, s[k]);
+        s[K + k] = fma(q, q, s[K + k]);
+      }
+    }
+    c.sum(s);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      Ei[k] = sqrt(s[k]);
+      Eo[k] = sqrt(s[K + k]);
+    }
+  }
+
   // x <- x + t*dx and the matching residual update (impl:298,
   // full_variable.cc:55-65: y += t*(dy - b) with dy = b - A dz).
   FB_DEV void accept(double t) const {
@@ -198,14 +252,29 @@ struct Solver {
       if (o.nonmonotone_linesearch) {
         for (int k = 1; k < 5; k++) m0 = merit[k] > m0 ? merit[k] : m0;
       }
-      // impl:283-297: trial j = 0 at t = 1 came with the Newton step
+      // impl:283-297: trial j = 0 at t = 1 came with the Newton step; later
+      // trials are evaluated four step lengths per pass.
       double t = 1.0;
       double Et = sqrt(ti2), Eot = sqrt(to2);
       bool known = true;  // (Et, Eot) belong to the current t
+      constexpr int KT = 4;
+      double Em[KT], Eom[KT];
+      int have = 0, used = 0;  // batch of trial norms for t, t*beta, ...
       for (int j = 0; j < o.max_linesearch_iters; j++) {
         if (j > 0) {
-          FB_STAMP_COUNT(30);
-          norms_at(t, sigma, true, &Et, &Eot);
+          if (used == have) {
+            FB_STAMP_COUNT(30);
+            norms_at_multi<KT>(t, o.beta, sigma, Em, Eom);
+            have = KT;
+            used = 0;
+          }
+          Et = Em[0];
+          Eot = Eom[0];
+#pragma unroll
+          for (int k = 1; k < KT; k++) {
+            if (used == k) { Et = Em[k]; Eot = Eom[k]; }
+          }
+          used++;
           known = true;
         }
         const double mp = 0.5 * Et * Et;
@@ -213,7 +282,20 @@ struct Solver {
         t *= o.beta;
         known = false;
       }
-      if (!known) norms_at(t, sigma, true, &Et, &Eot);  // t = beta^max_ls is applied untested
+      if (!known) {
+        // t = beta^max_ls is applied untested (impl:283-298); its norms are
+        // needed as the next loop-top values
+        if (used < have) {
+          Et = Em[0];
+          Eot = Eom[0];
+#pragma unroll
+          for (int k = 1; k < KT; k++) {
+            if (used == k) { Et = Em[k]; Eot = Eom[k]; }
+          }
+        } else {
+          norms_at(t, sigma, true, &Et, &Eot);
+        }
+      }
       p.pend_t = t;
       Ei = Et;
       Eo = Eot;

@@ -169,6 +169,39 @@ FB_DEV void pfb_gradient(double a, double b, double alpha, double* g0, double* g
   }
 }
 
+// 1/x to (almost) full double precision without the IEEE division sequence:
+// hardware reciprocal seed + two Newton steps.  Used where the reference
+// divides but parity is by tolerance (never on a value that feeds a branch
+// directly).
+FB_DEV double rcp_fast(double x) {
+#if defined(FB_HOSTSIM)
+  return 1.0 / x;
+#else
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#endif
+}
+
+// phi(a,b) and its generalised gradient from ONE sqrt and ONE reciprocal
+// (pfb + pfb_gradient share r = sqrt(a^2+b^2)); same formulas as above.
+FB_DEV void pfb_all(double a, double b, double alpha, double* phi, double* g0, double* g1) {
+  const double r = sqrt(a * a + b * b);
+  const double pa = fmax0(a), pb = fmax0(b);
+  *phi = alpha * (a + b - r) + (1.0 - alpha) * pa * pb;
+  if (r < 1e-13) {
+    const double d = 0.70710678118654752440;
+    *g0 = alpha * (1.0 - d);
+    *g1 = alpha * (1.0 - d);
+  } else {
+    const double ir = rcp_fast(r);
+    const bool both = a > 0.0 && b > 0.0;
+    *g0 = alpha * (1.0 - a * ir) + (both ? (1.0 - alpha) * b : 0.0);
+    *g1 = alpha * (1.0 - b * ir) + (both ? (1.0 - alpha) * a : 0.0);
+  }
+}
+
 // Result of the infeasibility test (reference: full_feasibility.h enum).
 enum Feasibility { kFeasible = 0, kPrimalInfeasible = 1, kDualInfeasible = 2, kBothInfeasible = 3 };
 

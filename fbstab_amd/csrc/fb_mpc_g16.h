@@ -44,16 +44,16 @@ FB_DEV void sfor(F&& f) {
 // ---- DPP helpers on one 16-lane row -------------------------------------------
 template <int CTRL>
 FB_DEV double dpp_mov(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  // 64-bit DPP move: for row_newbcast gfx950 has a single v_mov_b64_dpp; other
+  // controls are split into two 32-bit moves by the compiler.  old = 0 with
+  // bound_ctrl, so the destination is not tied to a copy of the source.
+  return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true);
 }
 // value of lane J of this lane's 16-lane row
 template <int J>
 FB_DEV double bc(double x) { return dpp_mov<0x150 + J>(x); }
 template <int J>
-FB_DEV int bci(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false); }
+FB_DEV int bci(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xf, 0xf, true); }
 
 struct OpSum16 { static FB_DEV double apply(double a, double b) { return a + b; } };
 struct OpMax16 { static FB_DEV double apply(double a, double b) { return a > b ? a : b; } };
@@ -214,6 +214,69 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
     bool ok = true;
 
     FB_STAMP_DECL;
+    // Everything a forward stage reads from memory, as one register bundle, so
+    // that the loads of stage i+1 can be issued while stage i still runs its
+    // second Cholesky chain (software pipelining by hand: the compiler does not
+    // move loads across the loop back-edge).  No lane-dependent branches:
+    // out-of-range lanes read a clamped, valid address.
+    struct FwdIn {
+      double sv[KS], sy[KS], svb[KS], sdv[KS], sadz[KS];
+      double zz, rzz, zbz, dzz, wzz, ll, rll, lbl, dll, wll;
+      double Cc[NC];
+      double K[NS];
+    };
+    auto load_fwd = [&](int i, FwdIn& in) {
+      sfor<0, KS>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        const int k = r + 16 * s;
+        const long g = (long)i * NC + (k < NC ? k : NC - 1);
+        in.sv[s] = v_[g];
+        in.sy[s] = y_[g];
+        in.svb[s] = vb_[g];
+        // (0 * stale data could be NaN: no pending step => exact zeros)
+        in.sdv[s] = tp != 0.0 ? dv_[g] : 0.0;
+        in.sadz[s] = tp != 0.0 ? adz_[g] : 0.0;
+      });
+      const long gz = (long)i * NS + (rs_ ? r : 0);
+      const long gl = (long)i * NX + (rx ? r : 0);
+      in.zz = z_[gz];
+      in.rzz = rz_[gz];
+      in.zbz = zb_[gz];
+      in.dzz = tp != 0.0 ? dz_[gz] : 0.0;
+      in.wzz = tp != 0.0 ? wz_[gz] : 0.0;
+      in.ll = l_[gl];
+      in.rll = rl_[gl];
+      in.lbl = lb_[gl];
+      in.dll = tp != 0.0 ? dl_[gl] : 0.0;
+      in.wll = tp != 0.0 ? wl_[gl] : 0.0;
+      // column r of C = [E L]
+      {
+        const double* src = rx ? D.E + ((long)i * NX + r) * NC : D.L + ((long)i * NU + (rs_ ? ru : 0)) * NC;
+        sfor<0, NC>([&](auto Kk) { in.Cc[decltype(Kk)::value] = src[decltype(Kk)::value]; });
+      }
+      // Row r of [Q S'; S R].  Two lane classes, each with compile-time strides
+      // so that every element is an immediate offset from one base pointer
+      // (per-lane strides make the compiler hoist one address per element).
+      if (rx) {
+        const double* q = D.Q + (long)i * NX * NX + r;
+        const double* st = D.S + (long)i * NU * NX + (long)r * NU;
+        sfor<0, NX>([&](auto Cc) { in.K[decltype(Cc)::value] = q[decltype(Cc)::value * NX]; });
+        sfor<NX, NS>([&](auto Cc) { in.K[decltype(Cc)::value] = st[decltype(Cc)::value - NX]; });
+      } else {
+        const double* sr = D.S + (long)i * NU * NX + (rs_ ? ru : 0);
+        const double* rr = D.R + (long)i * NU * NU + (rs_ ? ru : 0);
+        sfor<0, NX>([&](auto Cc) { in.K[decltype(Cc)::value] = sr[decltype(Cc)::value * NU]; });
+        sfor<NX, NS>([&](auto Cc) { in.K[decltype(Cc)::value] = rr[(decltype(Cc)::value - NX) * NU]; });
+      }
+      if constexpr (NS < 16) {
+        if (!rs_) {
+          sfor<0, NS>([&](auto Cc) { in.K[decltype(Cc)::value] = 0.0; });
+          sfor<0, NC>([&](auto Kk) { in.Cc[decltype(Kk)::value] = 0.0; });
+        }
+      }
+    };
+    FwdIn cur;
+    load_fwd(0, cur);
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N; i++) {
       double* F = fac_ + (long)i * f_stride;
@@ -221,69 +284,25 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       // where used instead of being hoisted out of the loop as 16+ live masks.
       int ro = r;
       asm volatile("" : "+v"(ro));
-      // ---- all of the stage's loads first, without lane-dependent branches
-      // (clamped indices instead), so that they are in flight together and the
-      // wave waits once.
-      double sv[KS], sy[KS], svb[KS], sdv[KS], sadz[KS];
-      sfor<0, KS>([&](auto S_) {
-        constexpr int s = decltype(S_)::value;
-        const int k = r + 16 * s;
-        const long g = (long)i * NC + (k < NC ? k : NC - 1);
-        sv[s] = v_[g];
-        sy[s] = y_[g];
-        svb[s] = vb_[g];
-        // (0 * stale data could be NaN: no pending step => exact zeros)
-        sdv[s] = tp != 0.0 ? dv_[g] : 0.0;
-        sadz[s] = tp != 0.0 ? adz_[g] : 0.0;
-      });
       const long gz = (long)i * NS + (rs_ ? r : 0);
       const long gl = (long)i * NX + (rx ? r : 0);
-      double zz = z_[gz], rzz = rz_[gz];
-      const double zbz = zb_[gz];
-      const double dzz = tp != 0.0 ? dz_[gz] : 0.0, wzz = tp != 0.0 ? wz_[gz] : 0.0;
-      double ll = l_[gl], rll = rl_[gl];
-      const double lbl = lb_[gl];
-      const double dll = tp != 0.0 ? dl_[gl] : 0.0, wll = tp != 0.0 ? wl_[gl] : 0.0;
-      // column r of C = [E L]
       double Cc_[NC];
-      {
-        const double* src = rx ? D.E + ((long)i * NX + r) * NC : D.L + ((long)i * NU + (rs_ ? ru : 0)) * NC;
-        sfor<0, NC>([&](auto Kk) { Cc_[decltype(Kk)::value] = src[decltype(Kk)::value]; });
-      }
-      // Row r of [Q S'; S R].  Two lane classes, each with compile-time strides
-      // so that every element is an immediate offset from one base pointer
-      // (per-lane strides make the compiler hoist one address per element).
+      sfor<0, NC>([&](auto Kk) { Cc_[decltype(Kk)::value] = cur.Cc[decltype(Kk)::value]; });
       double K[NS];
-      if (rx) {
-        const double* q = D.Q + (long)i * NX * NX + r;
-        const double* st = D.S + (long)i * NU * NX + (long)r * NU;
-        sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] = q[decltype(Cc)::value * NX]; });
-        sfor<NX, NS>([&](auto Cc) { K[decltype(Cc)::value] = st[decltype(Cc)::value - NX]; });
-      } else {
-        const double* sr = D.S + (long)i * NU * NX + (rs_ ? ru : 0);
-        const double* rr = D.R + (long)i * NU * NU + (rs_ ? ru : 0);
-        sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] = sr[decltype(Cc)::value * NU]; });
-        sfor<NX, NS>([&](auto Cc) { K[decltype(Cc)::value] = rr[(decltype(Cc)::value - NX) * NU]; });
-      }
-      if constexpr (NS < 16) {
-        if (!rs_) {
-          sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = 0.0; });
-          sfor<0, NC>([&](auto Kk) { Cc_[decltype(Kk)::value] = 0.0; });
-        }
-      }
+      sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = cur.K[decltype(Cc)::value]; });
       // ---- pending step (tp = 0: no-op), PFB gradient (riccati_linear_solver.cc:91-99)
       double Gam[KS], Rvm[KS];
       sfor<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
         const int k = r + 16 * s;
-        const double vk = fma(tp, sdv[s], sv[s]);
-        const double yk = fma(-tp, sadz[s], sy[s]);
-        const double ys = yk + sigma * (vk - svb[s]);
-        double g0, g1;
-        pfb_gradient(ys, vk, alpha, &g0, &g1);
-        const double mu = g1 + sigma * g0;
-        const double G_ = g0 / mu;
-        const double rm = -pfb(ys, vk, alpha) / mu;
+        const double vk = fma(tp, cur.sdv[s], cur.sv[s]);
+        const double yk = fma(-tp, cur.sadz[s], cur.sy[s]);
+        const double ys = yk + sigma * (vk - cur.svb[s]);
+        double ph, g0, g1;
+        pfb_all(ys, vk, alpha, &ph, &g0, &g1);
+        const double imu = rcp_fast(g1 + sigma * g0);
+        const double G_ = g0 * imu;
+        const double rm = -ph * imu;
         if (k < NC) {
           const long g = (long)i * NC + k;
           v_[g] = vk;
@@ -295,10 +314,10 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         Rvm[s] = k < NC ? rm : 0.0;
       });
       // pending step on (z, rz), (l, rl); eliminated right-hand side (:222-225)
-      zz = fma(tp, dzz, zz);
-      rzz = fma(tp, wzz, rzz);
-      ll = fma(tp, dll, ll);
-      rll = fma(tp, wll, rll);
+      const double zz = fma(tp, cur.dzz, cur.zz);
+      const double rzz = fma(tp, cur.wzz, cur.rzz);
+      const double ll = fma(tp, cur.dll, cur.ll);
+      const double rll = fma(tp, cur.wll, cur.rll);
       if (rs_) {
         z_[gz] = zz;
         rz_[gz] = rzz;
@@ -307,8 +326,8 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         l_[gl] = ll;
         rl_[gl] = rll;
       }
-      double r1 = rs_ ? -(rzz + sigma * (zz - zbz)) : 0.0;
-      const double r2 = rx ? rll + sigma * (ll - lbl) : 0.0;
+      double r1 = rs_ ? -(rzz + sigma * (zz - cur.zbz)) : 0.0;
+      const double r2 = rx ? rll + sigma * (ll - cur.lbl) : 0.0;
       __builtin_amdgcn_sched_barrier(0);
       FB_STAMP_LAP(0);
       // C to LDS (other rows read it as broadcasts)
@@ -345,6 +364,15 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       F[fTh + r] = th;
       __builtin_amdgcn_sched_barrier(0);
       FB_STAMP_LAP(2);
+      // [A B] row r for W, requested now so that it arrives behind the chains
+      double AB[NS];
+      sfor<0, NS>([&](auto Cc) { AB[decltype(Cc)::value] = 0.0; });
+      if (rx && i < N) {
+        const double* pa = D.A + (long)i * NX * NX + r;
+        const double* pb = D.B + (long)i * NX * NU + r;
+        sfor<0, NX>([&](auto Cc) { AB[decltype(Cc)::value] = pa[decltype(Cc)::value * NX]; });
+        sfor<NX, NS>([&](auto Cc) { AB[decltype(Cc)::value] = pb[(decltype(Cc)::value - NX) * NX]; });
+      }
       // ---- Lc = chol(K), columns of inv(Lc)
       ok = chol_rows<NS>(K, ro, sigma) && ok;
       if (!ok) return false;
@@ -371,23 +399,15 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         __builtin_amdgcn_sched_barrier(0);
         // ---- W = [A B] inv(Lc)'  (AM and -P of :149-175)
         double W[NS];
-        {
-          double AB[NS];
-          sfor<0, NS>([&](auto Cc) { AB[decltype(Cc)::value] = 0.0; });
-          if (rx) {
-            const double* pa = D.A + (long)i * NX * NX + r;
-            const double* pb = D.B + (long)i * NX * NU + r;
-            sfor<0, NX>([&](auto Cc) { AB[decltype(Cc)::value] = pa[decltype(Cc)::value * NX]; });
-            sfor<NX, NS>([&](auto Cc) { AB[decltype(Cc)::value] = pb[(decltype(Cc)::value - NX) * NX]; });
-          }
-          sfor<0, NS>([&](auto Cc) {
-            constexpr int cc = decltype(Cc)::value;
-            double s = 0.0;
-            sfor<0, cc + 1>([&](auto Kk) { s = fma(AB[decltype(Kk)::value], bc<cc>(XR[decltype(Kk)::value]), s); });
-            W[cc] = s;
-          });
-        }
+        sfor<0, NS>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          double s = 0.0;
+          sfor<0, cc + 1>([&](auto Kk) { s = fma(AB[decltype(Kk)::value], bc<cc>(XR[decltype(Kk)::value]), s); });
+          W[cc] = s;
+        });
         sfor<0, NS>([&](auto Cc) { F[fW + decltype(Cc)::value * 16 + r] = W[decltype(Cc)::value]; });
+        // next stage's inputs: in flight during the second chain below
+        load_fwd(i + 1, cur);
         __builtin_amdgcn_sched_barrier(0);
         FB_STAMP_LAP(6);
         // theta(i+1) partial = -W t

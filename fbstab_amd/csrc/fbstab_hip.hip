@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
 
 
 #ifndef FB_G16_MIN_WAVES
-#define FB_G16_MIN_WAVES 2
+#define FB_G16_MIN_WAVES 1
 #endif
 // Four QPs per wavefront, one per 16-lane DPP row (fb_mpc_g16.h).  Rows run
 // the solver loop independently (SIMT divergence between rows) and pull QP
