@@ -315,3 +315,47 @@ def test_full_size_properties(hip):
     out2 = hip.out_to_numpy(s.Solve(data, z2, l2, v2, y2))
     assert torch.equal(z, z2) and torch.equal(v, v2)
     assert np.array_equal(out["newton_iters"], out2["newton_iters"])
+
+
+def test_receding_horizon_sweep_matches_oracle(hip, oracle):
+    """BASELINE config 5 in miniature: 24 closed-loop trajectories x 10 steps,
+    warm-started (unshifted) from the previous solution, problem data resident
+    on the device and only x0 changing.  Per step: identical exit flags and
+    iteration counts, and the same applied input, as the oracle in the same loop."""
+    import torch
+    from fbstab_amd import receding_horizon as rh
+    T, S = 24, 10
+    p = fx.synthetic_mpc_batch(T, first_id=4000)
+    N, nx, nu, nc = p.sizes()
+    A, B = fx.quadrotor_model()
+    dev = torch.device("cuda:0")
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=T)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+
+    def solve_gpu(x0, z, l, v):
+        data["x0"] = x0.contiguous()
+        y = mk(p.nv)
+        out = hip.out_to_numpy(s.Solve(data, z, l, v, y))
+        return z, l, v, y, out
+
+    def solve_cpu(x0, z, l, v):
+        q = fx.MpcProblem(N, nx, nu, nc)
+        q.arrays = dict(p.arrays)
+        q.arrays["x0"] = np.ascontiguousarray(x0)
+        zz, ll, vv, yy, out = oracle.solve_mpc(q, (z, l, v))
+        return zz, ll, vv, yy, out
+
+    g = rh.closed_loop(solve_gpu, torch.from_numpy(p.arrays["x0"].copy()).to(dev), mk(p.nz), mk(p.nl),
+                       mk(p.nv), torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), nx, nu, S)
+    c = rh.closed_loop(solve_cpu, p.arrays["x0"].copy(), np.zeros((T, p.nz)), np.zeros((T, p.nl)),
+                       np.zeros((T, p.nv)), A, B, nx, nu, S)
+    for k in range(S):
+        assert np.array_equal(g[k]["out"]["eflag"], c[k]["out"]["eflag"]), k
+        assert np.array_equal(g[k]["out"]["prox_iters"], c[k]["out"]["prox_iters"]), k
+        dn = np.abs(g[k]["out"]["newton_iters"].astype(int) - c[k]["out"]["newton_iters"].astype(int))
+        assert dn.max() <= 2, (k, dn.max())
+        np.testing.assert_allclose(g[k]["u0"].cpu().numpy(), c[k]["u0"], atol=2e-5)
+        np.testing.assert_allclose(g[k]["x0"].cpu().numpy(), c[k]["x0"], atol=2e-5)
+    # warm starts pay off: later steps need fewer Newton iterations than the cold first one
+    assert g[-1]["out"]["newton_iters"].mean() < g[0]["out"]["newton_iters"].mean()
