@@ -307,6 +307,209 @@ struct Solver {
     return Eo_top;
   }
 
+  // The whole solve as ONE flat loop over "Newton iterations of this row", for
+  // policies that host several QPs per wavefront (fb_mpc_g16.h): every trip of
+  // the loop runs at most one Newton step, and the proximal-level bookkeeping
+  // (impl:158-216) and the fetch of the next QP happen inside the same loop
+  // under per-row predicates.  Rows of a wavefront therefore meet at every
+  // Newton step instead of waiting for each other at the end of each proximal
+  // subproblem and of each QP (nested loops reconverge at their exits).
+  // Same statements, same order per QP as solve()/subproblem_fused().
+  // `next(p)` binds the policy to the next QP and returns its index or -1.
+  template <class Next>
+  FB_DEV void solve_stream(Next&& next, fbstab_solver_out_t* out_base) const {
+    enum { kFetch = 0, kProxTop = 1, kInner = 2 };
+    int phase = kFetch;
+    fbstab_solver_out_t* out = out_base;
+    const double sigma = o.sigma0;
+    double combo_tol = 0.0, Ek = 0.0, E0 = 0.0, rk_last = 0.0, inner_tol = 0.0, dx_norm = 0.0;
+    double Ei = 0.0, Eo = 0.0, Eo_top = 0.0;
+    double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int newton = 0, prox = 0, k = 0, inner_i = 0;
+    for (;;) {
+      if (phase == kFetch) {
+        const int q = next(p);
+        if (q < 0) break;
+        out = out_base + q;
+        combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
+        p.load_guess(c);
+        copy_x_to_xbar();
+        dx_norm = sqrt((double)(p.nz + p.nl + p.nv));
+        p.residual(c);
+        Ek = pnr_norm();
+        E0 = Ek;
+        rk_last = Ek;
+        newton = 0;
+        prox = 0;
+        k = 0;
+        if (o.inner_tol_min > o.inner_tol_max) {
+          p.write_x(c);
+          finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
+          continue;  // phase stays kFetch
+        }
+        inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
+        phase = kProxTop;
+      }
+      if (phase == kProxTop) {
+        if (k >= o.max_prox_iters) {  // impl:219-223
+          p.write_x(c);
+          finish(out, FBSTAB_MAXITERATIONS, rk_last, newton, prox, E0);
+          phase = kFetch;
+          continue;
+        }
+        rk_last = Ek;
+        if (Ek <= combo_tol || dx_norm <= o.stall_tol) {
+          p.write_x(c);
+          finish(out, FBSTAB_SUCCESS, rk_last, newton, prox, E0);
+          phase = kFetch;
+          continue;
+        }
+        if (o.inner_tol_min > Ek) {
+          p.write_x(c);
+          finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
+          phase = kFetch;
+          continue;
+        }
+        inner_tol = sat(inner_tol * o.delta, o.inner_tol_min, Ek);
+        // SolveProximalSubproblem prologue (impl:233-243)
+        for (int m = 0; m < 5; m++) merit[m] = 0.0;
+        norms_at(0.0, sigma, true, &Ei, &Eo);
+        Eo_top = Eo;
+        inner_i = 0;
+        phase = kInner;
+      }
+      // phase == kInner: top of one inner iteration (impl:237-260)
+      bool leave = inner_i >= o.max_inner_iters;
+      if (!leave) {
+        Eo_top = Eo;
+        rk_last = Eo;
+        leave = ((Ei <= inner_tol && Eo < Ek) || (Ei <= o.inner_tol_min)) ||
+                (newton >= o.max_newton_iters);
+      }
+      if (!leave) {
+        double ti2, to2;
+        if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2)) {
+          p.flush(c);
+          p.write_x(c);
+          finish(out, FBSTAB_DIVERGENCE, rk_last, newton, prox, E0);
+          phase = kFetch;
+          continue;
+        }
+        newton++;
+        const double cm = 0.5 * Ei * Ei;
+        merit[4] = merit[3];
+        merit[3] = merit[2];
+        merit[2] = merit[1];
+        merit[1] = merit[0];
+        merit[0] = cm;
+        double m0 = cm;
+        if (o.nonmonotone_linesearch) {
+          for (int m = 1; m < 5; m++) m0 = merit[m] > m0 ? merit[m] : m0;
+        }
+        double t = 1.0;
+        double Et = sqrt(ti2), Eot = sqrt(to2);
+        bool known = true;
+        constexpr int KT = 4;
+        double Em[KT], Eom[KT];
+        int have = 0, used = 0;
+        for (int j = 0; j < o.max_linesearch_iters; j++) {
+          if (j > 0) {
+            if (used == have) {
+              norms_at_multi<KT>(t, o.beta, sigma, Em, Eom);
+              have = KT;
+              used = 0;
+            }
+            Et = Em[0];
+            Eot = Eom[0];
+#pragma unroll
+            for (int m = 1; m < KT; m++) {
+              if (used == m) { Et = Em[m]; Eot = Eom[m]; }
+            }
+            used++;
+            known = true;
+          }
+          const double mp = 0.5 * Et * Et;
+          if (mp <= m0 - 2.0 * t * o.eta * cm) break;
+          t *= o.beta;
+          known = false;
+        }
+        if (!known) {
+          if (used < have) {
+            Et = Em[0];
+            Eot = Eom[0];
+#pragma unroll
+            for (int m = 1; m < KT; m++) {
+              if (used == m) { Et = Em[m]; Eot = Eom[m]; }
+            }
+          } else {
+            norms_at(t, sigma, true, &Et, &Eot);
+          }
+        }
+        p.pend_t = t;
+        Ei = Et;
+        Eo = Eot;
+        inner_i++;
+      } else {
+        // subproblem epilogue (impl:301-303) and the rest of the proximal
+        // iteration (impl:186-216)
+        p.flush(c);
+        for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
+        c.sync();
+        const double Eo_ret = Eo_top;
+        if (newton >= o.max_newton_iters) {
+          if (Eo_ret < Ek) {
+            p.residual(c);
+            rk_last = pnr_norm();
+            p.write_x(c);
+          } else {
+            rk_last = Ek;
+            p.write_xbar(c);
+          }
+          finish(out, FBSTAB_MAXITERATIONS, rk_last, newton, prox, E0);
+          phase = kFetch;
+          continue;
+        }
+        double s[1] = {0.0};
+        for (int i = c.tid; i < p.nz; i += C::nt) {
+          const double d = p.z[i] - p.zb[i];
+          p.dz[i] = d;
+          s[0] += d * d;
+        }
+        for (int i = c.tid; i < p.nl; i += C::nt) {
+          const double d = p.l[i] - p.lb[i];
+          p.dl[i] = d;
+          s[0] += d * d;
+        }
+        for (int i = c.tid; i < p.nv; i += C::nt) {
+          const double d = p.v[i] - p.vb[i];
+          p.dv[i] = d;
+          s[0] += d * d;
+        }
+        c.sum(s);
+        dx_norm = sqrt(s[0]);
+        c.sync();
+        if (o.check_feasibility) {
+          const int f = p.feasibility(c, o.infeas_tol);
+          if (f != kFeasible) {
+            const int eflag = f == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
+                              : f == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
+                                                     : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
+            p.write_certificate(c);
+            finish(out, eflag, rk_last, newton, prox, E0);
+            phase = kFetch;
+            continue;
+          }
+        }
+        copy_x_to_xbar();
+        prox++;
+        k++;
+        p.residual(c);
+        Ek = pnr_norm();
+        phase = kProxTop;
+      }
+    }
+  }
+
   // FBstabAlgorithm::Solve (impl:113-224).
   FB_DEV void solve(fbstab_solver_out_t* out) const {
     const double sigma = o.sigma0;

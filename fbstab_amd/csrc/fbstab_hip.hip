@@ -166,21 +166,35 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
   Ctx16 ctx;
   ctx.tid = lane & 15;
   double* ws = scratch + ((long)blockIdx.x * 4 + row) * lay.ws_doubles;
-  for (;;) {
+  MpcProblemG16<NX, NU, NC> p;
+  // Binds the policy to the next QP of the shared queue; -1 when it is empty.
+  auto next = [&](MpcProblemG16<NX, NU, NC>& pp) -> int {
     int q = 0;
     if (ctx.tid == 0) q = atomicAdd(counter, 1);
     q = bci<0>(q);
-    if (q >= batch) break;
-    MpcProblemG16<NX, NU, NC> p;
-    p.bind(lay, mpc_data_of(data, q), x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
-           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
-    if constexpr (DBG) {
-      newton_probe(p, ctx, opts, dbg);
-    } else {
-      Solver<MpcProblemG16<NX, NU, NC>, Ctx16> solver(p, ctx, opts);
+    if (q >= batch) return -1;
+    pp.bind(lay, mpc_data_of(data, q), x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
+            x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
+    pp.pend_t = 0.0;
+    return q;
+  };
+  if constexpr (DBG) {
+    if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
+  } else {
+    Solver<MpcProblemG16<NX, NU, NC>, Ctx16> solver(p, ctx, opts);
+#ifdef FB_G16_FLAT
+    // One flat loop over Newton steps (rows never wait at subproblem exits).
+    // Measured slower on the BASELINE workload (77.7k vs 99.4k QP/s): the
+    // proximal-level passes are then run by one row at a time instead of by
+    // the four rows together.  Kept for later rounds.
+    solver.solve_stream(next, out);
+#else
+    for (;;) {
+      const int q = next(p);
+      if (q < 0) break;
       solver.solve(out + q);
     }
-    ctx.sync();
+#endif
   }
 }
 
