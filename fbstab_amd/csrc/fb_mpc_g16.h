@@ -414,17 +414,14 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         thp = 0.0;
         sfor<0, NS>([&](auto Cc) { thp = fma(-W[decltype(Cc)::value], bc<decltype(Cc)::value>(tvec), thp); });
         // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L)
-        c.sync();
-        sfor<0, NS>([&](auto Cc) { Tr[r * TS + decltype(Cc)::value] = W[decltype(Cc)::value]; });
-        c.sync();
         double Pn[NX];
-        sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = 0.0; });
-#pragma unroll 2
-        for (int k = 0; k < NS; k++) {
-          const double wk = Tr[r * TS + k];
-          sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = fma(wk, Tr[decltype(Cc)::value * TS + k], Pn[decltype(Cc)::value]); });
-        }
-        sfor<0, NX>([&](auto Cc) { if (!rx) Pn[decltype(Cc)::value] = 0.0; });
+        sfor<0, NX>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          double acc = 0.0;
+          sfor<0, NS>([&](auto Kk) { acc = fma(W[decltype(Kk)::value], bc<cc>(W[decltype(Kk)::value]), acc); });
+          Pn[cc] = rx ? acc : 0.0;
+          __builtin_amdgcn_sched_barrier(0);
+        });
         __builtin_amdgcn_sched_barrier(0);
         FB_STAMP_LAP(7);
         ok = chol_rows<NX>(Pn, ro, sigma) && ok;
@@ -433,16 +430,14 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         double T[NX];
         tri_inv_cols<NX>(Pn, T, ro);
         __builtin_amdgcn_sched_barrier(0);
-        c.sync();
-        sfor<0, NX>([&](auto Kk) { Tr[r * TS + decltype(Kk)::value] = T[decltype(Kk)::value]; });
-        c.sync();
-        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
-#pragma unroll 2
-        for (int k = 0; k < NX; k++) {
-          const double tk = Tr[r * TS + k];  // T[k][r]; zero for k < r
-          sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = fma(tk, Tr[decltype(Cc)::value * TS + k], Pinv[decltype(Cc)::value]); });
-        }
-        sfor<0, NX>([&](auto Cc) { if (!rx) Pinv[decltype(Cc)::value] = 0.0; });
+        // inv(Pi)[r][cc] = sum_k T[k][r] T[k][cc], T[k][cc] = lane cc's T[k] (zero for k < cc)
+        sfor<0, NX>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          double acc = 0.0;
+          sfor<cc, NX>([&](auto Kk) { acc = fma(T[decltype(Kk)::value], bc<cc>(T[decltype(Kk)::value]), acc); });
+          Pinv[cc] = rx ? acc : 0.0;
+          __builtin_amdgcn_sched_barrier(0);
+        });
         FB_STAMP_LAP(8);
       }
     }
