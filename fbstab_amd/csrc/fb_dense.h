@@ -32,6 +32,11 @@ struct DenseLayout {
   // LDS carve (offsets in doubles)
   int o_k, o_rhs, o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz,
       o_rz, o_rl, o_wz, o_wl, o_gam, o_rvm, o_perm, o_red, lds_doubles;
+  // A (nv x nz) is constant over the whole solve and used by every phase:
+  // when it fits it is kept in LDS with an odd leading dimension lda (column
+  // walks by different lanes then hit different banks).  a_lds == 0: read A
+  // from global memory instead.
+  int o_a, lda, a_lds;
 
 #if !defined(FB_HOSTSIM)
   __host__ __device__
@@ -48,6 +53,11 @@ struct DenseLayout {
     o_gam = s; s += nv; o_rvm = s; s += nv;
     o_perm = s; s += (nk + 1) / 2 + 1;  // nk ints
     o_red = s; s += kMaxReduce * ((nthreads + 63) / 64);
+    s = (s + 1) & ~1;
+    lda = nv | 1;
+    o_a = s;
+    a_lds = (long)(s + (long)lda * nz) * 8 <= 80 * 1024 ? 1 : 0;  // two workgroups per CU must still fit
+    if (a_lds) s += lda * nz;
     lds_doubles = (s + 1) & ~1;
   }
 };
@@ -61,7 +71,7 @@ struct DenseProblem {
   lds_ptr lds;
   int nz, nl, nv;
   lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
-  lds_ptr gam, rvm, K, rhs;
+  lds_ptr gam, rvm, K, rhs, Al;
   FB_LDS int* perm;
 
   FB_DEV void bind(const DenseLayout& L_, const DenseData& D_, double* uz_, double* ul_,
@@ -75,6 +85,7 @@ struct DenseProblem {
     rz = lds + lay.o_rz; rl = lds + lay.o_rl; wz = lds + lay.o_wz; wl = lds + lay.o_wl;
     gam = lds + lay.o_gam; rvm = lds + lay.o_rvm;
     perm = (FB_LDS int*)(lds + lay.o_perm);
+    Al = lds + lay.o_a;
   }
 
   // dot of column j of a column-major m-row matrix with an LDS vector
@@ -91,6 +102,25 @@ struct DenseProblem {
     return s;
   }
 
+  // (A x)_i and (A' x)_j from the LDS copy of A when present
+  FB_DEV double A_row_dot(int i, lds_ptr x) const {
+    if (lay.a_lds) {
+      double s = 0.0;
+      for (int k = 0; k < nz; k++) s += Al[i + k * lay.lda] * x[k];
+      return s;
+    }
+    return row_dot(D.A, nv, nz, i, x);
+  }
+  FB_DEV double A_col_dot(int j, lds_ptr x) const {
+    if (lay.a_lds) {
+      lds_ptr col = Al + j * lay.lda;
+      double s = 0.0;
+      for (int k = 0; k < nv; k++) s += col[k] * x[k];
+      return s;
+    }
+    return col_dot(D.A, nv, j, x);
+  }
+
   FB_DEV double forcing_norm(const C& c) const {  // dense_data.h:72-73
     double s[1] = {0.0};
     for (int i = c.tid; i < nz; i += C::nt) s[0] += D.f[i] * D.f[i];
@@ -105,8 +135,11 @@ struct DenseProblem {
     for (int i = c.tid; i < nz; i += C::nt) z[i] = uz[i];
     for (int i = c.tid; i < nl; i += C::nt) l[i] = ul[i];
     for (int i = c.tid; i < nv; i += C::nt) v[i] = uv[i];
+    if (lay.a_lds) {
+      for (int e = c.tid; e < nv * nz; e += C::nt) Al[(e % nv) + (e / nv) * lay.lda] = D.A[e];
+    }
     c.sync();
-    for (int i = c.tid; i < nv; i += C::nt) y[i] = D.b[i] - row_dot(D.A, nv, nz, i, z);
+    for (int i = c.tid; i < nv; i += C::nt) y[i] = D.b[i] - A_row_dot(i, z);
     c.sync();
   }
 
@@ -114,8 +147,7 @@ struct DenseProblem {
   FB_DEV void residual(const C& c) const {
     for (int i = c.tid; i < nz + nl; i += C::nt) {
       if (i < nz) {
-        rz[i] = D.f[i] + row_dot(D.H, nz, nz, i, z) + col_dot(D.G, nl, i, l) +
-                col_dot(D.A, nv, i, v);
+        rz[i] = D.f[i] + row_dot(D.H, nz, nz, i, z) + col_dot(D.G, nl, i, l) + A_col_dot(i, v);
       } else {
         const int j = i - nz;
         rl[j] = D.h[j] - row_dot(D.G, nl, nz, j, z);
@@ -132,7 +164,7 @@ struct DenseProblem {
       if (i < nz) {
         mx[2] = fmax(mx[2], fabs(row_dot(D.H, nz, nz, i, dz)));
         mx[3] = fmax(mx[3], fabs(dz[i]));
-        mx[4] = fmax(mx[4], fabs(col_dot(D.A, nv, i, dv) + col_dot(D.G, nl, i, dl)));
+        mx[4] = fmax(mx[4], fabs(A_col_dot(i, dv) + col_dot(D.G, nl, i, dl)));
         sm[0] += D.f[i] * dz[i];
       } else if (i < nz + nl) {
         const int j = i - nz;
@@ -141,7 +173,7 @@ struct DenseProblem {
         sm[1] += D.h[j] * dl[j];
       } else {
         const int j = i - nz - nl;
-        mx[0] = fmax(mx[0], row_dot(D.A, nv, nz, j, dz));
+        mx[0] = fmax(mx[0], A_row_dot(j, dz));
         ul_[0] = fmax(ul_[0], fabs(dv[j]));
         sm[1] += D.b[j] * dv[j];
       }
@@ -270,6 +302,49 @@ struct DenseProblem {
     c.sync();
     // K = [H + sigma I + A'Gamma A  .; G  -sigma I] (lower; :52-69) and the
     // eliminated right-hand side (:98-104).
+    if (lay.a_lds) {
+      // E = H + sigma I + A' Gamma A (lower), A from LDS: a task is row i and a
+      // chunk of JC columns, so that Gamma_k A[k][i] is reused JC times
+      constexpr int JC = 6;
+      const int nch = (nz + JC - 1) / JC;
+      for (int t = c.tid; t < nz * nch; t += C::nt) {
+        const int i = t / nch, j0 = (t % nch) * JC;
+        if (j0 > i) continue;
+        double acc[JC];
+#pragma unroll
+        for (int m = 0; m < JC; m++) acc[m] = 0.0;
+        lds_ptr ai = Al + i * lay.lda;
+        lds_ptr aj = Al + j0 * lay.lda;
+        int off[JC];  // columns past nz re-read column j0; their sums are discarded
+#pragma unroll
+        for (int m = 0; m < JC; m++) off[m] = (j0 + m < nz) ? m * lay.lda : 0;
+        for (int k = 0; k < nv; k++) {
+          const double g = gam[k] * ai[k];
+#pragma unroll
+          for (int m = 0; m < JC; m++) acc[m] = fma(g, aj[k + off[m]], acc[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < JC; m++) {
+          const int j = j0 + m;
+          if (j <= i && j < nz) K[i + j * n] = D.H[i + (long)j * nz] + (i == j ? sigma : 0.0) + acc[m];
+        }
+      }
+      for (int e = c.tid; e < nl * n + n; e += C::nt) {
+        if (e < nl * n) {
+          const int i = nz + e % nl, j = e / nl;  // rows of [G  -sigma I]
+          if (j < nz) K[i + j * n] = D.G[(i - nz) + (long)j * nl];
+          else if (i >= j) K[i + j * n] = (i == j) ? -sigma : 0.0;
+        } else {
+          const int j = e - nl * n;
+          if (j < nz) {
+            rhs[j] = -(rz[j] + sigma * (z[j] - zb[j])) - A_col_dot(j, rvm);
+          } else {
+            const int q = j - nz;
+            rhs[j] = rl[q] + sigma * (l[q] - lb[q]);
+          }
+        }
+      }
+    } else
     for (int e = c.tid; e < n * n + n; e += C::nt) {
       if (e < n * n) {
         const int i = e % n, j = e / n;
@@ -306,7 +381,7 @@ struct DenseProblem {
     c.sync();
     // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124)
     for (int i = c.tid; i < nv; i += C::nt) {
-      const double a = row_dot(D.A, nv, nz, i, dz);
+      const double a = A_row_dot(i, dz);
       adz[i] = a;
       dv[i] = rvm[i] + gam[i] * a;
     }
@@ -314,7 +389,7 @@ struct DenseProblem {
     // W = (H dz + G'dl + A'dv, -G dz)
     for (int i = c.tid; i < nz + nl; i += C::nt) {
       if (i < nz)
-        wz[i] = row_dot(D.H, nz, nz, i, dz) + col_dot(D.G, nl, i, dl) + col_dot(D.A, nv, i, dv);
+        wz[i] = row_dot(D.H, nz, nz, i, dz) + col_dot(D.G, nl, i, dl) + A_col_dot(i, dv);
       else
         wl[i - nz] = -row_dot(D.G, nl, nz, i - nz, dz);
     }
