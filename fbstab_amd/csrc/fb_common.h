@@ -124,6 +124,43 @@ struct Ctx {
     (void)v;
 #endif
   }
+  // argmax with ties resolved to the SMALLEST index (Eigen's maxCoeff(&index)
+  // returns the first maximum): one pass over (value, index) pairs.
+  FB_DEV void argmax_first(double* val, int* idx) const {
+#if !defined(FB_HOSTSIM)
+    double v = *val;
+    int ix = *idx;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double ov = __shfl_xor(v, m, 64);
+      const int oi = __shfl_xor(ix, m, 64);
+      const bool take = (ov > v) || (ov == v && oi < ix);
+      v = take ? ov : v;
+      ix = take ? oi : ix;
+    }
+    if (NT > 64) {
+      const int wave = tid >> 6;
+      const int nw = NT / 64;
+      sync();
+      if ((tid & 63) == 0) {
+        red[wave] = v;
+        red[nw + wave] = (double)ix;
+      }
+      sync();
+      v = red[0];
+      ix = (int)red[nw];
+      for (int w = 1; w < nw; w++) {
+        const double ov = red[w];
+        const int oi = (int)red[nw + w];
+        const bool take = (ov > v) || (ov == v && oi < ix);
+        v = take ? ov : v;
+        ix = take ? oi : ix;
+      }
+    }
+    *val = v;
+    *idx = ix;
+#endif
+  }
   template <int K>
   FB_DEV void sum(double (&v)[K]) const { reduce<OpSum, K>(v); }
   template <int K>

@@ -199,14 +199,13 @@ struct DenseProblem {
     bool found_zero_pivot = false;
     for (int k = 0; k < n; k++) {
       // largest |diagonal| in the trailing corner; the first maximum wins
-      double best[1] = {-1.0};
-      for (int i = k + c.tid; i < n; i += C::nt) best[0] = fmax(best[0], fabs(K[i + i * n]));
-      c.max(best);
-      double cand[1] = {-1e300};
-      for (int i = k + c.tid; i < n; i += C::nt)
-        if (fabs(K[i + i * n]) == best[0]) cand[0] = fmax(cand[0], -(double)i);
-      c.max(cand);
-      const int p = (int)(-cand[0]);
+      double best = -1.0;
+      int p = n;
+      for (int i = k + c.tid; i < n; i += C::nt) {
+        const double a = fabs(K[i + i * n]);
+        if (a > best) { best = a; p = i; }  // i ascending: first maximum kept
+      }
+      c.argmax_first(&best, &p);
       if (c.tid == 0) perm[k] = p;
       if (p != k) {
         c.sync();
@@ -241,10 +240,13 @@ struct DenseProblem {
       if (rs > 0 && valid) {
         // trailing update of the lower triangle: K(i,j) -= K(i,k) K(j,k) / d
         const double id = 1.0 / d;
-        const int tot = rs * rs;
-        for (int e = c.tid; e < tot; e += C::nt) {
-          const int i = k + 1 + e % rs, j = k + 1 + e / rs;
-          if (i >= j) K[i + j * n] -= K[i + k * n] * (K[j + k * n] * id);
+        // 2-D sweep of the trailing block without integer divisions
+        constexpr int TW = C::nt >= 256 ? 16 : (C::nt >= 64 ? 8 : 1);
+        constexpr int TH = C::nt / TW;
+        const int ti = c.tid % TW, tj = c.tid / TW;
+        for (int j = k + 1 + tj; j < n; j += TH) {
+          const double ljk = K[j + k * n] * id;
+          for (int i = j + ti; i < n; i += TW) K[i + j * n] -= K[i + k * n] * ljk;
         }
         c.sync();
         for (int i = k + 1 + c.tid; i < n; i += C::nt) K[i + k * n] *= id;
