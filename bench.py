@@ -68,14 +68,15 @@ def pmc_traffic(batch: int):
     (FETCH_SIZE and WRITE_SIZE, separate passes; see the note in the file).
     bench.py cannot run the profiler on itself, so this is the figure of the
     last profiled build for the same batch, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_b_g16_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("batch") == batch:
-            return t["hbm_bytes_per_launch_raw"]
-    except (OSError, ValueError, KeyError):
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("batch") == batch:
+                return t["hbm_bytes_per_launch_raw"]
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
@@ -196,7 +197,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(B),
-                         "kernel": "fbstab_mpc_kernel", "kernel_ms": k_ms,
+                         "kernel": "fbstab_mpc_g16_kernel<12,4,20>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B},
             "fp64": {"model_flop_per_newton_iter": FLOP_PER_NEWTON,
                      "mean_newton_iters": mean_newton,
