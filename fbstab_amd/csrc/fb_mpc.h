@@ -43,7 +43,8 @@ struct MpcLayout {
   int f_minv, f_sm, f_am, f_p, f_sginv, f_linv, f_tx, f_tu, f_th, f_stride;
   // iterate vectors in global scratch (offsets in doubles)
   long v_z, v_l, v_v, v_y, v_zb, v_lb, v_vb, v_yb, v_dz, v_dl, v_dv, v_adz, v_rz, v_rl,
-      v_wz, v_wl, v_gam, v_rvm, v_fac, ws_doubles;
+      v_wz, v_wl, v_gam, v_rvm, v_fac, v_pack, ws_doubles;
+  int pack_stride;  // doubles per stage of the lane-major data copy (fb_mpc_g16.h), 0 if unused
   // LDS carve (offsets in doubles)
   int t_q, t_r, t_s, t_a, t_b, t_e, t_l;                  // data tile
   int s_z, s_l, s_ln, s_v;                                // vector slices of the stage
@@ -84,6 +85,16 @@ struct MpcLayout {
     v_gam = g; g += nv; v_rvm = g; g += nv;
     g = (g + 1) & ~1L;
     v_fac = g; g += (long)f_stride * (N + 1);
+    // lane-major copy of the stage matrices for the 16-lane register kernel:
+    // 16 doubles per slot, slots = rows of [Q S';S R], columns of [E L], rows and
+    // columns of [A B]
+    pack_stride = 0;
+    g = (g + 15) & ~15L;
+    v_pack = g;
+    if (nx + nu <= 16) {
+      pack_stride = 16 * ((16 + ((nc + 1) & ~1) + 16 + nx + 1) & ~1);
+      g += (long)pack_stride * (N + 1);
+    }
     ws_doubles = (g + 15) & ~15L;  // 128-byte multiple per workgroup slot
     int s = 0;
     t_q = s; s += nx * nx;  t_r = s; s += nu * nu;  t_s = s; s += nu * nx;

@@ -90,53 +90,172 @@ struct Ctx16 {
   }
 };
 
-// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps.
+// Pins the emitted instruction order at this point.  The 64-bit DPP move has a
+// result latency of ~17 cycles while a wave can issue one FP64/DPP instruction
+// every ~6.5 (tools/probes/bcast_probe.hip): a broadcast must be issued a few
+// instructions ahead of the FMA that consumes it, or the pair costs 2.4x its
+// issue slots.  The compiler's scheduler places them back to back, so the hot
+// products below spell the order out and fence it.
+#define FB_SB() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int kBcAhead = 4;  // broadcasts in flight ahead of their consumers
+
+// Runs consume(I, mov(I)) for I in [0, CNT) with the mov of I + kBcAhead issued
+// before the consumer of I.
+template <int CNT, class Mov, class Use>
+FB_DEV void bc_pipeline(Mov&& mov, Use&& use) {
+  if constexpr (CNT > 0) {
+    double t[CNT];
+    constexpr int P = CNT < kBcAhead ? CNT : kBcAhead;
+    sfor<0, P>([&](auto I) {
+      t[decltype(I)::value] = mov(I);
+      FB_SB();
+    });
+    sfor<0, CNT>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (i + P < CNT) {
+        t[i + P] = mov(std::integral_constant<int, i + P>{});
+        FB_SB();
+      }
+      use(I, t[i]);
+      FB_SB();
+    });
+  }
+}
+
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed (~2^-24 relative) and one
+// third-order step r(1 + e/2 + 3e^2/8), e = 1 - d r^2 (error ~e^3): four
+// dependent levels instead of the six of two Newton steps.  Split into stages
+// so that a caller can put independent work between the dependent levels.
+struct RsqrtChain {
+  double d, r, e, p, re, q;
+  template <int S>
+  FB_DEV void stage() {
+    if constexpr (S == 0) r = __builtin_amdgcn_rsq(d);
+    if constexpr (S == 1) e = -d * r;
+    if constexpr (S == 2) e = fma(e, r, 1.0);
+    if constexpr (S == 3) { p = fma(0.375, e, 0.5); re = r * e; }
+    if constexpr (S == 4) q = fma(re, p, r);
+  }
+  static constexpr int kStages = 5;
+};
 FB_DEV double rsqrt_full(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  double e = fma(-d * r, r, 1.0);
-  r = fma(r * 0.5, e, r);
-  e = fma(-d * r, r, 1.0);
-  r = fma(r * 0.5, e, r);
-  return r;
+  RsqrtChain c;
+  c.d = d;
+  sfor<0, RsqrtChain::kStages>([&](auto S) { c.template stage<decltype(S)::value>(); });
+  return c.q;
 }
 
 // In-place Cholesky of an N x N SPD matrix held one row per lane (a[c] = A[r][c],
 // lower triangle meaningful).  On return a[k] = L[r][k] for k < r and the
 // diagonal slot a[r] holds 1/L[r][r] (only the reciprocal is ever needed).
 // Returns false (row-uniform) on a non-positive pivot.
+//
+// Pivot j + 1's dependent chain (broadcast, rsqrt levels, scaling) is issued one
+// level at a time between the rank-1 update instructions of pivot j, which do
+// not depend on it: the chain's latency is covered instead of exposed.
 template <int N>
 FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
   bool ok = true;
+  RsqrtChain ch;
+  double lj, nlj;
+  // chain levels of pivot J: 0 = pivot broadcast, 1..5 = rsqrt, 6 = scale column J
+  constexpr int kLevels = RsqrtChain::kStages + 2;
+  auto level = [&](auto J, auto S) {
+    constexpr int j = decltype(J)::value;
+    constexpr int lv = decltype(S)::value;
+    if constexpr (lv == 0) {
+      // the caller's "+ diag_add * I" is applied here, at pivot time: no per-lane
+      // (r == j) selects, which the compiler would otherwise hoist and keep live
+      ch.d = bc<j>(a[j]) + diag_add;
+      ok = ok && (ch.d > 0.0);
+    } else if constexpr (lv <= RsqrtChain::kStages) {
+      ch.template stage<lv - 1>();
+    } else {
+      lj = a[j] * ch.q;  // L[r][j] for r > j
+      nlj = -lj;
+      a[j] = (r == j) ? ch.q : lj;
+    }
+    FB_SB();
+  };
+  sfor<0, kLevels>([&](auto S) { level(std::integral_constant<int, 0>{}, S); });
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    // the caller's "+ diag_add * I" is applied here, at pivot time: no per-lane
-    // (r == j) selects, which the compiler would otherwise hoist and keep live
-    const double d = bc<j>(a[j]) + diag_add;
-    ok = ok && (d > 0.0);
-    const double q = rsqrt_full(d);
-    const double lj = a[j] * q;  // L[r][j] for r > j
-    a[j] = (r == j) ? q : lj;
-    sfor<j + 1, N>([&](auto Cc) {
-      constexpr int c = decltype(Cc)::value;
-      a[c] = fma(-lj, bc<c>(lj), a[c]);
-    });
+    constexpr int cnt = N - j - 1;
+    const double ljj = lj, nljj = nlj;  // this pivot's column (lj is rewritten by level 6)
+    // column j + 1 first: the next pivot's chain hangs on it
+    bc_pipeline<cnt>(
+        [&](auto I) { return bc<j + 1 + decltype(I)::value>(ljj); },
+        [&](auto I, double t) {
+          constexpr int i = decltype(I)::value;
+          a[j + 1 + i] = fma(nljj, t, a[j + 1 + i]);
+          if constexpr (i < kLevels) {
+            FB_SB();
+            level(std::integral_constant<int, j + 1>{}, I);
+          }
+        });
+    if constexpr (j + 1 < N) {
+      sfor<(cnt < kLevels ? cnt : kLevels), kLevels>(
+          [&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
+    }
   });
   return ok;
 }
 
 // Column r of inv(L) for the row-held factor of chol_rows (a[k] = L[r][k],
-// a[r] = 1/L[r][r]).
+// a[r] = 1/L[r][r]).  Column-oriented: once x[k] is known it is folded into every
+// later row's sum, so only one FMA and one multiply per row sit on the chain.
 template <int N>
 FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
-  sfor<0, N>([&](auto RR) {
-    constexpr int rr = decltype(RR)::value;
-    double s = (r == rr) ? 1.0 : 0.0;
-    sfor<0, rr>([&](auto Kk) {
-      constexpr int k = decltype(Kk)::value;
-      s = fma(-bc<rr>(a[k]), x[k], s);
-    });
-    x[rr] = s * bc<rr>(a[rr]);
+  sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
+  double dg = bc<0>(a[0]);  // 1 / L[k][k], fetched one column ahead
+  sfor<0, N>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    if constexpr (k == 0) x[0] *= dg;
+    const double nx = -x[k];
+    if constexpr (k + 1 < N) dg = bc<k + 1>(a[k + 1]);
+    FB_SB();
+    bc_pipeline<N - k - 1>(
+        [&](auto I) { return bc<k + 1 + decltype(I)::value>(a[k]); },
+        [&](auto I, double t) {
+          constexpr int i = decltype(I)::value;
+          x[k + 1 + i] = fma(t, nx, x[k + 1 + i]);
+          if constexpr (i == 0) {
+            FB_SB();
+            x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
+          }
+        });
   });
+}
+
+// acc = sum_c m[c] * (lane c's v), c in [B, E): four partial sums so that the
+// FMAs do not form one dependent chain.
+template <int B, int E, int N>
+FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
+  double p[4] = {init, 0.0, 0.0, 0.0};
+  bc_pipeline<E - B>([&](auto I) { return bc<B + decltype(I)::value>(v); },
+                     [&](auto I, double t) {
+                       constexpr int i = decltype(I)::value;
+                       p[i & 3] = fma(m[B + i], t, p[i & 3]);
+                     });
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// out[c] = lane c's v, c in [0, N)
+template <int N>
+FB_DEV void bc_all(double v, double (&out)[N]) {
+  sfor<0, N>([&](auto Cc) { out[decltype(Cc)::value] = bc<decltype(Cc)::value>(v); });
+  FB_SB();
+}
+// sum_c m[c] * b[c], c in [0, N), four partial sums
+template <int N, int NM, int NB>
+FB_DEV double dot4(const double (&m)[NM], const double (&b)[NB], double init = 0.0) {
+  double p[4] = {init, 0.0, 0.0, 0.0};
+  sfor<0, N>([&](auto Cc) {
+    constexpr int c = decltype(Cc)::value;
+    p[c & 3] = fma(m[c], b[c], p[c & 3]);
+  });
+  return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 template <int NX, int NU, int NC>
@@ -160,6 +279,73 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
   // factor record offsets (doubles)
   static constexpr int fXc = 0, fW = 256, fPinv = 512, fT = 512 + 16 * NX, fTh = fT + 16;
   static constexpr int kRecord = fTh + 16;
+  // Lane-major copy of the stage matrices ("pack", built once per QP by
+  // load_guess): slot pairs interleaved so that one 16-byte load per lane
+  // fetches two slots and every load instruction of a row reads 256 contiguous
+  // bytes.  Element (slot s, lane r) of stage i lives at
+  //   pack + i * kPackStride + (s >> 1) * 32 + r * 2 + (s & 1).
+  // Lanes and stages that have no such row/column hold zeros, so the sweeps load
+  // without predicates.  (Reading E/L columns straight from the MatrixSequence
+  // image costs 64 cache lines per load instruction.)
+  static constexpr int pK = 0;                  // row r of [Q S'; S R], 16 slots
+  static constexpr int pC = 16;                 // column r of C = [E L], NC slots
+  static constexpr int pABr = pC + ((NC + 1) & ~1);  // row r of [A B], 16 slots
+  static constexpr int pABc = pABr + 16;        // column r of [A B], NX slots
+  static constexpr int kPackSlots = (pABc + NX + 1) & ~1;
+  static constexpr int kPackStride = 16 * kPackSlots;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  // slots [S0, S0 + CNT) of the pack record `pk` (already offset by lane) into out[0..CNT)
+  template <int S0, int CNT, int NOUT>
+  static FB_DEV void pack_load(const double* pk, double (&out)[NOUT]) {
+    static_assert((S0 & 1) == 0, "slot ranges start on a pair");
+    sfor<0, (CNT + 1) / 2>([&](auto P_) {
+      constexpr int pr = decltype(P_)::value;
+      const dbl2 t = *reinterpret_cast<const dbl2*>(pk + (S0 / 2 + pr) * 32);
+      out[2 * pr] = t[0];
+      if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
+    });
+  }
+  double* pack = nullptr;
+
+  // x <- caller's guess, y = b - A z (generic), then the lane-major data copy.
+  FB_DEV void load_guess(const C& c) {
+    MpcProblem<C>::load_guess(c);
+    const int r = c.tid;
+    const MpcData D = this->D;
+    const int N = this->lay.N;
+    const bool rx = r < NX, rs_ = r < NS;
+    const int ru = r - NX;
+    pack = this->ws + this->lay.v_pack;
+    for (int i = 0; i <= N; i++) {
+      double* pk = pack + (long)i * kPackStride + r * 2;
+      auto put = [&](int slot, double val) { pk[(slot >> 1) * 32 + (slot & 1)] = val; };
+      for (int cc = 0; cc < 16; cc++) {
+        double kv = 0.0;
+        if (rx && cc < NX) kv = D.Q[(long)i * NX * NX + r + cc * NX];
+        else if (rx && cc < NS) kv = D.S[(long)i * NU * NX + (long)r * NU + (cc - NX)];
+        else if (rs_ && cc < NX) kv = D.S[(long)i * NU * NX + ru + cc * NU];
+        else if (rs_ && cc < NS) kv = D.R[(long)i * NU * NU + ru + (cc - NX) * NU];
+        put(pK + cc, kv);
+        double ab = 0.0;
+        if (rx && i < N && cc < NX) ab = D.A[(long)i * NX * NX + r + cc * NX];
+        else if (rx && i < N && cc < NS) ab = D.B[(long)i * NX * NU + r + (cc - NX) * NX];
+        put(pABr + cc, ab);
+      }
+      for (int k = 0; k < ((NC + 1) & ~1); k++) {
+        double cv = 0.0;
+        if (k < NC && rx) cv = D.E[((long)i * NX + r) * NC + k];
+        else if (k < NC && rs_) cv = D.L[((long)i * NU + ru) * NC + k];
+        put(pC + k, cv);
+      }
+      for (int j = 0; j < kPackSlots - pABc; j++) {
+        double av = 0.0;
+        if (j < NX && i < N && rx) av = D.A[(long)i * NX * NX + (long)r * NX + j];
+        else if (j < NX && i < N && rs_) av = D.B[(long)i * NX * NU + (long)ru * NX + j];
+        put(pABc + j, av);
+      }
+    }
+    c.sync();
+  }
 
   // Step length of an accepted but not yet applied Newton step (0 = none).
   // The forward sweep of the next newton_step applies it stage by stage; every
@@ -202,6 +388,7 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
     double* const dv_ = this->dv; double* const adz_ = this->adz; double* const rz_ = this->rz;
     double* const rl_ = this->rl; double* const wz_ = this->wz; double* const wl_ = this->wl;
     double* const gam_ = this->gam; double* const rvm_ = this->rvm;
+    const double* const pack_ = this->pack + r * 2;
     const bool rx = r < NX;          // lane owns a state row
     const bool rs_ = r < NS;         // lane owns a row of the stage block
     const int ru = r - NX;
@@ -249,31 +436,10 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       in.lbl = lb_[gl];
       in.dll = tp != 0.0 ? dl_[gl] : 0.0;
       in.wll = tp != 0.0 ? wl_[gl] : 0.0;
-      // column r of C = [E L]
-      {
-        const double* src = rx ? D.E + ((long)i * NX + r) * NC : D.L + ((long)i * NU + (rs_ ? ru : 0)) * NC;
-        sfor<0, NC>([&](auto Kk) { in.Cc[decltype(Kk)::value] = src[decltype(Kk)::value]; });
-      }
-      // Row r of [Q S'; S R].  Two lane classes, each with compile-time strides
-      // so that every element is an immediate offset from one base pointer
-      // (per-lane strides make the compiler hoist one address per element).
-      if (rx) {
-        const double* q = D.Q + (long)i * NX * NX + r;
-        const double* st = D.S + (long)i * NU * NX + (long)r * NU;
-        sfor<0, NX>([&](auto Cc) { in.K[decltype(Cc)::value] = q[decltype(Cc)::value * NX]; });
-        sfor<NX, NS>([&](auto Cc) { in.K[decltype(Cc)::value] = st[decltype(Cc)::value - NX]; });
-      } else {
-        const double* sr = D.S + (long)i * NU * NX + (rs_ ? ru : 0);
-        const double* rr = D.R + (long)i * NU * NU + (rs_ ? ru : 0);
-        sfor<0, NX>([&](auto Cc) { in.K[decltype(Cc)::value] = sr[decltype(Cc)::value * NU]; });
-        sfor<NX, NS>([&](auto Cc) { in.K[decltype(Cc)::value] = rr[(decltype(Cc)::value - NX) * NU]; });
-      }
-      if constexpr (NS < 16) {
-        if (!rs_) {
-          sfor<0, NS>([&](auto Cc) { in.K[decltype(Cc)::value] = 0.0; });
-          sfor<0, NC>([&](auto Kk) { in.Cc[decltype(Kk)::value] = 0.0; });
-        }
-      }
+      // column r of C = [E L] and row r of [Q S'; S R] from the lane-major copy
+      const double* pk = pack_ + (long)i * kPackStride;
+      pack_load<pC, NC>(pk, in.Cc);
+      pack_load<pK, NS>(pk, in.K);
     };
     FwdIn cur;
     load_fwd(0, cur);
@@ -336,13 +502,17 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       // K row: H + sigma I + inv(Pi) block + C' Gamma C (:101-123, :142-145).
       // Gamma_k C[k][r] goes to LDS too so that k can stay a rolled loop (a
       // fully unrolled 16x20 product drives the register allocator to spill).
-      sfor<0, NC>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        const double gk = bc<(k & 15)>(Gam[k >> 4]);
-        const double rk = bc<(k & 15)>(Rvm[k >> 4]);
-        r1 = fma(-Cc_[k], rk, r1);
-        Gc[r * CS + k] = gk * Cc_[k];
-      });
+      bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(Gam[decltype(I)::value >> 4]); },
+                      [&](auto I, double gk) { Gc[r * CS + decltype(I)::value] = gk * Cc_[decltype(I)::value]; });
+      {
+        double p[4] = {r1, 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(Rvm[decltype(I)::value >> 4]); },
+                        [&](auto I, double rk) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(-Cc_[k], rk, p[k & 3]);
+                        });
+        r1 = (p[0] + p[1]) + (p[2] + p[3]);
+      }
       sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] += Pinv[decltype(Cc)::value]; });
       c.sync();
 #pragma unroll 2
@@ -356,8 +526,7 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       const double th = thp + r2;
       double gv = r1;
       {
-        double hsum = 0.0;
-        sfor<0, NX>([&](auto Cc) { hsum = fma(Pinv[decltype(Cc)::value], bc<decltype(Cc)::value>(th), hsum); });
+        const double hsum = bc_dot<0, NX>(Pinv, th);
         if (rx) gv = r1 - hsum;
       }
       sfor<0, NX>([&](auto Cc) { F[fPinv + decltype(Cc)::value * 16 + r] = Pinv[decltype(Cc)::value]; });
@@ -366,13 +535,7 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       FB_STAMP_LAP(2);
       // [A B] row r for W, requested now so that it arrives behind the chains
       double AB[NS];
-      sfor<0, NS>([&](auto Cc) { AB[decltype(Cc)::value] = 0.0; });
-      if (rx && i < N) {
-        const double* pa = D.A + (long)i * NX * NX + r;
-        const double* pb = D.B + (long)i * NX * NU + r;
-        sfor<0, NX>([&](auto Cc) { AB[decltype(Cc)::value] = pa[decltype(Cc)::value * NX]; });
-        sfor<NX, NS>([&](auto Cc) { AB[decltype(Cc)::value] = pb[(decltype(Cc)::value - NX) * NX]; });
-      }
+      pack_load<pABr, NS>(pack_ + (long)i * kPackStride, AB);
       // ---- Lc = chol(K), columns of inv(Lc)
       ok = chol_rows<NS>(K, ro, sigma) && ok;
       if (!ok) return false;
@@ -391,19 +554,19 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       sfor<0, NS>([&](auto Cc) { XR[decltype(Cc)::value] = Tr[r * TS + decltype(Cc)::value]; });
       __builtin_amdgcn_sched_barrier(0);
       // t = inv(Lc) g
-      double tvec = 0.0;
-      sfor<0, NS>([&](auto Cc) { tvec = fma(XR[decltype(Cc)::value], bc<decltype(Cc)::value>(gv), tvec); });
+      const double tvec = bc_dot<0, NS>(XR, gv);
       F[fT + r] = tvec;
       FB_STAMP_LAP(5);
       if (i < N) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- W = [A B] inv(Lc)'  (AM and -P of :149-175)
         double W[NS];
-        sfor<0, NS>([&](auto Cc) {
-          constexpr int cc = decltype(Cc)::value;
-          double s = 0.0;
-          sfor<0, cc + 1>([&](auto Kk) { s = fma(AB[decltype(Kk)::value], bc<cc>(XR[decltype(Kk)::value]), s); });
-          W[cc] = s;
+        sfor<0, NS>([&](auto Cc) { W[decltype(Cc)::value] = 0.0; });
+        sfor<0, NS>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          // X[cc][k] = lane cc's XR[k], nonzero for cc >= k
+          bc_pipeline<NS - k>([&](auto I) { return bc<k + decltype(I)::value>(XR[k]); },
+                              [&](auto I, double t) { W[k + decltype(I)::value] = fma(AB[k], t, W[k + decltype(I)::value]); });
         });
         sfor<0, NS>([&](auto Cc) { F[fW + decltype(Cc)::value * 16 + r] = W[decltype(Cc)::value]; });
         // next stage's inputs: in flight during the second chain below
@@ -411,17 +574,16 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         __builtin_amdgcn_sched_barrier(0);
         FB_STAMP_LAP(6);
         // theta(i+1) partial = -W t
-        thp = 0.0;
-        sfor<0, NS>([&](auto Cc) { thp = fma(-W[decltype(Cc)::value], bc<decltype(Cc)::value>(tvec), thp); });
+        thp = -bc_dot<0, NS>(W, tvec);
         // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L)
         double Pn[NX];
-        sfor<0, NX>([&](auto Cc) {
-          constexpr int cc = decltype(Cc)::value;
-          double acc = 0.0;
-          sfor<0, NS>([&](auto Kk) { acc = fma(W[decltype(Kk)::value], bc<cc>(W[decltype(Kk)::value]), acc); });
-          Pn[cc] = rx ? acc : 0.0;
-          __builtin_amdgcn_sched_barrier(0);
+        sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = 0.0; });
+        sfor<0, NS>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          bc_pipeline<NX>([&](auto I) { return bc<decltype(I)::value>(W[k]); },
+                          [&](auto I, double t) { Pn[decltype(I)::value] = fma(W[k], t, Pn[decltype(I)::value]); });
         });
+        sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = rx ? Pn[decltype(Cc)::value] : 0.0; });
         __builtin_amdgcn_sched_barrier(0);
         FB_STAMP_LAP(7);
         ok = chol_rows<NX>(Pn, ro, sigma) && ok;
@@ -431,13 +593,14 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         tri_inv_cols<NX>(Pn, T, ro);
         __builtin_amdgcn_sched_barrier(0);
         // inv(Pi)[r][cc] = sum_k T[k][r] T[k][cc], T[k][cc] = lane cc's T[k] (zero for k < cc)
-        sfor<0, NX>([&](auto Cc) {
-          constexpr int cc = decltype(Cc)::value;
-          double acc = 0.0;
-          sfor<cc, NX>([&](auto Kk) { acc = fma(T[decltype(Kk)::value], bc<cc>(T[decltype(Kk)::value]), acc); });
-          Pinv[cc] = rx ? acc : 0.0;
-          __builtin_amdgcn_sched_barrier(0);
+        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
+        sfor<0, NX>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          // T[k][cc] = lane cc's T[k], nonzero for cc <= k
+          bc_pipeline<k + 1>([&](auto I) { return bc<decltype(I)::value>(T[k]); },
+                             [&](auto I, double t) { Pinv[decltype(I)::value] = fma(T[k], t, Pinv[decltype(I)::value]); });
         });
+        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = rx ? Pinv[decltype(Cc)::value] : 0.0; });
         FB_STAMP_LAP(8);
       }
     }
@@ -455,25 +618,25 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = F[fPinv + decltype(Cc)::value * 16 + r]; });
       double s = F[fT + r];
       const double th = F[fTh + r];
+      const double* pk = pack_ + (long)i * kPackStride;
       double Cc_[NC];
-      {
-        const double* src = rx ? D.E + ((long)i * NX + r) * NC : D.L + ((long)i * NU + (rs_ ? ru : 0)) * NC;
-        sfor<0, NC>([&](auto Kk) { Cc_[decltype(Kk)::value] = rs_ ? src[decltype(Kk)::value] : 0.0; });
-      }
+      pack_load<pC, NC>(pk, Cc_);
+      double lpb[NX];  // dl(i+1), every lane
+      bc_all<NX>(lp, lpb);
       if (i < N) {
         double Wc[NX];
         sfor<0, NX>([&](auto RR) { Wc[decltype(RR)::value] = F[fW + r * 16 + decltype(RR)::value]; });
-        sfor<0, NX>([&](auto RR) { s = fma(-Wc[decltype(RR)::value], bc<decltype(RR)::value>(lp), s); });
+        s -= dot4<NX>(Wc, lpb);
       }
       __builtin_amdgcn_sched_barrier(0);
       // [dx; du] = inv(Lc)' s
-      double dzu = 0.0;
-      sfor<0, NS>([&](auto RR) { dzu = fma(XC[decltype(RR)::value], bc<decltype(RR)::value>(s), dzu); });
+      const double dzu = bc_dot<0, NS>(XC, s);
       // dl = -inv(Pi)(theta + dx)
       const double tx = th + dzu;
-      double dli = 0.0;
-      sfor<0, NX>([&](auto Cc) { dli = fma(-Pinv[decltype(Cc)::value], bc<decltype(Cc)::value>(tx), dli); });
+      double dli = -bc_dot<0, NX>(Pinv, tx);
       if (!rx) dli = 0.0;
+      double dzb[NS];  // [dx; du](i), every lane
+      bc_all<NS>(dzu, dzb);
       if (rs_) dz_[(long)i * NS + r] = dzu;
       if (rx) dl_[(long)i * NX + r] = dli;
       FB_STAMP_LAP(9);
@@ -486,8 +649,9 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
         constexpr int sl = decltype(S_)::value;
         const int k = r + 16 * sl;
         const int kk = k < NC ? k : 0;
-        double a = 0.0;
-        sfor<0, NS>([&](auto Cc) { a = fma(Cl[decltype(Cc)::value * CS + kk], bc<decltype(Cc)::value>(dzu), a); });
+        double clk[NS];
+        sfor<0, NS>([&](auto Cc) { clk[decltype(Cc)::value] = Cl[decltype(Cc)::value * CS + kk]; });
+        const double a = dot4<NS>(clk, dzb);
         double d = 0.0;
         if (k < NC) {
           const long g = (long)i * NC + k;
@@ -509,42 +673,31 @@ struct MpcProblemG16 : MpcProblem<Ctx16> {
       double w = 0.0;
       {
         double Hr[NS];
-        if (rx) {
-          const double* q = D.Q + (long)i * NX * NX + r;
-          const double* st = D.S + (long)i * NU * NX + (long)r * NU;
-          sfor<0, NX>([&](auto Cc) { Hr[decltype(Cc)::value] = q[decltype(Cc)::value * NX]; });
-          sfor<NX, NS>([&](auto Cc) { Hr[decltype(Cc)::value] = st[decltype(Cc)::value - NX]; });
-        } else if (rs_) {
-          const double* sr = D.S + (long)i * NU * NX + ru;
-          const double* rr = D.R + (long)i * NU * NU + ru;
-          sfor<0, NX>([&](auto Cc) { Hr[decltype(Cc)::value] = sr[decltype(Cc)::value * NU]; });
-          sfor<NX, NS>([&](auto Cc) { Hr[decltype(Cc)::value] = rr[(decltype(Cc)::value - NX) * NU]; });
-        } else {
-          sfor<0, NS>([&](auto Cc) { Hr[decltype(Cc)::value] = 0.0; });
-        }
-        sfor<0, NS>([&](auto Cc) { w = fma(Hr[decltype(Cc)::value], bc<decltype(Cc)::value>(dzu), w); });
+        pack_load<pK, NS>(pk, Hr);
+        w = dot4<NS>(Hr, dzb);
       }
-      sfor<0, NC>([&](auto Kk) { constexpr int k = decltype(Kk)::value; w = fma(Cc_[k], bc<(k & 15)>(dvs[k >> 4]), w); });
+      {
+        double p[4] = {w, 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
+                        [&](auto I, double t) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(Cc_[k], t, p[k & 3]);
+                        });
+        w = (p[0] + p[1]) + (p[2] + p[3]);
+      }
       w -= dli;  // zero on the input rows
       if (i < N) {
         // column r of [A B] dot dl(i+1); row r of [A B] dot dz(i)
-        if (rs_) {
-          const double* pc = rx ? D.A + (long)i * NX * NX + (long)r * NX : D.B + (long)i * NX * NU + (long)ru * NX;
+        {
           double Ac[NX];
-          sfor<0, NX>([&](auto RR) { Ac[decltype(RR)::value] = pc[decltype(RR)::value]; });
-          sfor<0, NX>([&](auto RR) { w = fma(Ac[decltype(RR)::value], bc<decltype(RR)::value>(lp), w); });
+          pack_load<pABc, NX>(pk, Ac);
+          w += dot4<NX>(Ac, lpb);  // zero rows where there is no column
         }
         double abz = 0.0;
         {
           double AB[NS];
-          sfor<0, NS>([&](auto Cc) { AB[decltype(Cc)::value] = 0.0; });
-          if (rx) {
-            const double* pa = D.A + (long)i * NX * NX + r;
-            const double* pb = D.B + (long)i * NX * NU + r;
-            sfor<0, NX>([&](auto Cc) { AB[decltype(Cc)::value] = pa[decltype(Cc)::value * NX]; });
-            sfor<NX, NS>([&](auto Cc) { AB[decltype(Cc)::value] = pb[(decltype(Cc)::value - NX) * NX]; });
-          }
-          sfor<0, NS>([&](auto Cc) { abz = fma(AB[decltype(Cc)::value], bc<decltype(Cc)::value>(dzu), abz); });
+          pack_load<pABr, NS>(pk, AB);
+          abz = dot4<NS>(AB, dzb);
         }
         if (rx) {
           // l block i+1: wl = -(A dx + B du - dx(i+1)); trial norms (full_residual.cc:60-66)

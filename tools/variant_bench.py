@@ -14,6 +14,13 @@ from fbstab_amd import fixtures as fx, hip_api  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 p = fx.synthetic_mpc_batch(B)
+same = os.environ.get("FB_SAME")
+if same is not None:
+    # every QP of the batch is a physical copy of instance `same` (no divergence
+    # between the rows of a wavefront; same HBM traffic pattern)
+    p1 = fx.synthetic_mpc_batch(1, first_id=int(same))
+    for k in p.arrays:
+        p.arrays[k] = np.ascontiguousarray(np.broadcast_to(p1.arrays[k], p.arrays[k].shape))
 dev = torch.device("cuda:0")
 s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B)
 data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
