@@ -38,20 +38,30 @@ struct Solver {
   // sqrt(sum rz^2 + sum rl^2 + sum pnr(y,v)^2): norm of the penalised natural
   // residual at the current x (full_residual.cc:99-109, :40-42).
   FB_DEV double pnr_norm() const {
-    double s[1] = {0.0};
-    for (int i = c.tid; i < p.nz; i += C::nt) s[0] += p.rz[i] * p.rz[i];
-    for (int i = c.tid; i < p.nl; i += C::nt) s[0] += p.rl[i] * p.rl[i];
-    for (int i = c.tid; i < p.nv; i += C::nt) {
-      const double r = pnr(p.y[i], p.v[i], o.alpha);
-      s[0] += r * r;
+    if constexpr (P::kOwnVectorOps) {
+      return p.pnr_norm(c, o.alpha);
+    } else {
+      double s[1] = {0.0};
+      for (int i = c.tid; i < p.nz; i += C::nt) s[0] += p.rz[i] * p.rz[i];
+      for (int i = c.tid; i < p.nl; i += C::nt) s[0] += p.rl[i] * p.rl[i];
+      for (int i = c.tid; i < p.nv; i += C::nt) {
+        const double r = pnr(p.y[i], p.v[i], o.alpha);
+        s[0] += r * r;
+      }
+      c.sum(s);
+      return sqrt(s[0]);
     }
-    c.sum(s);
-    return sqrt(s[0]);
   }
 
   // (Ei, Eo) at x + t*dx for the proximal subproblem centred at xbar
   // (full_residual.cc:49-74 and :99-109).  t == 0 never touches dx/W.
   FB_DEV void norms_at(double t, double sigma, bool want_outer, double* Ei, double* Eo) const {
+    if constexpr (P::kOwnVectorOps) {
+      double e[1], f[1];
+      p.template norms_at_multi<1>(c, t, 1.0, sigma, o.alpha, e, f);
+      *Ei = e[0];
+      *Eo = f[0];
+    } else {
     double s[2] = {0.0, 0.0};
     for (int i = c.tid; i < p.nz; i += C::nt) {
       double r = p.rz[i], zi = p.z[i];
@@ -90,6 +100,7 @@ struct Solver {
     c.sum(s);
     *Ei = sqrt(s[0]);
     *Eo = sqrt(s[1]);
+    }
   }
 
   // The norms of norms_at() for K step lengths t0*beta^k in ONE pass over the
@@ -98,6 +109,9 @@ struct Solver {
   template <int K>
   FB_DEV void norms_at_multi(double t0, double beta, double sigma, double (&Ei)[K],
                              double (&Eo)[K]) const {
+    if constexpr (P::kOwnVectorOps) {
+      p.template norms_at_multi<K>(c, t0, beta, sigma, o.alpha, Ei, Eo);
+    } else {
     double tt[K];
     tt[0] = t0;
 #pragma unroll
@@ -143,6 +157,7 @@ struct Solver {
     for (int k = 0; k < K; k++) {
       Ei[k] = sqrt(s[k]);
       Eo[k] = sqrt(s[K + k]);
+    }
     }
   }
 
@@ -301,9 +316,13 @@ struct Solver {
       Eo = Eot;
       FB_STAMP_LAP(18);
     }
-    p.flush(c);
-    for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
-    c.sync();
+    if constexpr (P::kOwnVectorOps) {
+      p.flush_and_project(c);
+    } else {
+      p.flush(c);
+      for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
+      c.sync();
+    }
     return Eo_top;
   }
 
@@ -334,7 +353,7 @@ struct Solver {
         combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
         p.load_guess(c);
         copy_x_to_xbar();
-        dx_norm = sqrt((double)(p.nz + p.nl + p.nv));
+        dx_norm = sqrt((double)p.num_primal_dual());
         p.residual(c);
         Ek = pnr_norm();
         E0 = Ek;
@@ -452,9 +471,13 @@ struct Solver {
       } else {
         // subproblem epilogue (impl:301-303) and the rest of the proximal
         // iteration (impl:186-216)
-        p.flush(c);
-        for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
-        c.sync();
+        if constexpr (P::kOwnVectorOps) {
+          p.flush_and_project(c);
+        } else {
+          p.flush(c);
+          for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
+          c.sync();
+        }
         const double Eo_ret = Eo_top;
         if (newton >= o.max_newton_iters) {
           if (Eo_ret < Ek) {
@@ -469,25 +492,7 @@ struct Solver {
           phase = kFetch;
           continue;
         }
-        double s[1] = {0.0};
-        for (int i = c.tid; i < p.nz; i += C::nt) {
-          const double d = p.z[i] - p.zb[i];
-          p.dz[i] = d;
-          s[0] += d * d;
-        }
-        for (int i = c.tid; i < p.nl; i += C::nt) {
-          const double d = p.l[i] - p.lb[i];
-          p.dl[i] = d;
-          s[0] += d * d;
-        }
-        for (int i = c.tid; i < p.nv; i += C::nt) {
-          const double d = p.v[i] - p.vb[i];
-          p.dv[i] = d;
-          s[0] += d * d;
-        }
-        c.sum(s);
-        dx_norm = sqrt(s[0]);
-        c.sync();
+        dx_norm = dx_from_xbar();
         if (o.check_feasibility) {
           const int f = p.feasibility(c, o.infeas_tol);
           if (f != kFeasible) {
@@ -516,7 +521,7 @@ struct Solver {
     const double combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
     p.load_guess(c);  // xk <- (z0,l0,v0), y = b - A z (impl:140, :334-347)
     copy_x_to_xbar();
-    double dx_norm = sqrt((double)(p.nz + p.nl + p.nv));  // dx.Fill(1) (impl:142)
+    double dx_norm = sqrt((double)p.num_primal_dual());  // dx.Fill(1) (impl:142)
     p.residual(c);
     double Ek = pnr_norm();
     const double E0 = Ek;
@@ -571,25 +576,7 @@ struct Solver {
       }
       // dx <- x(k+1) - x(k) (impl:202-203); its norm excludes y
       // (full_variable.cc:77-83).
-      double s[1] = {0.0};
-      for (int i = c.tid; i < p.nz; i += C::nt) {
-        const double d = p.z[i] - p.zb[i];
-        p.dz[i] = d;
-        s[0] += d * d;
-      }
-      for (int i = c.tid; i < p.nl; i += C::nt) {
-        const double d = p.l[i] - p.lb[i];
-        p.dl[i] = d;
-        s[0] += d * d;
-      }
-      for (int i = c.tid; i < p.nv; i += C::nt) {
-        const double d = p.v[i] - p.vb[i];
-        p.dv[i] = d;
-        s[0] += d * d;
-      }
-      c.sum(s);
-      dx_norm = sqrt(s[0]);
-      c.sync();
+      dx_norm = dx_from_xbar();
       if (o.check_feasibility) {
         const int f = p.feasibility(c, o.infeas_tol);
         if (f != kFeasible) {
@@ -617,14 +604,44 @@ struct Solver {
   }
 
  private:
-  FB_DEV void copy_x_to_xbar() const {
-    for (int i = c.tid; i < p.nz; i += C::nt) p.zb[i] = p.z[i];
-    for (int i = c.tid; i < p.nl; i += C::nt) p.lb[i] = p.l[i];
-    for (int i = c.tid; i < p.nv; i += C::nt) {
-      p.vb[i] = p.v[i];
-      p.yb[i] = p.y[i];
+  // dx <- x - xbar (z, l, v blocks); returns its norm.
+  FB_DEV double dx_from_xbar() const {
+    if constexpr (P::kOwnVectorOps) {
+      return p.dx_from_xbar(c);
+    } else {
+      double s[1] = {0.0};
+      for (int i = c.tid; i < p.nz; i += C::nt) {
+        const double d = p.z[i] - p.zb[i];
+        p.dz[i] = d;
+        s[0] += d * d;
+      }
+      for (int i = c.tid; i < p.nl; i += C::nt) {
+        const double d = p.l[i] - p.lb[i];
+        p.dl[i] = d;
+        s[0] += d * d;
+      }
+      for (int i = c.tid; i < p.nv; i += C::nt) {
+        const double d = p.v[i] - p.vb[i];
+        p.dv[i] = d;
+        s[0] += d * d;
+      }
+      c.sum(s);
+      c.sync();
+      return sqrt(s[0]);
     }
-    c.sync();
+  }
+  FB_DEV void copy_x_to_xbar() const {
+    if constexpr (P::kOwnVectorOps) {
+      p.copy_x_to_xbar(c);
+    } else {
+      for (int i = c.tid; i < p.nz; i += C::nt) p.zb[i] = p.z[i];
+      for (int i = c.tid; i < p.nl; i += C::nt) p.lb[i] = p.l[i];
+      for (int i = c.tid; i < p.nv; i += C::nt) {
+        p.vb[i] = p.v[i];
+        p.yb[i] = p.y[i];
+      }
+      c.sync();
+    }
   }
   FB_DEV void finish(fbstab_solver_out_t* out, int eflag, double residual, int newton,
                      int prox, double E0) const {

@@ -65,6 +65,7 @@ struct DenseLayout {
 template <class C>
 struct DenseProblem {
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
+  static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
   DenseLayout lay;
   DenseData D;
   double *uz, *ul, *uv, *uy;
@@ -129,6 +130,7 @@ struct DenseProblem {
     c.sum(s);
     return sqrt(s[0]);
   }
+  FB_DEV int num_primal_dual() const { return nz + nl + nv; }
   FB_DEV double bvec(int i) const { return D.b[i]; }
 
   FB_DEV void load_guess(const C& c) const {

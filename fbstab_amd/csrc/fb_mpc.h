@@ -118,6 +118,7 @@ struct MpcLayout {
 template <class C>
 struct MpcProblem {
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
+  static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
   MpcLayout lay;
   MpcData D;
   double *uz, *ul, *uv, *uy;  // caller's (z,l,v,y) for this QP
@@ -259,6 +260,7 @@ struct MpcProblem {
     return sqrt(s[0]);
   }
 
+  FB_DEV int num_primal_dual() const { return nz + nl + nv; }
   FB_DEV double bvec(int i) const { return -D.d[i]; }  // b = -d (mpc_data.cc:276-289)
 
   // x <- caller's guess; y = b - A z (impl:334-347, full_variable.cc:47-53).

@@ -1,0 +1,934 @@
+// Record-based 16-lane MPC policy: FOUR QPs per 64-wide wavefront (one per
+// 16-lane DPP row), every array of a QP kept in ONE stage-major, lane-major
+// workspace so that each sweep over the horizon touches one contiguous record
+// per stage through a single base pointer.
+//
+// Mathematics: the block form of RiccatiLinearSolver documented at the top of
+// fb_mpc_g16.h (riccati_linear_solver.cc:77-344), the residual / feasibility /
+// variable algebra of full_residual.cc:49-109, full_feasibility.cc:25-88,
+// full_variable.cc:47-83 and the implicit block products of mpc_data.cc:17-289.
+// What differs from MpcProblemG16 is where the data lives and who runs the
+// proximal-level passes:
+//
+//   * Stage record i of a QP = kSlots slots of 16 doubles, lane r of the row
+//     owning element r of every slot:
+//       iterate vectors  z rz zb lb dz wz l rl dl wl | v y vb yb dv adz gam rvm
+//       constants        f h b                        (mpc_data.cc:240-289)
+//       matrix copy      row r of [Q S';S R], column r of [E L], row r and
+//                        column r of [A B]            (built once per QP)
+//       factor record    inv(Lc) by columns and by rows, inv(Pi), t, theta
+//     Slots are interleaved in pairs ((s>>1)*32 + 2r + (s&1)): one 16-byte
+//     access per lane moves two slots and every memory instruction of a row
+//     covers 256 contiguous bytes.  Lanes without an element hold zeros, so the
+//     sweeps carry no lane predicates on loads.
+//   * residual, feasibility, norms, the variable updates and the I/O passes are
+//     written for this layout too (one pass over the records each) instead of
+//     borrowing the workgroup-generic LDS-tile code: they cost a fraction of a
+//     Newton step, which is what lets rows of a wavefront run out of step.
+//   * the barrier Hessian C'Gamma C is accumulated with DPP broadcasts (no LDS
+//     round trip); LDS only transposes inv(Lc) (forward) and C (backward, for
+//     A dz): 2.9 KB per QP.
+//   * inv(Lc) is recorded by rows as well, so that the backward sweep forms
+//     W'dl = inv(Lc)([A B]'dl) from the already needed [A B]'dl instead of
+//     reading W by columns.
+#pragma once
+
+#include "fb_mpc_g16.h"
+
+namespace fbk {
+
+#if !defined(FB_HOSTSIM)
+
+// Batch descriptors as the kernel receives them (one base + stride per array).
+struct MpcBatchPtrs {
+  const double* base[12];
+  long long stride[12];
+};
+struct VarBatchPtrs {
+  double* base[4];
+  long long stride[4];
+};
+
+template <int NX, int NU, int NC>
+struct MpcR16 {
+  typedef Ctx16 C;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  static constexpr bool kFusedTrial = true;
+  static constexpr bool kOwnVectorOps = true;
+#if defined(FB_R16_PREFETCH)
+  static constexpr bool kPrefetch = FB_R16_PREFETCH != 0;
+#else
+  static constexpr bool kPrefetch = false;
+#endif
+  static constexpr int NS = NX + NU;
+  static constexpr int KS = (NC + 15) / 16;  // constraint slots per lane
+  static_assert(NS <= 16, "stage width must fit one DPP row");
+
+  // ---- stage record ----------------------------------------------------------
+  static constexpr int sZ = 0, sRZ = 1, sZB = 2, sLB = 3, sDZ = 4, sWZ = 5, sL = 6, sRL = 7,
+                       sDL = 8, sWL = 9;
+  static constexpr int sV = 10;              // pairs (V_s, Y_s)
+  static constexpr int sVB = sV + 2 * KS;    // pairs (VB_s, YB_s)
+  static constexpr int sDV = sVB + 2 * KS;   // pairs (DV_s, ADZ_s)
+  static constexpr int sGAM = sDV + 2 * KS;  // pairs (GAM_s, RVM_s)
+  static constexpr int sF = sGAM + 2 * KS, sH = sF + 1;
+  static constexpr int sB = sH + 1;          // KS slots
+  static constexpr int pK = (sB + KS + 1) & ~1;        // row r of [Q S'; S R], 16 slots
+  static constexpr int pC = pK + 16;                   // column r of C = [E L], NC slots
+  static constexpr int pABr = pC + ((NC + 1) & ~1);    // row r of [A B], 16 slots
+  static constexpr int pABc = pABr + 16;               // column r of [A B], NX slots
+  static constexpr int fXc = (pABc + NX + 1) & ~1;     // inv(Lc): lane r = column r
+  static constexpr int fXr = fXc + 16;                 // inv(Lc): lane r = row r
+  static constexpr int fPinv = fXr + 16;               // inv(Pi), NX slots
+  static constexpr int fT = (fPinv + NX + 1) & ~1, fTh = fT + 1;
+  static constexpr int kSlots = fT + 2;
+  static constexpr int kRec = 16 * kSlots;  // doubles per stage
+  static constexpr long ws_doubles(int N) { return (long)kRec * (N + 1); }
+
+  static constexpr int off(int slot) { return (slot >> 1) * 32 + (slot & 1); }
+
+  // LDS of one row: C as [col][k] (backward sweep, A z products) or the 16 x 16
+  // transpose buffer (forward sweep); odd strides, rows 16 doubles mod 32 apart.
+  static constexpr int CS = NC | 1, TS = 17;
+  static constexpr int kLdsDoubles = 16 * (CS > TS ? CS : TS);
+  static constexpr int kLdsPerRow = ((kLdsDoubles + 31) & ~31) + 16;
+
+  // ---- state -------------------------------------------------------------------
+  double* rec;  // this row's records, lane offset included
+  lds_ptr lds;
+  const MpcBatchPtrs* data;  // kernel arguments (uniform)
+  const VarBatchPtrs* var;
+  long q;  // QP index
+  int N;
+  // Step length of an accepted but not yet applied Newton step (0 = none); the
+  // next forward sweep applies it stage by stage, everything else flushes first.
+  double pend_t;
+
+  FB_DEV void bind(double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d, const VarBatchPtrs* x,
+                   long q_, int N_, int lane16) {
+    rec = ws_row + 2 * lane16;
+    lds = lds_row;
+    data = d;
+    var = x;
+    q = q_;
+    N = N_;
+    pend_t = 0.0;
+  }
+  FB_DEV int num_primal_dual() const { return (N + 1) * (NS + NX + NC); }
+
+  // ---- record access -------------------------------------------------------------
+  static FB_DEV double ld(const double* R, int slot) { return R[off(slot)]; }
+  static FB_DEV void st(double* R, int slot, double v) { R[off(slot)] = v; }
+  static FB_DEV dbl2 ld2(const double* R, int even_slot) {
+    return *reinterpret_cast<const dbl2*>(R + off(even_slot));
+  }
+  static FB_DEV void st2(double* R, int even_slot, double a, double b) {
+    dbl2 t = {a, b};
+    *reinterpret_cast<dbl2*>(R + off(even_slot)) = t;
+  }
+  // slots [S0, S0 + CNT) into out[0..CNT); S0 even
+  template <int S0, int CNT, int NOUT>
+  static FB_DEV void ldv(const double* R, double (&out)[NOUT]) {
+    static_assert((S0 & 1) == 0, "slot ranges start on a pair");
+    sfor<0, (CNT + 1) / 2>([&](auto P_) {
+      constexpr int pr = decltype(P_)::value;
+      const dbl2 t = *reinterpret_cast<const dbl2*>(R + (S0 / 2 + pr) * 32);
+      out[2 * pr] = t[0];
+      if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
+    });
+  }
+  template <int S0, int CNT, int NIN>
+  static FB_DEV void stv(double* R, const double (&in)[NIN]) {
+    static_assert((S0 & 1) == 0, "slot ranges start on a pair");
+    sfor<0, CNT / 2>([&](auto P_) {
+      constexpr int pr = decltype(P_)::value;
+      dbl2 t = {in[2 * pr], in[2 * pr + 1]};
+      *reinterpret_cast<dbl2*>(R + (S0 / 2 + pr) * 32) = t;
+    });
+    if constexpr (CNT & 1) R[(S0 / 2 + CNT / 2) * 32] = in[CNT - 1];
+  }
+
+  // (A zz)_k for the constraints k = r + 16 s of this lane, zz given in every
+  // lane (zb[c] = element c of the stage vector): C through its LDS transpose.
+  // Caller has written Cl and synchronised.
+  template <class Out>
+  FB_DEV void rows_of_C_times(lds_ptr Cl, const double (&zb)[NS], int r, Out&& out) const {
+    sfor<0, KS>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      const int k = r + 16 * s;
+      const int kk = k < NC ? k : 0;
+      double clk[NS];
+      sfor<0, NS>([&](auto Cc) { clk[decltype(Cc)::value] = Cl[decltype(Cc)::value * CS + kk]; });
+      out(S_, k < NC, dot4<NS>(clk, zb));
+    });
+  }
+  FB_DEV void C_to_lds(const C& c, lds_ptr Cl, const double (&Cc)[NC], int r) const {
+    c.sync();
+    sfor<0, NC>([&](auto Kk) { Cl[r * CS + decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
+    c.sync();
+  }
+
+  // ---- pointers into the caller's arrays ----------------------------------------
+  FB_DEV const double* arr(int a) const { return data->base[a] + q * data->stride[a]; }
+  FB_DEV double* xarr(int a) const { return var->base[a] + q * var->stride[a]; }
+
+  // ||(f,h,b)||_2 (mpc_data.h:88-97).
+  FB_DEV double forcing_norm(const C& c) const {
+    const int N_ = N;
+    const double *pq = arr(FBSTAB_MPC_q), *pr = arr(FBSTAB_MPC_r), *pd = arr(FBSTAB_MPC_d),
+                 *px0 = arr(FBSTAB_MPC_x0), *pc = arr(FBSTAB_MPC_c);
+    double s = 0.0;
+    for (int i = c.tid; i < (N_ + 1) * NX; i += 16) s += pq[i] * pq[i];
+    for (int i = c.tid; i < (N_ + 1) * NU; i += 16) s += pr[i] * pr[i];
+    for (int i = c.tid; i < (N_ + 1) * NC; i += 16) s += pd[i] * pd[i];
+    for (int i = c.tid; i < NX; i += 16) s += px0[i] * px0[i];
+    for (int i = c.tid; i < N_ * NX; i += 16) s += pc[i] * pc[i];
+    return sqrt(row_reduce<OpSum16>(s));
+  }
+
+  // x <- caller's guess, y = b - A z (impl:334-347, full_variable.cc:47-53), and
+  // the one-off copies of the problem data into the records.
+  FB_DEV void load_guess(const C& c) {
+    const int r = c.tid, N_ = N;
+    const bool rx = r < NX, rs_ = r < NS;
+    const int ru = r - NX;
+    double* const R0 = rec;
+    lds_ptr Cl = lds;
+    const double *Q = arr(FBSTAB_MPC_Q), *Rm = arr(FBSTAB_MPC_R), *S = arr(FBSTAB_MPC_S),
+                 *pq = arr(FBSTAB_MPC_q), *pr = arr(FBSTAB_MPC_r), *A = arr(FBSTAB_MPC_A),
+                 *B = arr(FBSTAB_MPC_B), *pc = arr(FBSTAB_MPC_c), *E = arr(FBSTAB_MPC_E),
+                 *L = arr(FBSTAB_MPC_L), *pd = arr(FBSTAB_MPC_d), *px0 = arr(FBSTAB_MPC_x0);
+    const double *uz = xarr(0), *ul = xarr(1), *uv = xarr(2);
+    pend_t = 0.0;
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      const bool has_ab = i < N_;
+      // matrices
+      double Kr[16], ABr[16], Cc[NC], ABc[NX];
+      sfor<0, 16>([&](auto Cc_) {
+        constexpr int cc = decltype(Cc_)::value;
+        double kv = 0.0, ab = 0.0;
+        if constexpr (cc < NX) {
+          if (rx) kv = Q[(long)i * NX * NX + r + cc * NX];
+          else if (rs_) kv = S[(long)i * NU * NX + ru + cc * NU];
+          if (rx && has_ab) ab = A[(long)i * NX * NX + r + cc * NX];
+        } else if constexpr (cc < NS) {
+          if (rx) kv = S[(long)i * NU * NX + (long)r * NU + (cc - NX)];
+          else if (rs_) kv = Rm[(long)i * NU * NU + ru + (cc - NX) * NU];
+          if (rx && has_ab) ab = B[(long)i * NX * NU + r + (cc - NX) * NX];
+        }
+        Kr[cc] = kv;
+        ABr[cc] = ab;
+      });
+      {
+        const double* src = rx ? E + ((long)i * NX + r) * NC : L + ((long)i * NU + (rs_ ? ru : 0)) * NC;
+        sfor<0, NC>([&](auto Kk) { Cc[decltype(Kk)::value] = rs_ ? src[decltype(Kk)::value] : 0.0; });
+      }
+      {
+        const double* src = rx ? A + (long)i * NX * NX + (long)r * NX
+                               : B + (long)i * NX * NU + (long)(rs_ ? ru : 0) * NX;
+        sfor<0, NX>([&](auto J) { ABc[decltype(J)::value] = (rs_ && has_ab) ? src[decltype(J)::value] : 0.0; });
+      }
+      stv<pK, 16>(R, Kr);
+      stv<pABr, 16>(R, ABr);
+      stv<pC, NC>(R, Cc);
+      stv<pABc, NX>(R, ABc);
+      // constants f, h, b (mpc_data.cc:240-289)
+      const double f = rx ? pq[(long)i * NX + r] : (rs_ ? pr[(long)i * NU + ru] : 0.0);
+      const double h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * NX + r]) : 0.0;
+      st2(R, sF, f, h);
+      // the guess and y = b - A z
+      const double zz = rs_ ? uz[(long)i * NS + r] : 0.0;
+      const double ll = rx ? ul[(long)i * NX + r] : 0.0;
+      st2(R, sZ, zz, 0.0);
+      st2(R, sL, ll, 0.0);
+      st2(R, sDZ, 0.0, 0.0);
+      st2(R, sDL, 0.0, 0.0);
+      double zb[NS];
+      bc_all<NS>(zz, zb);
+      C_to_lds(c, Cl, Cc, r);
+      rows_of_C_times(Cl, zb, r, [&](auto S_, bool valid, double az) {
+        constexpr int s = decltype(S_)::value;
+        const int k = r + 16 * s;
+        const double b = valid ? -pd[(long)i * NC + k] : 0.0;
+        const double vv = valid ? uv[(long)i * NC + k] : 0.0;
+        st(R, sB + s, b);
+        st2(R, sV + 2 * s, vv, valid ? b - az : 0.0);
+        st2(R, sDV + 2 * s, 0.0, 0.0);
+      });
+    }
+    c.sync();
+  }
+
+  // Natural residual blocks at x: rz = Hz + f + G'l + A'v, rl = h - Gz
+  // (full_residual.cc:79-91; mpc_data.cc:28-63, :127-152, :171-198, :217-237).
+  FB_DEV void residual(const C& c) const {
+    const int r = c.tid, N_ = N;
+    const bool rx = r < NX;
+    double* const R0 = rec;
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+      ldv<pK, NS>(R, Kr);
+      ldv<pC, NC>(R, Cc);
+      ldv<pABr, NS>(R, ABr);
+      ldv<pABc, NX>(R, ABc);
+      const double zz = ld(R, sZ), ll = ld(R, sL);
+      const dbl2 fh = ld2(R, sF);
+      double vs[KS];
+      sfor<0, KS>([&](auto S_) { vs[decltype(S_)::value] = ld(R, sV + 2 * decltype(S_)::value); });
+      double ln = 0.0, zn = 0.0;  // l(i+1), z(i+1)
+      double hn = 0.0;
+      if (i < N_) {
+        ln = ld(R + kRec, sL);
+        zn = ld(R + kRec, sZ);
+        hn = ld(R + kRec, sH);
+      }
+      double zb[NS], lnb[NX];
+      bc_all<NS>(zz, zb);
+      bc_all<NX>(ln, lnb);
+      double s = fh[0] + dot4<NS>(Kr, zb);
+      s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
+      {
+        double p[4] = {s, 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(vs[decltype(I)::value >> 4]); },
+                        [&](auto I, double t) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
+                        });
+        s = (p[0] + p[1]) + (p[2] + p[3]);
+      }
+      st(R, sRZ, s);  // zero where there is no row: every term is
+      // block 0: h0 - (Gz)0 = -x0 + x(0); block i+1: -c(i) - (A x + B u - x(i+1))
+      if (i == 0) st(R, sRL, rx ? fh[1] + zz : 0.0);
+      if (i < N_) {
+        const double abz = dot4<NS>(ABr, zb);
+        st(R + kRec, sRL, rx ? hn - (abz - zn) : 0.0);
+      }
+    }
+    c.sync();
+  }
+
+  // sqrt(sum rz^2 + rl^2 + pnr(y,v)^2) (full_residual.cc:99-109, :40-42).
+  FB_DEV double pnr_norm(const C& c, double alpha) const {
+    const int N_ = N;
+    const double* const R0 = rec;
+    double s = 0.0;
+    for (int i = 0; i <= N_; i++) {
+      const double* R = R0 + (long)i * kRec;
+      const double a = ld(R, sRZ), b = ld(R, sRL);
+      s = fma(a, a, s);
+      s = fma(b, b, s);
+      sfor<0, KS>([&](auto S_) {
+        const dbl2 vy = ld2(R, sV + 2 * decltype(S_)::value);
+        const double p = pnr(vy[1], vy[0], alpha);  // zero on padding lanes
+        s = fma(p, p, s);
+      });
+    }
+    return sqrt(row_reduce<OpSum16>(s));
+  }
+
+  // (Ei, Eo) at x + t dx for the K step lengths t0 beta^k in one pass
+  // (full_residual.cc:49-74 and :99-109).  A pending step is applied first.
+  template <int K>
+  FB_DEV void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
+                             double (&Ei)[K], double (&Eo)[K]) {
+    flush(c);
+    const int N_ = N;
+    const double* const R0 = rec;
+    double tt[K], s[2 * K];
+    tt[0] = t0;
+    sfor<1, K>([&](auto Kk) { tt[decltype(Kk)::value] = tt[decltype(Kk)::value - 1] * beta; });
+    sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
+    for (int i = 0; i <= N_; i++) {
+      const double* R = R0 + (long)i * kRec;
+      const dbl2 zr = ld2(R, sZ), bb = ld2(R, sZB), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+      sfor<0, K>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        const double rzt = fma(tt[k], dw[1], zr[1]);
+        const double rzi = rzt + sigma * (fma(tt[k], dw[0], zr[0]) - bb[0]);
+        const double rlt = fma(tt[k], dwl[1], lr[1]);
+        const double rli = rlt + sigma * (fma(tt[k], dwl[0], lr[0]) - bb[1]);
+        s[k] = fma(rzi, rzi, s[k]);
+        s[k] = fma(rli, rli, s[k]);
+        s[K + k] = fma(rzt, rzt, s[K + k]);
+        s[K + k] = fma(rlt, rlt, s[K + k]);
+      });
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const dbl2 vy = ld2(R, sV + 2 * sl), da = ld2(R, sDV + 2 * sl);
+        const double vb = ld(R, sVB + 2 * sl);
+        sfor<0, K>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          const double vi = fma(tt[k], da[0], vy[0]);
+          const double yi = fma(-tt[k], da[1], vy[1]);
+          const double ys = yi + sigma * (vi - vb);
+          const double ph = pfb(ys, vi, alpha);
+          const double pn = pnr(yi, vi, alpha);
+          s[k] = fma(ph, ph, s[k]);
+          s[K + k] = fma(pn, pn, s[K + k]);
+        });
+      });
+    }
+    sfor<0, K>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      Ei[k] = sqrt(row_reduce<OpSum16>(s[k]));
+      Eo[k] = sqrt(row_reduce<OpSum16>(s[K + k]));
+    });
+  }
+
+  // x <- x + t dx, (rz, rl) <- (rz, rl) + t W for the pending step (impl:298,
+  // full_variable.cc:55-65); with `project`, v <- max(v, 0) as well (impl:301).
+  template <bool PROJECT>
+  FB_DEV void flush_impl(const C& c) {
+    const double t = pend_t;
+    pend_t = 0.0;
+    if (t == 0.0 && !PROJECT) return;
+    const int N_ = N;
+    double* const R0 = rec;
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      if (t != 0.0) {
+        const dbl2 zr = ld2(R, sZ), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+        st2(R, sZ, fma(t, dw[0], zr[0]), fma(t, dw[1], zr[1]));
+        st2(R, sL, fma(t, dwl[0], lr[0]), fma(t, dwl[1], lr[1]));
+      }
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        dbl2 vy = ld2(R, sV + 2 * sl);
+        if (t != 0.0) {
+          const dbl2 da = ld2(R, sDV + 2 * sl);
+          vy[0] = fma(t, da[0], vy[0]);
+          vy[1] = fma(-t, da[1], vy[1]);
+        }
+        if (PROJECT) vy[0] = fmax0(vy[0]);
+        st2(R, sV + 2 * sl, vy[0], vy[1]);
+      });
+    }
+    c.sync();
+  }
+  FB_DEV void flush(const C& c) { flush_impl<false>(c); }
+  FB_DEV void flush_and_project(const C& c) { flush_impl<true>(c); }
+
+  // dx <- x - xbar on (z, l, v); returns ||dx|| (impl:202-203, full_variable.cc:77-83).
+  FB_DEV double dx_from_xbar(const C& c) const {
+    const int N_ = N;
+    double* const R0 = rec;
+    double s = 0.0;
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      const dbl2 bb = ld2(R, sZB);
+      const double dz = ld(R, sZ) - bb[0], dl = ld(R, sL) - bb[1];
+      st(R, sDZ, dz);
+      st(R, sDL, dl);
+      s = fma(dz, dz, s);
+      s = fma(dl, dl, s);
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const double dv = ld(R, sV + 2 * sl) - ld(R, sVB + 2 * sl);
+        st(R, sDV + 2 * sl, dv);
+        s = fma(dv, dv, s);
+      });
+    }
+    c.sync();
+    return sqrt(row_reduce<OpSum16>(s));
+  }
+
+  FB_DEV void copy_x_to_xbar(const C& c) const {
+    const int N_ = N;
+    double* const R0 = rec;
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      st2(R, sZB, ld(R, sZ), ld(R, sL));
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const dbl2 vy = ld2(R, sV + 2 * sl);
+        st2(R, sVB + 2 * sl, vy[0], vy[1]);
+      });
+    }
+    c.sync();
+  }
+
+  // Infeasibility certificates for dx = (dz, dl, dv) (full_feasibility.cc:25-88).
+  FB_DEV int feasibility(const C& c, double tol) const {
+    const int r = c.tid, N_ = N;
+    const bool rx = r < NX;
+    const double* const R0 = rec;
+    lds_ptr Cl = lds;
+    double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
+    double s_fdz = 0.0, s_p2 = 0.0;
+    for (int i = 0; i <= N_; i++) {
+      const double* R = R0 + (long)i * kRec;
+      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+      ldv<pK, NS>(R, Kr);
+      ldv<pC, NC>(R, Cc);
+      ldv<pABr, NS>(R, ABr);
+      ldv<pABc, NX>(R, ABc);
+      const double dz = ld(R, sDZ), dl = ld(R, sDL);
+      const dbl2 fh = ld2(R, sF);
+      double dvs[KS], bs[KS];
+      sfor<0, KS>([&](auto S_) {
+        dvs[decltype(S_)::value] = ld(R, sDV + 2 * decltype(S_)::value);
+        bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value);
+      });
+      double dln = 0.0, dzn = 0.0;
+      if (i < N_) {
+        dln = ld(R + kRec, sDL);
+        dzn = ld(R + kRec, sDZ);
+      }
+      double dzb[NS], dlnb[NX];
+      bc_all<NS>(dz, dzb);
+      bc_all<NX>(dln, dlnb);
+      m_hdz = fmax(m_hdz, fabs(dot4<NS>(Kr, dzb)));
+      m_dz = fmax(m_dz, fabs(dz));
+      {
+        double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? dl : 0.0), 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
+                        [&](auto I, double t) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
+                        });
+        m_atv = fmax(m_atv, fabs((p[0] + p[1]) + (p[2] + p[3])));
+      }
+      s_fdz = fma(fh[0], dz, s_fdz);
+      // (G dz): block 0 = -dx(0); block i+1 = A dx + B du - dx(i+1); h'dl
+      m_u = fmax(m_u, fabs(dl));
+      s_p2 = fma(fh[1], dl, s_p2);
+      if (i == 0) m_gdz = fmax(m_gdz, rx ? fabs(dz) : 0.0);
+      if (i < N_) {
+        const double g = dot4<NS>(ABr, dzb) - dzn;
+        m_gdz = fmax(m_gdz, rx ? fabs(g) : 0.0);
+      }
+      C_to_lds(c, Cl, Cc, r);
+      rows_of_C_times(Cl, dzb, r, [&](auto S_, bool valid, double az) {
+        constexpr int s = decltype(S_)::value;
+        if (valid) m_adz = fmax(m_adz, az);
+        m_u = fmax(m_u, fabs(dvs[s]));
+        s_p2 = fma(bs[s], dvs[s], s_p2);
+      });
+    }
+    c.sync();
+    const double d1 = row_reduce<OpMax16>(m_adz), d2 = row_reduce<OpMax16>(m_gdz),
+                 d3 = row_reduce<OpMax16>(m_hdz), w = row_reduce<OpMax16>(m_dz),
+                 p1 = row_reduce<OpMax16>(m_atv), u = row_reduce<OpMax16>(m_u);
+    const double d4 = row_reduce<OpSum16>(s_fdz), p2 = row_reduce<OpSum16>(s_p2);
+    bool dual_feasible = true, primal_feasible = true;
+    if ((d1 <= w * tol) && (d2 <= tol * w) && (d3 <= tol * w) && (d4 < 0) && (w > 1e-14))
+      dual_feasible = false;
+    if ((p1 <= tol * u) && (p2 < 0)) primal_feasible = false;
+    if (primal_feasible && dual_feasible) return kFeasible;
+    if (primal_feasible && !dual_feasible) return kDualInfeasible;
+    if (!primal_feasible && dual_feasible) return kPrimalInfeasible;
+    return kBothInfeasible;
+  }
+
+  // ---- results ---------------------------------------------------------------------
+  // which: 0 = x, 1 = xbar, 2 = certificate dx with dx.y = y - ybar + b
+  // (impl:202-210, full_variable.cc:55-65)
+  template <int WHICH>
+  FB_DEV void write_out(const C& c) const {
+    const int r = c.tid, N_ = N;
+    const double* const R0 = rec;
+    double *uz = xarr(0), *ul = xarr(1), *uv = xarr(2), *uy = xarr(3);
+    for (int i = 0; i <= N_; i++) {
+      const double* R = R0 + (long)i * kRec;
+      const double zz = ld(R, WHICH == 0 ? sZ : (WHICH == 1 ? sZB : sDZ));
+      const double ll = ld(R, WHICH == 0 ? sL : (WHICH == 1 ? sLB : sDL));
+      if (r < NS) uz[(long)i * NS + r] = zz;
+      if (r < NX) ul[(long)i * NX + r] = ll;
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const int k = r + 16 * sl;
+        const dbl2 vy = ld2(R, sV + 2 * sl);
+        double vv = vy[0], yy = vy[1];
+        if (WHICH == 1) {
+          const dbl2 b = ld2(R, sVB + 2 * sl);
+          vv = b[0];
+          yy = b[1];
+        } else if (WHICH == 2) {
+          vv = ld(R, sDV + 2 * sl);
+          yy = (vy[1] - ld(R, sVB + 2 * sl + 1)) + ld(R, sB + sl);
+        }
+        if (k < NC) {
+          uv[(long)i * NC + k] = vv;
+          uy[(long)i * NC + k] = yy;
+        }
+      });
+    }
+  }
+  FB_DEV void write_x(const C& c) const { write_out<0>(c); }
+  FB_DEV void write_xbar(const C& c) const { write_out<1>(c); }
+  FB_DEV void write_certificate(const C& c) const { write_out<2>(c); }
+
+  // ---- diagnostics (tests): xbar in, one Newton step's vectors out ------------------
+  FB_DEV void probe_set_xbar(const C& c, const double* dbg) const {
+    const int r = c.tid, N_ = N;
+    double* const R0 = rec;
+    const int nz = (N_ + 1) * NS, nl = (N_ + 1) * NX;
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      st2(R, sZB, r < NS ? dbg[(long)i * NS + r] : 0.0, r < NX ? dbg[nz + (long)i * NX + r] : 0.0);
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const int k = r + 16 * sl;
+        st(R, sVB + 2 * sl, k < NC ? dbg[nz + nl + (long)i * NC + k] : 0.0);
+      });
+    }
+    c.sync();
+  }
+  FB_DEV void probe_dump(const C& c, double* o, bool ok) const {
+    const int r = c.tid, N_ = N;
+    const double* const R0 = rec;
+    const long nz = (N_ + 1) * NS, nl = (N_ + 1) * NX, nv = (N_ + 1) * NC;
+    for (int i = 0; i <= N_; i++) {
+      const double* R = R0 + (long)i * kRec;
+      if (r < NS) {
+        o[(long)i * NS + r] = ld(R, sDZ);
+        o[nz + nl + 2 * nv + (long)i * NS + r] = ld(R, sWZ);
+        o[2 * nz + 2 * nl + 2 * nv + (long)i * NS + r] = ld(R, sRZ);
+      }
+      if (r < NX) {
+        o[nz + (long)i * NX + r] = ld(R, sDL);
+        o[2 * nz + nl + 2 * nv + (long)i * NX + r] = ld(R, sWL);
+        o[3 * nz + 2 * nl + 2 * nv + (long)i * NX + r] = ld(R, sRL);
+      }
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const int k = r + 16 * sl;
+        if (k < NC) {
+          o[nz + nl + (long)i * NC + k] = ld(R, sDV + 2 * sl);
+          o[nz + nl + nv + (long)i * NC + k] = ld(R, sDV + 2 * sl + 1);
+        }
+      });
+    }
+    if (r == 0) o[3 * nz + 3 * nl + 2 * nv] = ok ? 1.0 : 0.0;
+  }
+
+  // ---- the Newton step ----------------------------------------------------------------
+  // Forward sweep: applies the pending step, factors, forward substitution.
+  // Backward sweep: back substitution fused with dv, A dz, the residual
+  // increment W = (H dz + G'dl + A'dv, -G dz) and the squared norms of the inner
+  // and penalised natural residuals at x + dx (the first line-search trial,
+  // fbstab_algorithm-impl.h:283-290).  Returns false on a non-positive pivot
+  // (riccati_linear_solver.cc:131-136).
+  struct FwdIn {
+    dbl2 zr, bb, dw, lr, dwl;
+    dbl2 vy[KS], da[KS];
+    double vb[KS];
+    double Cc[NC], K[NS];
+  };
+  static FB_DEV void load_fwd(const double* R, FwdIn& in) {
+    in.zr = ld2(R, sZ);
+    in.bb = ld2(R, sZB);
+    in.dw = ld2(R, sDZ);
+    in.lr = ld2(R, sL);
+    in.dwl = ld2(R, sDL);
+    sfor<0, KS>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      in.vy[s] = ld2(R, sV + 2 * s);
+      in.da[s] = ld2(R, sDV + 2 * s);
+      in.vb[s] = ld(R, sVB + 2 * s);
+    });
+    ldv<pC, NC>(R, in.Cc);
+    ldv<pK, NS>(R, in.K);
+  }
+
+  FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
+                          double* trial_outer2) {
+    // Locals only below: lambdas must not capture `this`.
+    const int N_ = N;
+    const int r = c.tid;
+    double* const R0 = rec;
+    lds_ptr Tr = lds;
+    lds_ptr Cl = lds;
+    const bool rx = r < NX;
+    const double tp = pend_t;  // pending step length
+    pend_t = 0.0;
+
+    double Pinv[NX];  // row r of inv(Pi_i); Pi_0 = sigma I (riccati_linear_solver.cc:127)
+    sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = (rx && r == decltype(Cc)::value) ? 1.0 / sigma : 0.0; });
+    double thp = 0.0;
+    bool ok = true;
+
+    FB_STAMP_DECL;
+    // kPrefetch: the loads of stage i+1 are issued during stage i's second
+    // Cholesky chain (hand software pipelining, for one wave per SIMD); without
+    // it each stage loads at its top and a second resident wave covers the wait.
+    FwdIn cur;
+    if (kPrefetch) load_fwd(R0, cur);
+    // ===================== forward sweep ===================================
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      if (!kPrefetch) load_fwd(R, cur);
+      // Lane id made opaque per iteration: (ro == j) selects are then recomputed
+      // where used instead of being hoisted out of the loop as 16+ live masks.
+      int ro = r;
+      asm volatile("" : "+v"(ro));
+      double Cc_[NC];
+      sfor<0, NC>([&](auto Kk) { Cc_[decltype(Kk)::value] = cur.Cc[decltype(Kk)::value]; });
+      double K[NS];
+      sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = cur.K[decltype(Cc)::value]; });
+      // ---- pending step (tp = 0: no-op), PFB gradient (riccati_linear_solver.cc:91-99)
+      double Gam[KS], Rvm[KS];
+      sfor<0, KS>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        const int k = r + 16 * s;
+        const double vk = fma(tp, cur.da[s][0], cur.vy[s][0]);
+        const double yk = fma(-tp, cur.da[s][1], cur.vy[s][1]);
+        const double ys = yk + sigma * (vk - cur.vb[s]);
+        double ph, g0, g1;
+        pfb_all(ys, vk, alpha, &ph, &g0, &g1);
+        const double imu = rcp_fast(g1 + sigma * g0);
+        Gam[s] = k < NC ? g0 * imu : 0.0;
+        Rvm[s] = k < NC ? -ph * imu : 0.0;
+        st2(R, sV + 2 * s, vk, yk);
+        st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
+      });
+      // pending step on (z, rz), (l, rl); eliminated right-hand side (:222-225)
+      const double zz = fma(tp, cur.dw[0], cur.zr[0]);
+      const double rzz = fma(tp, cur.dw[1], cur.zr[1]);
+      const double ll = fma(tp, cur.dwl[0], cur.lr[0]);
+      const double rll = fma(tp, cur.dwl[1], cur.lr[1]);
+      st2(R, sZ, zz, rzz);
+      st2(R, sL, ll, rll);
+      double r1 = -(rzz + sigma * (zz - cur.bb[0]));  // zero where there is no row
+      const double r2 = rll + sigma * (ll - cur.bb[1]);
+      FB_SB();
+      FB_STAMP_LAP(0);
+      // K row: H + sigma I (at pivot time) + inv(Pi) block + C' Gamma C (:101-123, :142-145)
+      sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] += Pinv[decltype(Cc)::value]; });
+      {
+        double p[4] = {r1, 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(Rvm[decltype(I)::value >> 4]); },
+                        [&](auto I, double rk) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(-Cc_[k], rk, p[k & 3]);
+                        });
+        r1 = (p[0] + p[1]) + (p[2] + p[3]);
+      }
+      sfor<0, NC>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        const double gc = bc<(k & 15)>(Gam[k >> 4]) * Cc_[k];  // Gamma_k C[k][r]
+        bc_pipeline<NS>([&](auto I) { return bc<decltype(I)::value>(Cc_[k]); },
+                        [&](auto I, double t) { K[decltype(I)::value] = fma(gc, t, K[decltype(I)::value]); });
+      });
+      FB_SB();
+      FB_STAMP_LAP(1);
+      // theta(i), h(i) = inv(Pi) theta - rx, g = [-h; ru] (:231-236, :252-261)
+      const double th = thp + r2;
+      double gv = r1;
+      {
+        const double hsum = bc_dot<0, NX>(Pinv, th);
+        if (rx) gv = r1 - hsum;
+      }
+      stv<fPinv, NX>(R, Pinv);
+      FB_SB();
+      FB_STAMP_LAP(2);
+      // [A B] row r for W, requested now so that it arrives behind the chains
+      double AB[NS];
+      ldv<pABr, NS>(R, AB);
+      // ---- Lc = chol(K), columns of inv(Lc)
+      ok = chol_rows<NS>(K, ro, sigma) && ok;
+      if (!ok) return false;
+      double XC[NS];
+      FB_STAMP_LAP(3);
+      FB_SB();
+      tri_inv_cols<NS>(K, XC, ro);
+      FB_STAMP_LAP(4);
+      FB_SB();
+      stv<fXc, NS>(R, XC);
+      // rows of inv(Lc) through an LDS transpose
+      double XR[NS];
+      c.sync();
+      sfor<0, NS>([&](auto RR) { Tr[decltype(RR)::value * TS + r] = XC[decltype(RR)::value]; });
+      c.sync();
+      sfor<0, NS>([&](auto Cc) { XR[decltype(Cc)::value] = Tr[r * TS + decltype(Cc)::value]; });
+      FB_SB();
+      stv<fXr, NS>(R, XR);
+      // t = inv(Lc) g
+      const double tvec = bc_dot<0, NS>(XR, gv);
+      st2(R, fT, tvec, th);
+      FB_STAMP_LAP(5);
+      if (i < N_) {
+        FB_SB();
+        // ---- W = [A B] inv(Lc)'  (AM and -P of :149-175)
+        double W[NS];
+        sfor<0, NS>([&](auto Cc) { W[decltype(Cc)::value] = 0.0; });
+        sfor<0, NS>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          // X[cc][k] = lane cc's XR[k], nonzero for cc >= k
+          bc_pipeline<NS - k>([&](auto I) { return bc<k + decltype(I)::value>(XR[k]); },
+                              [&](auto I, double t) { W[k + decltype(I)::value] = fma(AB[k], t, W[k + decltype(I)::value]); });
+        });
+        // next stage's inputs: in flight during the second chain below
+        if (kPrefetch) load_fwd(R + kRec, cur);
+        FB_SB();
+        FB_STAMP_LAP(6);
+        // theta(i+1) partial = -W t
+        thp = -bc_dot<0, NS>(W, tvec);
+        // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L)
+        double Pn[NX];
+        sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = 0.0; });
+        sfor<0, NS>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          bc_pipeline<NX>([&](auto I) { return bc<decltype(I)::value>(W[k]); },
+                          [&](auto I, double t) { Pn[decltype(I)::value] = fma(W[k], t, Pn[decltype(I)::value]); });
+        });
+        sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = rx ? Pn[decltype(Cc)::value] : 0.0; });
+        FB_SB();
+        FB_STAMP_LAP(7);
+        ok = chol_rows<NX>(Pn, ro, sigma) && ok;
+        if (!ok) return false;
+        FB_SB();
+        double T[NX];
+        tri_inv_cols<NX>(Pn, T, ro);
+        FB_SB();
+        // inv(Pi)[r][cc] = sum_k T[k][r] T[k][cc], T[k][cc] = lane cc's T[k] (zero for k < cc)
+        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
+        sfor<0, NX>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          bc_pipeline<k + 1>([&](auto I) { return bc<decltype(I)::value>(T[k]); },
+                             [&](auto I, double t) { Pinv[decltype(I)::value] = fma(T[k], t, Pinv[decltype(I)::value]); });
+        });
+        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = rx ? Pinv[decltype(Cc)::value] : 0.0; });
+        FB_STAMP_LAP(8);
+      }
+    }
+
+    // ============ backward sweep (:267-341), fused with dv, A dz, W and the
+    // residual norms of the first line-search trial ==========================
+    double lp = 0.0;    // dl(i+1), lanes < NX
+    double dzn = 0.0;   // dx(i+1), lanes < NX
+    double s_in = 0.0, s_out = 0.0;
+    for (int i = N_; i >= 0; i--) {
+      double* R = R0 + (long)i * kRec;
+      // With kPrefetch every load of the stage is issued up front (one wave per
+      // SIMD: nothing else covers the latency); otherwise each group is loaded
+      // one step ahead of its use, which keeps ~3 groups live instead of 7.
+      double XC[NS], XR[NS], Cc_[NC], Hr[NS], AB[NS], Ac[NX];
+      dbl2 tth, zr, bb;
+      dbl2 vy[KS], gr[KS];
+      double vb[KS];
+      dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1
+      double lbn = 0.0;
+      auto load_g0 = [&]() { ldv<fXr, NS>(R, XR); ldv<pABc, NX>(R, Ac); tth = ld2(R, fT); };
+      auto load_g1 = [&]() { ldv<fXc, NS>(R, XC); };
+      auto load_g2 = [&]() { ldv<fPinv, NX>(R, Pinv); };
+      auto load_g3 = [&]() {
+        ldv<pC, NC>(R, Cc_);
+        sfor<0, KS>([&](auto S_) {
+          constexpr int sl = decltype(S_)::value;
+          vy[sl] = ld2(R, sV + 2 * sl);
+          gr[sl] = ld2(R, sGAM + 2 * sl);
+          vb[sl] = ld(R, sVB + 2 * sl);
+        });
+      };
+      auto load_g4 = [&]() {
+        ldv<pK, NS>(R, Hr);
+        zr = ld2(R, sZ);
+        bb = ld2(R, sZB);
+      };
+      auto load_g5 = [&]() {
+        ldv<pABr, NS>(R, AB);
+        if (i < N_) {
+          lrn = ld2(R + kRec, sL);
+          lbn = ld(R + kRec, sLB);
+        }
+      };
+      load_g0();
+      load_g1();
+      if (kPrefetch) { load_g2(); load_g3(); load_g4(); load_g5(); }
+      FB_SB();
+      // u = [A B]' dl(i+1) (zero at the terminal stage: lp = 0)
+      double lpb[NX];
+      bc_all<NX>(lp, lpb);
+      const double u = dot4<NX>(Ac, lpb);
+      // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
+      const double s = tth[0] - bc_dot<0, NS>(XR, u);
+      if (!kPrefetch) { load_g2(); FB_SB(); }
+      const double dzu = bc_dot<0, NS>(XC, s);
+      if (!kPrefetch) { load_g3(); FB_SB(); }
+      // dl = -inv(Pi)(theta + dx)
+      const double tx = tth[1] + dzu;
+      double dli = -bc_dot<0, NX>(Pinv, tx);
+      if (!rx) dli = 0.0;
+      double dzb[NS];  // [dx; du](i), every lane
+      bc_all<NS>(dzu, dzb);
+      if (!kPrefetch) { load_g4(); FB_SB(); }
+      FB_STAMP_LAP(9);
+      // ---- A dz and dv (:329-341) through the LDS copy of C
+      C_to_lds(c, Cl, Cc_, r);
+      double dvs[KS];
+      rows_of_C_times(Cl, dzb, r, [&](auto S_, bool valid, double a) {
+        constexpr int sl = decltype(S_)::value;
+        double d = 0.0;
+        if (valid) {
+          d = gr[sl][1] + gr[sl][0] * a;
+          // first line-search trial, v block (full_residual.cc:68-71, :99-106)
+          const double vi = vy[sl][0] + d;
+          const double yi = vy[sl][1] - a;
+          const double ys = yi + sigma * (vi - vb[sl]);
+          const double ph = pfb(ys, vi, alpha);
+          const double pn = pnr(yi, vi, alpha);
+          s_in = fma(ph, ph, s_in);
+          s_out = fma(pn, pn, s_out);
+        }
+        st2(R, sDV + 2 * sl, d, valid ? a : 0.0);
+        dvs[sl] = d;
+      });
+      if (!kPrefetch) { load_g5(); FB_SB(); }
+      // ---- wz = H dz + G'dl + A'dv
+      double w;
+      {
+        double p[4] = {dot4<NS>(Hr, dzb) + (u - dli), 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
+                        [&](auto I, double t) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(Cc_[k], t, p[k & 3]);
+                        });
+        w = (p[0] + p[1]) + (p[2] + p[3]);
+      }
+      if (i < N_) {
+        // l block i+1: wl = -(A dx + B du - dx(i+1)); trial norms (full_residual.cc:60-66)
+        const double abz = dot4<NS>(AB, dzb);
+        const double wlv = rx ? -(abz - dzn) : 0.0;
+        st(R + kRec, sWL, wlv);
+        const double lr = lrn[1] + wlv;
+        const double li = lrn[0] + lp;
+        const double ri = lr + sigma * (li - lbn);
+        s_in = fma(ri, ri, s_in);
+        s_out = fma(lr, lr, s_out);
+      }
+      {
+        st2(R, sDZ, dzu, w);
+        const double zrr = zr[1] + w;
+        const double zi = zr[0] + dzu;
+        const double ri = zrr + sigma * (zi - bb[0]);
+        s_in = fma(ri, ri, s_in);
+        s_out = fma(zrr, zrr, s_out);
+      }
+      st(R, sDL, dli);
+      if (i == 0) {
+        // l block 0: -(G dz)_0 = dx(0)
+        const dbl2 lr0 = ld2(R, sL);
+        const double wl0 = rx ? dzu : 0.0;
+        st(R, sWL, wl0);
+        const double lr = lr0[1] + wl0;
+        const double li = lr0[0] + dli;
+        const double ri = lr + sigma * (li - bb[1]);
+        s_in = fma(ri, ri, s_in);
+        s_out = fma(lr, lr, s_out);
+      }
+      lp = dli;
+      dzn = rx ? dzu : 0.0;
+      FB_STAMP_LAP(10);
+    }
+    *trial_inner2 = row_reduce<OpSum16>(s_in);
+    *trial_outer2 = row_reduce<OpSum16>(s_out);
+    return true;
+  }
+};
+
+#endif  // !FB_HOSTSIM
+
+}  // namespace fbk

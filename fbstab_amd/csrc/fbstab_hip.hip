@@ -19,6 +19,7 @@
 #include "fb_dense.h"
 #include "fb_mpc.h"
 #include "fb_mpc_g16.h"
+#include "fb_mpc_r16.h"
 
 #if defined(FB_STAMP)
 namespace fbk { __device__ unsigned long long g_stamps[32]; }
@@ -66,6 +67,15 @@ __device__ __forceinline__ int next_qp(int* counter, lds_ptr slot) {
 template <class P, class C>
 __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_options_t& opts, double* dbg) {
   p.load_guess(ctx);
+  if constexpr (P::kOwnVectorOps) {
+    p.probe_set_xbar(ctx, dbg);
+    p.residual(ctx);
+    double a, b;
+    const bool ok = p.newton_step(ctx, opts.sigma0, opts.alpha, &a, &b);
+    ctx.sync();
+    p.probe_dump(ctx, dbg, ok);
+    return;
+  } else {
   const int nz = p.nz, nl = p.nl, nv = p.nv;
   for (int i = ctx.tid; i < nz; i += C::nt) p.zb[i] = dbg[i];
   for (int i = ctx.tid; i < nl; i += C::nt) p.lb[i] = dbg[nz + i];
@@ -98,6 +108,7 @@ __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_op
   for (int i = ctx.tid; i < nl; i += C::nt) o[i] = p.rl[i];
   o += nl;
   if (ctx.tid == 0) o[0] = ok ? 1.0 : 0.0;
+  }
 }
 
 __device__ __forceinline__ MpcData mpc_data_of(const MpcBatchArgs& data, long q) {
@@ -194,6 +205,48 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
       if (q < 0) break;
       solver.solve(out + q);
     }
+#endif
+  }
+}
+
+#ifndef FB_R16_MIN_WAVES
+#define FB_R16_MIN_WAVES 2
+#endif
+// Record-based 16-lane kernel (fb_mpc_r16.h): four QPs per wavefront, rows pull
+// QP indices from the shared counter.  scratch: rows * ws_doubles(N).
+template <int NX, int NU, int NC, bool DBG>
+__global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
+    MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
+    int* counter, int batch, int N, double* dbg) {
+  typedef MpcR16<NX, NU, NC> P;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x, row = lane >> 4;
+  Ctx16 ctx;
+  ctx.tid = lane & 15;
+  P p;
+  double* const ws = scratch + ((long)blockIdx.x * 4 + row) * P::ws_doubles(N);
+  lds_ptr const lds = (lds_ptr)smem + row * P::kLdsPerRow;
+  // Binds the policy to the next QP of the shared queue; -1 when it is empty.
+  auto next = [&](P& pp) -> int {
+    int q = 0;
+    if (ctx.tid == 0) q = atomicAdd(counter, 1);
+    q = bci<0>(q);
+    if (q >= batch) return -1;
+    pp.bind(ws, lds, &data, &x, q, N, ctx.tid);
+    return q;
+  };
+  if constexpr (DBG) {
+    if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
+  } else {
+    Solver<P, Ctx16> solver(p, ctx, opts);
+#ifdef FB_R16_NESTED
+    for (;;) {
+      const int q = next(p);
+      if (q < 0) break;
+      solver.solve(out + q);
+    }
+#else
+    solver.solve_stream(next, out);
 #endif
   }
 }
@@ -364,6 +417,7 @@ int check_common(const void* handle, int batch, const void* data, const fbstab_v
 struct fbstab_mpc_solver : SolverBase {
   fbk::MpcLayout lay;
   bool g16 = false;       // 16-lane register kernel (four QPs per wavefront)
+  bool r16 = false;       // record-based 16-lane kernel (fb_mpc_r16.h), the default for its shapes
   int lds_per_row = 0;
   int qps_per_wg = 1;
 };
@@ -374,13 +428,25 @@ bool g16_shape(int nx, int nu, int nc) { return nx == 12 && nu == 4 && nc == 20;
 
 template <class... A>
 void launch_mpc(fbstab_mpc_solver* h, int grid, hipStream_t s, A... args) {
-  if (h->g16) {
+  if (h->r16) {
+    // unreachable: the record kernel takes a different argument list (launch_r16)
+  } else if (h->g16) {
     hipLaunchKernelGGL((fbstab_mpc_g16_kernel<12, 4, 20, false>), dim3(grid), dim3(64), h->lds_bytes, s,
                        args..., h->lds_per_row, (double*)nullptr);
   } else {
     hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, false>), dim3(grid), dim3(h->threads), h->lds_bytes, s,
                        args..., (double*)nullptr);
   }
+}
+template <bool DBG>
+void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArgs& a, const VarBatchArgs& v,
+                fbstab_solver_out_t* out, int batch, double* dbg) {
+  MpcBatchPtrs d;
+  VarBatchPtrs x;
+  for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { d.base[i] = a.base[i]; d.stride[i] = a.stride[i]; }
+  for (int i = 0; i < 4; i++) { x.base[i] = v.base[i]; x.stride[i] = v.stride[i]; }
+  hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG>), dim3(grid), dim3(64), h->lds_bytes, s, d, x, out,
+                     h->opts, h->scratch, h->counter, batch, h->lay.N, dbg);
 }
 }  // namespace
 struct fbstab_dense_solver : SolverBase {
@@ -413,6 +479,16 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
   const char* force_generic = getenv("FBSTAB_HIP_GENERIC");
   s->g16 = g16_shape(nx, nu, nc) && !(force_generic && atoi(force_generic) > 0);
+  // FBSTAB_HIP_MPC_KERNEL=g16 selects the previous register kernel (comparisons)
+  const char* which = getenv("FBSTAB_HIP_MPC_KERNEL");
+  s->r16 = s->g16 && !(which && strcmp(which, "g16") == 0);
+  typedef fbk::MpcR16<12, 4, 20> R16;
+  if (s->r16) {
+    s->g16 = false;
+    s->lds_per_row = R16::kLdsPerRow;
+    s->qps_per_wg = 4;
+    s->lds_bytes = 4 * R16::kLdsPerRow * (int)sizeof(double);
+  }
   if (s->g16) {
     int d = s->lay.w_sb;  // tile + stage slices of the generic passes
     if (d < fbk::MpcProblemG16<12, 4, 20>::kLdsDoubles) d = fbk::MpcProblemG16<12, 4, 20>::kLdsDoubles;
@@ -427,10 +503,12 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  const void* kern = s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, false>)
-                           : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>);
-  const void* kern_dbg = s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, true>)
-                               : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>);
+  const void* kern = s->r16   ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false>)
+                     : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, false>)
+                              : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>);
+  const void* kern_dbg = s->r16   ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true>)
+                         : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, true>)
+                                  : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>);
   hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   if (e == hipSuccess) e = hipFuncSetAttribute(kern_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0, cus = 0;
@@ -452,7 +530,8 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
     const int need = (max_batch + s->qps_per_wg - 1) / s->qps_per_wg;
     if (s->workgroups > need) s->workgroups = need;
   }
-  s->scratch_bytes = (long long)s->lay.ws_doubles * sizeof(double) * s->workgroups * s->qps_per_wg;
+  const long long ws_doubles = s->r16 ? (long long)R16::ws_doubles(N) : (long long)s->lay.ws_doubles;
+  s->scratch_bytes = ws_doubles * sizeof(double) * s->workgroups * s->qps_per_wg;
   e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
   if (e != hipSuccess) {
     s->release(); delete s;
@@ -534,7 +613,11 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mp
   int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  launch_mpc(h, grid, s, h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
+  if (h->r16) {
+    launch_r16<false>(h, grid, s, a, v, d_out, batch, nullptr);
+  } else {
+    launch_mpc(h, grid, s, h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
@@ -587,7 +670,9 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
   HIP_TRY(hipMalloc(&d_io, n_io * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(d_io, io, sizeof(double) * (L.nz + L.nl + L.nv), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
-  if (h->g16) {
+  if (h->r16) {
+    launch_r16<true>(h, 1, s, a, v, h->d_out, 1, d_io);
+  } else if (h->g16) {
     hipLaunchKernelGGL((fbstab_mpc_g16_kernel<12, 4, 20, true>), dim3(1), dim3(64), h->lds_bytes, s, h->lay, a, v,
                        h->d_out, h->opts, h->scratch, h->counter, 1, h->lds_per_row, d_io);
   } else {
