@@ -73,17 +73,28 @@ struct MpcR16 {
   static constexpr int sGAM = sDV + 2 * KS;  // pairs (GAM_s, RVM_s)
   static constexpr int sF = sGAM + 2 * KS, sH = sF + 1;
   static constexpr int sB = sH + 1;          // KS slots
-  static constexpr int pK = (sB + KS + 1) & ~1;        // row r of [Q S'; S R], 16 slots
-  static constexpr int pC = pK + 16;                   // column r of C = [E L], NC slots
-  static constexpr int pABr = pC + ((NC + 1) & ~1);    // row r of [A B], 16 slots
-  static constexpr int pABc = pABr + 16;               // column r of [A B], NX slots
-  static constexpr int fXc = (pABc + NX + 1) & ~1;     // inv(Lc): lane r = column r
-  static constexpr int fXr = fXc + 16;                 // inv(Lc): lane r = row r
-  static constexpr int fPinv = fXr + 16;               // inv(Pi), NX slots
+  // factor record.  inv(Lc) is lower triangular: slot j of fX holds, in lane r,
+  // X[max(j,r)][min(j,r)] - column r of inv(Lc) for j >= r, row r for j <= r.
+  static constexpr int fX = (sB + KS + 1) & ~1;
+  static constexpr int fPinv = fX + 16;                // inv(Pi), NX slots
   static constexpr int fT = (fPinv + NX + 1) & ~1, fTh = fT + 1;
   static constexpr int kSlots = fT + 2;
   static constexpr int kRec = 16 * kSlots;  // doubles per stage
-  static constexpr long ws_doubles(int N) { return (long)kRec * (N + 1); }
+  // Matrix copy ("pack"), a region of its own: stage i's copy sits at
+  // pack + i * kPack.  A stage whose matrices are bitwise identical to the
+  // previous stage's reads that stage's copy instead (poff[i], the offset of
+  // the copy stage i uses): for a time-invariant plant - the common case in
+  // MPC, e.g. OcpGenerator::CopyOverHorizon - the sweeps then stream two or
+  // three cache-resident 8 KB copies per QP rather than N + 1 from HBM.
+  // Time-varying data simply gets poff[i] = i * kPack.
+  static constexpr int pK = 0;                         // row r of [Q S'; S R], 16 slots
+  static constexpr int pC = pK + 16;                   // column r of C = [E L], NC slots
+  static constexpr int pABr = pC + ((NC + 1) & ~1);    // row r of [A B], 16 slots
+  static constexpr int pABc = pABr + 16;               // column r of [A B], NX slots
+  static constexpr int kPackSlots = (pABc + NX + 1) & ~1;
+  static constexpr int kPack = 16 * kPackSlots;
+  static constexpr long hdr_doubles(int N) { return ((N + 1) / 2 + 16) & ~15L; }  // poff[N+1] ints
+  static constexpr long ws_doubles(int N) { return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1); }
 
   static constexpr int off(int slot) { return (slot >> 1) * 32 + (slot & 1); }
 
@@ -94,7 +105,9 @@ struct MpcR16 {
   static constexpr int kLdsPerRow = ((kLdsDoubles + 31) & ~31) + 16;
 
   // ---- state -------------------------------------------------------------------
-  double* rec;  // this row's records, lane offset included
+  double* rec;   // this row's records, lane offset included
+  double* pack;  // this row's matrix copies, lane offset included
+  int* poff;     // per stage: offset (doubles) of the copy it reads
   lds_ptr lds;
   const MpcBatchPtrs* data;  // kernel arguments (uniform)
   const VarBatchPtrs* var;
@@ -106,7 +119,9 @@ struct MpcR16 {
 
   FB_DEV void bind(double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d, const VarBatchPtrs* x,
                    long q_, int N_, int lane16) {
-    rec = ws_row + 2 * lane16;
+    poff = reinterpret_cast<int*>(ws_row);
+    pack = ws_row + hdr_doubles(N_) + 2 * lane16;
+    rec = pack + (long)kPack * (N_ + 1);
     lds = lds_row;
     data = d;
     var = x;
@@ -200,8 +215,12 @@ struct MpcR16 {
                  *L = arr(FBSTAB_MPC_L), *pd = arr(FBSTAB_MPC_d), *px0 = arr(FBSTAB_MPC_x0);
     const double *uz = xarr(0), *ul = xarr(1), *uv = xarr(2);
     pend_t = 0.0;
+    double* const P0 = pack;
+    int* const po = poff;
+    int canon = 0;  // offset of the copy the previous stage uses (row-uniform)
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
+      double* PK = P0 + (long)i * kPack;
       const bool has_ab = i < N_;
       // matrices
       double Kr[16], ABr[16], Cc[NC], ABc[NX];
@@ -229,10 +248,31 @@ struct MpcR16 {
                                : B + (long)i * NX * NU + (long)(rs_ ? ru : 0) * NX;
         sfor<0, NX>([&](auto J) { ABc[decltype(J)::value] = (rs_ && has_ab) ? src[decltype(J)::value] : 0.0; });
       }
-      stv<pK, 16>(R, Kr);
-      stv<pABr, 16>(R, ABr);
-      stv<pC, NC>(R, Cc);
-      stv<pABc, NX>(R, ABc);
+      stv<pK, 16>(PK, Kr);
+      stv<pABr, 16>(PK, ABr);
+      stv<pC, NC>(PK, Cc);
+      stv<pABc, NX>(PK, ABc);
+      if (i > 0) {
+        // bitwise comparison with the copy the previous stage uses
+        const double* PC = P0 + canon;
+        double K0[16], AB0[16], C0[NC], Ac0[NX];
+        ldv<pK, 16>(PC, K0);
+        ldv<pABr, 16>(PC, AB0);
+        ldv<pC, NC>(PC, C0);
+        ldv<pABc, NX>(PC, Ac0);
+        bool differs = false;
+        sfor<0, 16>([&](auto Cc_) {
+          constexpr int cc = decltype(Cc_)::value;
+          differs = differs || !(Kr[cc] == K0[cc]) || !(ABr[cc] == AB0[cc]);
+        });
+        sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == C0[decltype(Kk)::value]); });
+        sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == Ac0[decltype(J)::value]); });
+#if defined(FB_R16_NO_SHARED_PACK)
+        differs = true;
+#endif
+        if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) canon = i * kPack;
+      }
+      po[i] = canon;  // every lane: each later reads its own store
       // constants f, h, b (mpc_data.cc:240-289)
       const double f = rx ? pq[(long)i * NX + r] : (rs_ ? pr[(long)i * NU + ru] : 0.0);
       const double h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * NX + r]) : 0.0;
@@ -266,13 +306,16 @@ struct MpcR16 {
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
     double* const R0 = rec;
+    const double* const P0 = pack;
+    const int* const po = poff;
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
+      const double* PK = P0 + po[i];
       double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-      ldv<pK, NS>(R, Kr);
-      ldv<pC, NC>(R, Cc);
-      ldv<pABr, NS>(R, ABr);
-      ldv<pABc, NX>(R, ABc);
+      ldv<pK, NS>(PK, Kr);
+      ldv<pC, NC>(PK, Cc);
+      ldv<pABr, NS>(PK, ABr);
+      ldv<pABc, NX>(PK, ABc);
       const double zz = ld(R, sZ), ll = ld(R, sL);
       const dbl2 fh = ld2(R, sF);
       double vs[KS];
@@ -454,16 +497,19 @@ struct MpcR16 {
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
     const double* const R0 = rec;
+    const double* const P0 = pack;
+    const int* const po = poff;
     lds_ptr Cl = lds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
     double s_fdz = 0.0, s_p2 = 0.0;
     for (int i = 0; i <= N_; i++) {
       const double* R = R0 + (long)i * kRec;
+      const double* PK = P0 + po[i];
       double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-      ldv<pK, NS>(R, Kr);
-      ldv<pC, NC>(R, Cc);
-      ldv<pABr, NS>(R, ABr);
-      ldv<pABc, NX>(R, ABc);
+      ldv<pK, NS>(PK, Kr);
+      ldv<pC, NC>(PK, Cc);
+      ldv<pABr, NS>(PK, ABr);
+      ldv<pABc, NX>(PK, ABc);
       const double dz = ld(R, sDZ), dl = ld(R, sDL);
       const dbl2 fh = ld2(R, sF);
       double dvs[KS], bs[KS];
@@ -617,7 +663,7 @@ struct MpcR16 {
     double vb[KS];
     double Cc[NC], K[NS];
   };
-  static FB_DEV void load_fwd(const double* R, FwdIn& in) {
+  static FB_DEV void load_fwd(const double* R, const double* PK, FwdIn& in) {
     in.zr = ld2(R, sZ);
     in.bb = ld2(R, sZB);
     in.dw = ld2(R, sDZ);
@@ -629,8 +675,8 @@ struct MpcR16 {
       in.da[s] = ld2(R, sDV + 2 * s);
       in.vb[s] = ld(R, sVB + 2 * s);
     });
-    ldv<pC, NC>(R, in.Cc);
-    ldv<pK, NS>(R, in.K);
+    ldv<pC, NC>(PK, in.Cc);
+    ldv<pK, NS>(PK, in.K);
   }
 
   FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
@@ -639,6 +685,8 @@ struct MpcR16 {
     const int N_ = N;
     const int r = c.tid;
     double* const R0 = rec;
+    const double* const P0 = pack;
+    const int* const po = poff;
     lds_ptr Tr = lds;
     lds_ptr Cl = lds;
     const bool rx = r < NX;
@@ -655,11 +703,15 @@ struct MpcR16 {
     // Cholesky chain (hand software pipelining, for one wave per SIMD); without
     // it each stage loads at its top and a second resident wave covers the wait.
     FwdIn cur;
-    if (kPrefetch) load_fwd(R0, cur);
+    // offsets of the matrix copies of stages i, i+1 (and i+2 in flight)
+    int pcur = po[0], pnxt = po[N_ > 0 ? 1 : 0];
+    if (kPrefetch) load_fwd(R0, P0 + pcur, cur);
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      if (!kPrefetch) load_fwd(R, cur);
+      const double* PK = P0 + pcur;
+      const int pnn = po[i + 2 <= N_ ? i + 2 : N_];
+      if (!kPrefetch) load_fwd(R, PK, cur);
       // Lane id made opaque per iteration: (ro == j) selects are then recomputed
       // where used instead of being hoisted out of the loop as 16+ live masks.
       int ro = r;
@@ -726,7 +778,7 @@ struct MpcR16 {
       FB_STAMP_LAP(2);
       // [A B] row r for W, requested now so that it arrives behind the chains
       double AB[NS];
-      ldv<pABr, NS>(R, AB);
+      ldv<pABr, NS>(PK, AB);
       // ---- Lc = chol(K), columns of inv(Lc)
       ok = chol_rows<NS>(K, ro, sigma) && ok;
       if (!ok) return false;
@@ -736,7 +788,6 @@ struct MpcR16 {
       tri_inv_cols<NS>(K, XC, ro);
       FB_STAMP_LAP(4);
       FB_SB();
-      stv<fXc, NS>(R, XC);
       // rows of inv(Lc) through an LDS transpose
       double XR[NS];
       c.sync();
@@ -744,7 +795,11 @@ struct MpcR16 {
       c.sync();
       sfor<0, NS>([&](auto Cc) { XR[decltype(Cc)::value] = Tr[r * TS + decltype(Cc)::value]; });
       FB_SB();
-      stv<fXr, NS>(R, XR);
+      {
+        double Xm[NS];  // column r below the diagonal, row r above it
+        sfor<0, NS>([&](auto J) { Xm[decltype(J)::value] = decltype(J)::value >= ro ? XC[decltype(J)::value] : XR[decltype(J)::value]; });
+        stv<fX, NS>(R, Xm);
+      }
       // t = inv(Lc) g
       const double tvec = bc_dot<0, NS>(XR, gv);
       st2(R, fT, tvec, th);
@@ -761,7 +816,7 @@ struct MpcR16 {
                               [&](auto I, double t) { W[k + decltype(I)::value] = fma(AB[k], t, W[k + decltype(I)::value]); });
         });
         // next stage's inputs: in flight during the second chain below
-        if (kPrefetch) load_fwd(R + kRec, cur);
+        if (kPrefetch) load_fwd(R + kRec, P0 + pnxt, cur);
         FB_SB();
         FB_STAMP_LAP(6);
         // theta(i+1) partial = -W t
@@ -793,6 +848,8 @@ struct MpcR16 {
         sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = rx ? Pinv[decltype(Cc)::value] : 0.0; });
         FB_STAMP_LAP(8);
       }
+      pcur = pnxt;
+      pnxt = pnn;
     }
 
     // ============ backward sweep (:267-341), fused with dv, A dz, W and the
@@ -800,8 +857,13 @@ struct MpcR16 {
     double lp = 0.0;    // dl(i+1), lanes < NX
     double dzn = 0.0;   // dx(i+1), lanes < NX
     double s_in = 0.0, s_out = 0.0;
+    pcur = po[N_];
     for (int i = N_; i >= 0; i--) {
       double* R = R0 + (long)i * kRec;
+      const double* PK = P0 + pcur;
+      pcur = po[i > 0 ? i - 1 : 0];
+      int ro = r;
+      asm volatile("" : "+v"(ro));
       // With kPrefetch every load of the stage is issued up front (one wave per
       // SIMD: nothing else covers the latency); otherwise each group is loaded
       // one step ahead of its use, which keeps ~3 groups live instead of 7.
@@ -811,11 +873,11 @@ struct MpcR16 {
       double vb[KS];
       dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1
       double lbn = 0.0;
-      auto load_g0 = [&]() { ldv<fXr, NS>(R, XR); ldv<pABc, NX>(R, Ac); tth = ld2(R, fT); };
-      auto load_g1 = [&]() { ldv<fXc, NS>(R, XC); };
+      auto load_g0 = [&]() { ldv<fX, NS>(R, XC); ldv<pABc, NX>(PK, Ac); tth = ld2(R, fT); };
+      auto load_g1 = [&]() {};
       auto load_g2 = [&]() { ldv<fPinv, NX>(R, Pinv); };
       auto load_g3 = [&]() {
-        ldv<pC, NC>(R, Cc_);
+        ldv<pC, NC>(PK, Cc_);
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
           vy[sl] = ld2(R, sV + 2 * sl);
@@ -824,12 +886,12 @@ struct MpcR16 {
         });
       };
       auto load_g4 = [&]() {
-        ldv<pK, NS>(R, Hr);
+        ldv<pK, NS>(PK, Hr);
         zr = ld2(R, sZ);
         bb = ld2(R, sZB);
       };
       auto load_g5 = [&]() {
-        ldv<pABr, NS>(R, AB);
+        ldv<pABr, NS>(PK, AB);
         if (i < N_) {
           lrn = ld2(R + kRec, sL);
           lbn = ld(R + kRec, sLB);
@@ -844,6 +906,10 @@ struct MpcR16 {
       bc_all<NX>(lp, lpb);
       const double u = dot4<NX>(Ac, lpb);
       // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
+      sfor<0, NS>([&](auto J) {
+        XR[decltype(J)::value] = decltype(J)::value <= ro ? XC[decltype(J)::value] : 0.0;
+        XC[decltype(J)::value] = decltype(J)::value >= ro ? XC[decltype(J)::value] : 0.0;
+      });
       const double s = tth[0] - bc_dot<0, NS>(XR, u);
       if (!kPrefetch) { load_g2(); FB_SB(); }
       const double dzu = bc_dot<0, NS>(XC, s);

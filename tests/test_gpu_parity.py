@@ -131,13 +131,23 @@ def test_mpc_reference_tests(hip, oracle, kats, idx):
 
 
 # -- one Newton step (LinearSolver::Initialize + Solve) -------------------------
-@pytest.mark.parametrize("generic", [0, 1])
-def test_newton_step_matches_oracle(hip, oracle, monkeypatch, generic):
+def _select_kernel(monkeypatch, kernel):
+    """r16: record-based 16-lane kernel (default for its shapes); g16: the earlier
+    16-lane register kernel; generic: one QP per wavefront through LDS."""
+    monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kernel == "generic" else "0")
+    if kernel == "g16":
+        monkeypatch.setenv("FBSTAB_HIP_MPC_KERNEL", "g16")
+    else:
+        monkeypatch.delenv("FBSTAB_HIP_MPC_KERNEL", raising=False)
+
+
+@pytest.mark.parametrize("kernel", ["r16", "g16", "generic"])
+def test_newton_step_matches_oracle(hip, oracle, monkeypatch, kernel):
     """Newton step of the device path vs the oracle's RiccatiLinearSolver at a
     random point of the BASELINE shape (cond(K) ~ 1e11 at sigma=1e-8), for the
-    generic LDS kernel and for the 16-lane register kernel; plus the W increment
+    generic LDS kernel and for the 16-lane kernels; plus the W increment
     against explicit matrices."""
-    monkeypatch.setenv("FBSTAB_HIP_GENERIC", str(generic))
+    _select_kernel(monkeypatch, kernel)
     p = fx.synthetic_mpc_batch(1, first_id=3)
     s = hip.FBstabMpcBatch(*p.sizes(), max_batch=1)
     rng = np.random.default_rng(5)
@@ -164,11 +174,10 @@ def test_newton_step_matches_oracle(hip, oracle, monkeypatch, generic):
     s.close()
 
 
-@pytest.mark.parametrize("generic", [0, 1])
-def test_mpc_paths_agree(hip, oracle, monkeypatch, generic):
-    """Both kernels (FBSTAB_HIP_GENERIC=1: one QP per wavefront through LDS;
-    default: four QPs per wavefront in registers) meet the parity definition."""
-    monkeypatch.setenv("FBSTAB_HIP_GENERIC", str(generic))
+@pytest.mark.parametrize("kernel", ["r16", "g16", "generic"])
+def test_mpc_paths_agree(hip, oracle, monkeypatch, kernel):
+    """All three kernels meet the parity definition."""
+    _select_kernel(monkeypatch, kernel)
     p = fx.synthetic_mpc_batch(192, first_id=500)
     o = default_options()
     gpu = _solve_mpc_host(hip, p, o)
@@ -184,6 +193,42 @@ def test_mpc_synthetic_batch_parity(hip, oracle):
     cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
     _assert_parity(gpu, cpu, o.abs_tol)
     assert (gpu[4]["residual"] <= o.abs_tol + o.rel_tol * 100).all()
+
+
+def _time_varying(p, plateau=(5, 10)):
+    """Stage-dependent matrices (the API is time-varying, fbstab_mpc.h:67-81):
+    costs, dynamics and constraint rows drift with the stage, except on a
+    plateau of identical stages in the middle of the horizon."""
+    N, nx, nu, nc = p.sizes()
+    a = {k: v.copy() for k, v in p.arrays.items()}
+    B = p.batch
+    def stage(i):
+        return plateau[0] if plateau[0] <= i < plateau[1] else i
+    for i in range(N + 1):
+        g = 1.0 + 0.03 * stage(i)
+        a["Q"].reshape(B, N + 1, nx * nx)[:, i] *= g
+        a["R"].reshape(B, N + 1, nu * nu)[:, i] *= 1.0 + 0.01 * stage(i)
+        a["E"].reshape(B, N + 1, nc * nx)[:, i] *= 1.0 + 0.02 * (stage(i) % 3)
+        a["L"].reshape(B, N + 1, nc * nu)[:, i] *= 1.0 + 0.01 * (stage(i) % 4)
+        if i < N:
+            a["A"].reshape(B, N, nx * nx)[:, i] *= 1.0 - 0.002 * stage(i)
+            a["B"].reshape(B, N, nx * nu)[:, i] *= 1.0 + 0.004 * stage(i)
+    q = fx.MpcProblem(N, nx, nu, nc)
+    q.arrays = a
+    return q
+
+
+@pytest.mark.parametrize("kernel", ["r16", "generic"])
+def test_time_varying_stage_data(hip, oracle, monkeypatch, kernel):
+    """Stage matrices that change along the horizon, with a run of identical
+    stages in the middle: the record kernel's per-stage matrix copies (shared
+    between identical neighbours) must reproduce the oracle either way."""
+    _select_kernel(monkeypatch, kernel)
+    p = _time_varying(fx.synthetic_mpc_batch(48, first_id=1200))
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
 
 
 def test_dense_synthetic_batch_parity(hip, oracle):
@@ -358,9 +403,12 @@ def test_receding_horizon_sweep_matches_oracle(hip, oracle):
         assert np.array_equal(g[k]["out"]["eflag"], c[k]["out"]["eflag"]), k
         dp = np.abs(g[k]["out"]["prox_iters"].astype(int) - c[k]["out"]["prox_iters"].astype(int))
         assert dp.max() <= 1, (k, dp.max())
-        flips += int((dp != 0).sum())
+        flipped = dp != 0
+        flips += int(flipped.sum())
         dn = np.abs(g[k]["out"]["newton_iters"].astype(int) - c[k]["out"]["newton_iters"].astype(int))
-        assert dn.max() <= 2, (k, dn.max())
+        # an extra (or missing) proximal iteration brings its Newton steps with it
+        assert dn[~flipped].max(initial=0) <= 2, (k, dn)
+        assert dn.max() <= 15, (k, dn)
         np.testing.assert_allclose(g[k]["u0"].cpu().numpy(), c[k]["u0"], atol=2e-5)
         np.testing.assert_allclose(g[k]["x0"].cpu().numpy(), c[k]["x0"], atol=2e-5)
     assert flips <= (T * S) // 50, flips

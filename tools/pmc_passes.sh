@@ -15,7 +15,7 @@ for set in \
   echo "pass $i rc=$?"
 done
 cd $R
-for i in 1 2 3 4; do python3 tools/rocpd_summary.py pmc $OUT/p$i/p_results.db g16 > $OUT/p$i.json 2>/dev/null; done
+for i in 1 2 3 4; do python3 tools/rocpd_summary.py pmc $OUT/p$i/p_results.db _kernel > $OUT/p$i.json 2>/dev/null; done
 python3 - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/p*.json")):
