@@ -181,10 +181,10 @@ struct Solver {
 
   // SolveProximalSubproblem (impl:229-304).  Returns Eo; *fail is set when
   // the linear solver could not factor (the reference throws, impl:263-274).
-  FB_DEV double subproblem(double tol, double sigma, double Ek, int* newton_iters,
+  FB_DEV double subproblem(double tol, double sigma, double Ek, double Ei0, int* newton_iters,
                            double* rk_last, bool* fail) const {
     if constexpr (P::kFusedTrial) {
-      return subproblem_fused(tol, sigma, Ek, newton_iters, rk_last, fail);
+      return subproblem_fused(tol, sigma, Ek, Ei0, newton_iters, rk_last, fail);
     } else {
       double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       double Eo = 0.0;
@@ -236,12 +236,18 @@ struct Solver {
   // accepted, a Newton iteration costs no pass over the iterate vectors beyond
   // the two stage sweeps of newton_step, and the loop-top norms of the next
   // iteration are the accepted trial's norms.
-  FB_DEV double subproblem_fused(double tol, double sigma, double Ek, int* newton_iters,
+  FB_DEV double subproblem_fused(double tol, double sigma, double Ek, double Ei0, int* newton_iters,
                                  double* rk_last, bool* fail) const {
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double Ei, Eo;
     FB_STAMP_DECL;
-    norms_at(0.0, sigma, true, &Ei, &Eo);
+    if constexpr (P::kOwnVectorOps) {
+      // open_prox() evaluated both norms at x = xbar together with the residual
+      Ei = Ei0;
+      Eo = Ek;
+    } else {
+      norms_at(0.0, sigma, true, &Ei, &Eo);
+    }
     double Eo_top = Eo;
     for (int i = 0; i < o.max_inner_iters; i++) {
       Eo_top = Eo;
@@ -316,9 +322,7 @@ struct Solver {
       Eo = Eot;
       FB_STAMP_LAP(18);
     }
-    if constexpr (P::kOwnVectorOps) {
-      p.flush_and_project(c);
-    } else {
+    if constexpr (!P::kOwnVectorOps) {  // (own policies: close_subproblem() does this)
       p.flush(c);
       for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
       c.sync();
@@ -342,7 +346,7 @@ struct Solver {
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
     double combo_tol = 0.0, Ek = 0.0, E0 = 0.0, rk_last = 0.0, inner_tol = 0.0, dx_norm = 0.0;
-    double Ei = 0.0, Eo = 0.0, Eo_top = 0.0;
+    double Ei = 0.0, Eo = 0.0, Eo_top = 0.0, Ei0 = 0.0;
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
     for (;;) {
@@ -352,10 +356,8 @@ struct Solver {
         out = out_base + q;
         combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
         p.load_guess(c);
-        copy_x_to_xbar();
         dx_norm = sqrt((double)p.num_primal_dual());
-        p.residual(c);
-        Ek = pnr_norm();
+        open_prox(sigma, &Ek, &Ei0);
         E0 = Ek;
         rk_last = Ek;
         newton = 0;
@@ -392,7 +394,12 @@ struct Solver {
         inner_tol = sat(inner_tol * o.delta, o.inner_tol_min, Ek);
         // SolveProximalSubproblem prologue (impl:233-243)
         for (int m = 0; m < 5; m++) merit[m] = 0.0;
-        norms_at(0.0, sigma, true, &Ei, &Eo);
+        if constexpr (P::kOwnVectorOps) {
+          Ei = Ei0;
+          Eo = Ek;
+        } else {
+          norms_at(0.0, sigma, true, &Ei, &Eo);
+        }
         Eo_top = Eo;
         inner_i = 0;
         phase = kInner;
@@ -471,8 +478,9 @@ struct Solver {
       } else {
         // subproblem epilogue (impl:301-303) and the rest of the proximal
         // iteration (impl:186-216)
+        int feas = kFeasible;
         if constexpr (P::kOwnVectorOps) {
-          p.flush_and_project(c);
+          feas = close_subproblem(&dx_norm);
         } else {
           p.flush(c);
           for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
@@ -492,24 +500,19 @@ struct Solver {
           phase = kFetch;
           continue;
         }
-        dx_norm = dx_from_xbar();
-        if (o.check_feasibility) {
-          const int f = p.feasibility(c, o.infeas_tol);
-          if (f != kFeasible) {
-            const int eflag = f == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
-                              : f == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
-                                                     : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
-            p.write_certificate(c);
-            finish(out, eflag, rk_last, newton, prox, E0);
-            phase = kFetch;
-            continue;
-          }
+        if constexpr (!P::kOwnVectorOps) feas = close_subproblem(&dx_norm);
+        if (feas != kFeasible) {
+          const int eflag = feas == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
+                            : feas == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
+                                                      : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
+          p.write_certificate(c);
+          finish(out, eflag, rk_last, newton, prox, E0);
+          phase = kFetch;
+          continue;
         }
-        copy_x_to_xbar();
         prox++;
         k++;
-        p.residual(c);
-        Ek = pnr_norm();
+        open_prox(sigma, &Ek, &Ei0);
         phase = kProxTop;
       }
     }
@@ -520,10 +523,9 @@ struct Solver {
     const double sigma = o.sigma0;
     const double combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
     p.load_guess(c);  // xk <- (z0,l0,v0), y = b - A z (impl:140, :334-347)
-    copy_x_to_xbar();
     double dx_norm = sqrt((double)p.num_primal_dual());  // dx.Fill(1) (impl:142)
-    p.residual(c);
-    double Ek = pnr_norm();
+    double Ek, Ei0;
+    open_prox(sigma, &Ek, &Ei0);
     const double E0 = Ek;
     double rk_last = Ek;
     int newton = 0, prox = 0;
@@ -554,13 +556,16 @@ struct Solver {
       }
       inner_tol = sat(inner_tol * o.delta, o.inner_tol_min, Ek);
       bool fail = false;
-      const double Eo = subproblem(inner_tol, sigma, Ek, &newton, &rk_last, &fail);
+      const double Eo = subproblem(inner_tol, sigma, Ek, Ei0, &newton, &rk_last, &fail);
       if (fail) {
         eflag = FBSTAB_DIVERGENCE;
+        if constexpr (P::kOwnVectorOps) p.flush(c);
         p.write_x(c);
         done = true;
         break;
       }
+      int feas = kFeasible;
+      if constexpr (P::kOwnVectorOps) feas = close_subproblem(&dx_norm);
       if (newton >= o.max_newton_iters) {  // impl:188-199
         eflag = FBSTAB_MAXITERATIONS;
         if (Eo < Ek) {
@@ -574,26 +579,21 @@ struct Solver {
         done = true;
         break;
       }
-      // dx <- x(k+1) - x(k) (impl:202-203); its norm excludes y
-      // (full_variable.cc:77-83).
-      dx_norm = dx_from_xbar();
-      if (o.check_feasibility) {
-        const int f = p.feasibility(c, o.infeas_tol);
-        if (f != kFeasible) {
-          eflag = f == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
-                  : f == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
-                                         : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
-          p.write_certificate(c);  // x <- dx (impl:205-210); residual stays stale
-          done = true;
-          break;
-        }
+      // dx <- x(k+1) - x(k) (impl:202-203; its norm excludes y,
+      // full_variable.cc:77-83) and the infeasibility certificates
+      if constexpr (!P::kOwnVectorOps) feas = close_subproblem(&dx_norm);
+      if (feas != kFeasible) {
+        eflag = feas == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
+                : feas == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
+                                          : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
+        p.write_certificate(c);  // x <- dx (impl:205-210); residual stays stale
+        done = true;
+        break;
       }
-      copy_x_to_xbar();
       prox++;
-      // Residual at the projected x(k+1): serves the next loop-top test
-      // (impl:162-163) and the first inner iteration (impl:239-243).
-      p.residual(c);
-      Ek = pnr_norm();
+      // xbar <- x and the residual at the projected x(k+1): serves the next
+      // loop-top test (impl:162-163) and the first inner iteration (impl:239-243).
+      open_prox(sigma, &Ek, &Ei0);
     }
     if (!done) {
       // Timeout exit (impl:219-223): residual is whatever rk last held.
@@ -604,6 +604,29 @@ struct Solver {
   }
 
  private:
+  // xbar <- x, natural residual at x, Ek = its norm (impl:140-146, :212-216).
+  // Policies with their own vector passes do all of it in one sweep and also
+  // return the inner residual norm at x = xbar (impl:239-243).
+  FB_DEV void open_prox(double sigma, double* Ek, double* Ei0) const {
+    if constexpr (P::kOwnVectorOps) {
+      p.open_prox(c, sigma, o.alpha, Ek, Ei0);
+    } else {
+      copy_x_to_xbar();
+      p.residual(c);
+      *Ek = pnr_norm();
+      *Ei0 = 0.0;  // unused: subproblem() evaluates it
+    }
+  }
+  // dx <- x - xbar, its norm, and the feasibility verdict (impl:202-210).  Own
+  // policies also apply the pending step and project the duals here (impl:301).
+  FB_DEV int close_subproblem(double* dx_norm) const {
+    if constexpr (P::kOwnVectorOps) {
+      return p.close_subproblem(c, o.infeas_tol, o.check_feasibility != 0, dx_norm);
+    } else {
+      *dx_norm = dx_from_xbar();
+      return o.check_feasibility ? p.feasibility(c, o.infeas_tol) : kFeasible;
+    }
+  }
   // dx <- x - xbar (z, l, v blocks); returns its norm.
   FB_DEV double dx_from_xbar() const {
     if constexpr (P::kOwnVectorOps) {

@@ -421,139 +421,133 @@ struct MpcR16 {
   }
 
   // x <- x + t dx, (rz, rl) <- (rz, rl) + t W for the pending step (impl:298,
-  // full_variable.cc:55-65); with `project`, v <- max(v, 0) as well (impl:301).
-  template <bool PROJECT>
-  FB_DEV void flush_impl(const C& c) {
+  // full_variable.cc:55-65).
+  FB_DEV void flush(const C& c) {
     const double t = pend_t;
     pend_t = 0.0;
-    if (t == 0.0 && !PROJECT) return;
+    if (t == 0.0) return;
     const int N_ = N;
     double* const R0 = rec;
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      if (t != 0.0) {
-        const dbl2 zr = ld2(R, sZ), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
-        st2(R, sZ, fma(t, dw[0], zr[0]), fma(t, dw[1], zr[1]));
-        st2(R, sL, fma(t, dwl[0], lr[0]), fma(t, dwl[1], lr[1]));
-      }
+      const dbl2 zr = ld2(R, sZ), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+      st2(R, sZ, fma(t, dw[0], zr[0]), fma(t, dw[1], zr[1]));
+      st2(R, sL, fma(t, dwl[0], lr[0]), fma(t, dwl[1], lr[1]));
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        dbl2 vy = ld2(R, sV + 2 * sl);
-        if (t != 0.0) {
-          const dbl2 da = ld2(R, sDV + 2 * sl);
-          vy[0] = fma(t, da[0], vy[0]);
-          vy[1] = fma(-t, da[1], vy[1]);
-        }
-        if (PROJECT) vy[0] = fmax0(vy[0]);
-        st2(R, sV + 2 * sl, vy[0], vy[1]);
-      });
-    }
-    c.sync();
-  }
-  FB_DEV void flush(const C& c) { flush_impl<false>(c); }
-  FB_DEV void flush_and_project(const C& c) { flush_impl<true>(c); }
-
-  // dx <- x - xbar on (z, l, v); returns ||dx|| (impl:202-203, full_variable.cc:77-83).
-  FB_DEV double dx_from_xbar(const C& c) const {
-    const int N_ = N;
-    double* const R0 = rec;
-    double s = 0.0;
-    for (int i = 0; i <= N_; i++) {
-      double* R = R0 + (long)i * kRec;
-      const dbl2 bb = ld2(R, sZB);
-      const double dz = ld(R, sZ) - bb[0], dl = ld(R, sL) - bb[1];
-      st(R, sDZ, dz);
-      st(R, sDL, dl);
-      s = fma(dz, dz, s);
-      s = fma(dl, dl, s);
-      sfor<0, KS>([&](auto S_) {
-        constexpr int sl = decltype(S_)::value;
-        const double dv = ld(R, sV + 2 * sl) - ld(R, sVB + 2 * sl);
-        st(R, sDV + 2 * sl, dv);
-        s = fma(dv, dv, s);
-      });
-    }
-    c.sync();
-    return sqrt(row_reduce<OpSum16>(s));
-  }
-
-  FB_DEV void copy_x_to_xbar(const C& c) const {
-    const int N_ = N;
-    double* const R0 = rec;
-    for (int i = 0; i <= N_; i++) {
-      double* R = R0 + (long)i * kRec;
-      st2(R, sZB, ld(R, sZ), ld(R, sL));
-      sfor<0, KS>([&](auto S_) {
-        constexpr int sl = decltype(S_)::value;
-        const dbl2 vy = ld2(R, sV + 2 * sl);
-        st2(R, sVB + 2 * sl, vy[0], vy[1]);
+        const dbl2 vy = ld2(R, sV + 2 * sl), da = ld2(R, sDV + 2 * sl);
+        st2(R, sV + 2 * sl, fma(t, da[0], vy[0]), fma(-t, da[1], vy[1]));
       });
     }
     c.sync();
   }
 
-  // Infeasibility certificates for dx = (dz, dl, dv) (full_feasibility.cc:25-88).
-  FB_DEV int feasibility(const C& c, double tol) const {
+  // End of a proximal subproblem, ONE pass over the records: applies the
+  // pending step, projects the duals (impl:298-301), forms dx = x - xbar on
+  // (z, l, v) with its norm (impl:202-203, full_variable.cc:77-83) and
+  // evaluates the infeasibility certificates for it (full_feasibility.cc:25-88).
+  // The (z, l) blocks of stage i+1 are needed at stage i (G dz, G'dl): they
+  // are fetched one stage ahead and handed on.
+  struct ZL {
+    double z, rz, l, rl, dz, dl;
+  };
+  static FB_DEV ZL stepped_zl(const double* R, double t) {
+    const dbl2 zr = ld2(R, sZ), bb = ld2(R, sZB), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+    ZL o;
+    o.z = fma(t, dw[0], zr[0]);
+    o.rz = fma(t, dw[1], zr[1]);
+    o.l = fma(t, dwl[0], lr[0]);
+    o.rl = fma(t, dwl[1], lr[1]);
+    o.dz = o.z - bb[0];
+    o.dl = o.l - bb[1];
+    return o;
+  }
+  FB_DEV int close_subproblem(const C& c, double tol, bool check, double* dx_norm) {
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
-    const double* const R0 = rec;
+    const double t = pend_t;
+    pend_t = 0.0;
+    double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
     lds_ptr Cl = lds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
-    double s_fdz = 0.0, s_p2 = 0.0;
+    double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
+    ZL cur = stepped_zl(R0, t);
     for (int i = 0; i <= N_; i++) {
-      const double* R = R0 + (long)i * kRec;
-      const double* PK = P0 + po[i];
-      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-      ldv<pK, NS>(PK, Kr);
-      ldv<pC, NC>(PK, Cc);
-      ldv<pABr, NS>(PK, ABr);
-      ldv<pABc, NX>(PK, ABc);
-      const double dz = ld(R, sDZ), dl = ld(R, sDL);
-      const dbl2 fh = ld2(R, sF);
-      double dvs[KS], bs[KS];
+      double* R = R0 + (long)i * kRec;
+      ZL nxt;
+      nxt.z = nxt.rz = nxt.l = nxt.rl = nxt.dz = nxt.dl = 0.0;
+      if (i < N_) nxt = stepped_zl(R + kRec, t);
+      dbl2 vy[KS], da[KS], vb[KS];
       sfor<0, KS>([&](auto S_) {
-        dvs[decltype(S_)::value] = ld(R, sDV + 2 * decltype(S_)::value);
-        bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value);
+        constexpr int sl = decltype(S_)::value;
+        vy[sl] = ld2(R, sV + 2 * sl);
+        da[sl] = ld2(R, sDV + 2 * sl);
+        vb[sl] = ld2(R, sVB + 2 * sl);
       });
-      double dln = 0.0, dzn = 0.0;
-      if (i < N_) {
-        dln = ld(R + kRec, sDL);
-        dzn = ld(R + kRec, sDZ);
-      }
-      double dzb[NS], dlnb[NX];
-      bc_all<NS>(dz, dzb);
-      bc_all<NX>(dln, dlnb);
-      m_hdz = fmax(m_hdz, fabs(dot4<NS>(Kr, dzb)));
-      m_dz = fmax(m_dz, fabs(dz));
-      {
-        double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? dl : 0.0), 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
-                        [&](auto I, double t) {
-                          constexpr int k = decltype(I)::value;
-                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
-                        });
-        m_atv = fmax(m_atv, fabs((p[0] + p[1]) + (p[2] + p[3])));
-      }
-      s_fdz = fma(fh[0], dz, s_fdz);
-      // (G dz): block 0 = -dx(0); block i+1 = A dx + B du - dx(i+1); h'dl
-      m_u = fmax(m_u, fabs(dl));
-      s_p2 = fma(fh[1], dl, s_p2);
-      if (i == 0) m_gdz = fmax(m_gdz, rx ? fabs(dz) : 0.0);
-      if (i < N_) {
-        const double g = dot4<NS>(ABr, dzb) - dzn;
-        m_gdz = fmax(m_gdz, rx ? fabs(g) : 0.0);
-      }
-      C_to_lds(c, Cl, Cc, r);
-      rows_of_C_times(Cl, dzb, r, [&](auto S_, bool valid, double az) {
-        constexpr int s = decltype(S_)::value;
-        if (valid) m_adz = fmax(m_adz, az);
-        m_u = fmax(m_u, fabs(dvs[s]));
-        s_p2 = fma(bs[s], dvs[s], s_p2);
+      st2(R, sZ, cur.z, cur.rz);
+      st2(R, sL, cur.l, cur.rl);
+      st2(R, sDZ, cur.dz, 0.0);
+      st2(R, sDL, cur.dl, 0.0);
+      s_dx = fma(cur.dz, cur.dz, s_dx);
+      s_dx = fma(cur.dl, cur.dl, s_dx);
+      double dvs[KS];
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const double vv = fmax0(fma(t, da[sl][0], vy[sl][0]));
+        const double yy = fma(-t, da[sl][1], vy[sl][1]);
+        dvs[sl] = vv - vb[sl][0];
+        st2(R, sV + 2 * sl, vv, yy);
+        st2(R, sDV + 2 * sl, dvs[sl], 0.0);
+        s_dx = fma(dvs[sl], dvs[sl], s_dx);
       });
+      if (check) {
+        const double* PK = P0 + po[i];
+        double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+        ldv<pK, NS>(PK, Kr);
+        ldv<pC, NC>(PK, Cc);
+        ldv<pABr, NS>(PK, ABr);
+        ldv<pABc, NX>(PK, ABc);
+        const dbl2 fh = ld2(R, sF);
+        double bs[KS];
+        sfor<0, KS>([&](auto S_) { bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value); });
+        double dzb[NS], dlnb[NX];
+        bc_all<NS>(cur.dz, dzb);
+        bc_all<NX>(nxt.dl, dlnb);
+        m_hdz = fmax(m_hdz, fabs(dot4<NS>(Kr, dzb)));
+        m_dz = fmax(m_dz, fabs(cur.dz));
+        {
+          double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? cur.dl : 0.0), 0.0, 0.0, 0.0};
+          bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
+                          [&](auto I, double tt) {
+                            constexpr int k = decltype(I)::value;
+                            p[k & 3] = fma(Cc[k], tt, p[k & 3]);
+                          });
+          m_atv = fmax(m_atv, fabs((p[0] + p[1]) + (p[2] + p[3])));
+        }
+        s_fdz = fma(fh[0], cur.dz, s_fdz);
+        // (G dz): block 0 = -dx(0); block i+1 = A dx + B du - dx(i+1); h'dl
+        m_u = fmax(m_u, fabs(cur.dl));
+        s_p2 = fma(fh[1], cur.dl, s_p2);
+        if (i == 0) m_gdz = fmax(m_gdz, rx ? fabs(cur.dz) : 0.0);
+        if (i < N_) {
+          const double g = dot4<NS>(ABr, dzb) - nxt.dz;
+          m_gdz = fmax(m_gdz, rx ? fabs(g) : 0.0);
+        }
+        C_to_lds(c, Cl, Cc, r);
+        rows_of_C_times(Cl, dzb, r, [&](auto S_, bool valid, double az) {
+          constexpr int s = decltype(S_)::value;
+          if (valid) m_adz = fmax(m_adz, az);
+          m_u = fmax(m_u, fabs(dvs[s]));
+          s_p2 = fma(bs[s], dvs[s], s_p2);
+        });
+      }
+      cur = nxt;
     }
     c.sync();
+    *dx_norm = sqrt(row_reduce<OpSum16>(s_dx));
+    if (!check) return kFeasible;
     const double d1 = row_reduce<OpMax16>(m_adz), d2 = row_reduce<OpMax16>(m_gdz),
                  d3 = row_reduce<OpMax16>(m_hdz), w = row_reduce<OpMax16>(m_dz),
                  p1 = row_reduce<OpMax16>(m_atv), u = row_reduce<OpMax16>(m_u);
@@ -566,6 +560,83 @@ struct MpcR16 {
     if (primal_feasible && !dual_feasible) return kDualInfeasible;
     if (!primal_feasible && dual_feasible) return kPrimalInfeasible;
     return kBothInfeasible;
+  }
+
+  // Start of a proximal iteration, ONE pass: xbar <- x (impl:212), the natural
+  // residual at x (residual() above) and both norms the algorithm needs next:
+  //   Ek  = ||(rz, rl, pnr(y, v))||                 (impl:146, :216)
+  //   Ei0 = ||(rz, rl, pfb(y, v))||, the inner residual norm at x = xbar, where
+  //         the sigma terms vanish identically      (impl:239-243)
+  FB_DEV void open_prox(const C& c, double sigma, double alpha, double* Ek, double* Ei0) const {
+    (void)sigma;
+    const int r = c.tid, N_ = N;
+    const bool rx = r < NX;
+    double* const R0 = rec;
+    const double* const P0 = pack;
+    const int* const po = poff;
+    double s_nat = 0.0, s_vo = 0.0, s_vi = 0.0;
+    dbl2 zl = {ld(R0, sZ), ld(R0, sL)};  // (z, l) of stage i, handed on
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      const double* PK = P0 + po[i];
+      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+      ldv<pK, NS>(PK, Kr);
+      ldv<pC, NC>(PK, Cc);
+      ldv<pABr, NS>(PK, ABr);
+      ldv<pABc, NX>(PK, ABc);
+      const dbl2 fh = ld2(R, sF);
+      dbl2 vy[KS];
+      sfor<0, KS>([&](auto S_) { vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
+      dbl2 zln = {0.0, 0.0};
+      double hn = 0.0;
+      if (i < N_) {
+        zln[0] = ld(R + kRec, sZ);
+        zln[1] = ld(R + kRec, sL);
+        hn = ld(R + kRec, sH);
+      }
+      const double zz = zl[0], ll = zl[1];
+      st2(R, sZB, zz, ll);
+      double zb[NS], lnb[NX];
+      bc_all<NS>(zz, zb);
+      bc_all<NX>(zln[1], lnb);
+      double s = fh[0] + dot4<NS>(Kr, zb);
+      s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
+      {
+        double p[4] = {s, 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(vy[decltype(I)::value >> 4][0]); },
+                        [&](auto I, double t) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
+                        });
+        s = (p[0] + p[1]) + (p[2] + p[3]);
+      }
+      st(R, sRZ, s);
+      s_nat = fma(s, s, s_nat);
+      if (i == 0) {
+        const double rl0 = rx ? fh[1] + zz : 0.0;
+        st(R, sRL, rl0);
+        s_nat = fma(rl0, rl0, s_nat);
+      }
+      if (i < N_) {
+        const double abz = dot4<NS>(ABr, zb);
+        const double rln = rx ? hn - (abz - zln[0]) : 0.0;
+        st(R + kRec, sRL, rln);
+        s_nat = fma(rln, rln, s_nat);
+      }
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        st2(R, sVB + 2 * sl, vy[sl][0], vy[sl][1]);
+        const double pn = pnr(vy[sl][1], vy[sl][0], alpha);  // zero on padding lanes
+        const double pf = pfb(vy[sl][1], vy[sl][0], alpha);
+        s_vo = fma(pn, pn, s_vo);
+        s_vi = fma(pf, pf, s_vi);
+      });
+      zl = zln;
+    }
+    c.sync();
+    const double nat = row_reduce<OpSum16>(s_nat);
+    *Ek = sqrt(nat + row_reduce<OpSum16>(s_vo));
+    *Ei0 = sqrt(nat + row_reduce<OpSum16>(s_vi));
   }
 
   // ---- results ---------------------------------------------------------------------
