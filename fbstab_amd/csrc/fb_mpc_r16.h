@@ -57,8 +57,10 @@ struct MpcR16 {
   static constexpr bool kOwnVectorOps = true;
 #if defined(FB_R16_PREFETCH)
   static constexpr bool kPrefetch = FB_R16_PREFETCH != 0;
-#else
+#elif defined(FB_R16_MIN_WAVES) && FB_R16_MIN_WAVES > 1
   static constexpr bool kPrefetch = false;
+#else
+  static constexpr bool kPrefetch = true;
 #endif
   static constexpr int NS = NX + NU;
   static constexpr int KS = (NC + 15) / 16;  // constraint slots per lane

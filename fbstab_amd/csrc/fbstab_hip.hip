@@ -209,8 +209,13 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
   }
 }
 
+// Build knobs (measured on the BASELINE workload):
+//   FB_R16_MIN_WAVES  1: 512 registers per wave, loads prefetched a stage ahead
+//                     2: two waves per SIMD, loads at the point of use
+//   FB_R16_FLAT       rows never wait for each other (solve_stream) instead of
+//                     the four rows of a wavefront running solve() in step
 #ifndef FB_R16_MIN_WAVES
-#define FB_R16_MIN_WAVES 2
+#define FB_R16_MIN_WAVES 1
 #endif
 // Record-based 16-lane kernel (fb_mpc_r16.h): four QPs per wavefront, rows pull
 // QP indices from the shared counter.  scratch: rows * ws_doubles(N).
@@ -239,14 +244,14 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
     Solver<P, Ctx16> solver(p, ctx, opts);
-#ifdef FB_R16_NESTED
+#ifdef FB_R16_FLAT
+    solver.solve_stream(next, out);
+#else
     for (;;) {
       const int q = next(p);
       if (q < 0) break;
       solver.solve(out + q);
     }
-#else
-    solver.solve_stream(next, out);
 #endif
   }
 }
