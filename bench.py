@@ -197,7 +197,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(B),
-                         "kernel": "fbstab_mpc_g16_kernel<12,4,20>", "kernel_ms": k_ms,
+                         "kernel": "fbstab_mpc_r16_kernel<12,4,20>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B},
             "fp64": {"model_flop_per_newton_iter": FLOP_PER_NEWTON,
                      "mean_newton_iters": mean_newton,
