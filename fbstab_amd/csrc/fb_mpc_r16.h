@@ -100,16 +100,25 @@ struct MpcR16 {
 
   static constexpr int off(int slot) { return (slot >> 1) * 32 + (slot & 1); }
 
-  // LDS of one row: C as [col][k] (backward sweep, A z products) or the 16 x 16
-  // transpose buffer (forward sweep); odd strides, rows 16 doubles mod 32 apart.
+  // LDS of one row:
+  //   [0, kPackLds)   the matrix copy the current stage uses, minus the [A B]
+  //                   columns (same pair-interleaved image as in HBM): loaded
+  //                   when poff[i] changes, i.e. three to five times per sweep
+  //                   pair for a time-invariant plant, and read by every pass
+  //                   with 16-byte LDS loads;
+  //   [kPackLds, ..)  C as [col][k] (A z products) or the 16 x 16 transpose
+  //                   buffer (forward sweep); odd strides.
   static constexpr int CS = NC | 1, TS = 17;
-  static constexpr int kLdsDoubles = 16 * (CS > TS ? CS : TS);
+  static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
+  static constexpr int kPackLds = 16 * kPackLdsSlots;
+  static constexpr int kLdsDoubles = kPackLds + 16 * (CS > TS ? CS : TS);
   static constexpr int kLdsPerRow = ((kLdsDoubles + 31) & ~31) + 16;
 
   // ---- state -------------------------------------------------------------------
   double* rec;   // this row's records, lane offset included
   double* pack;  // this row's matrix copies, lane offset included
   int* poff;     // per stage: offset (doubles) of the copy it reads
+  int lds_off;   // offset of the copy currently in LDS (-1: none)
   lds_ptr lds;
   const MpcBatchPtrs* data;  // kernel arguments (uniform)
   const VarBatchPtrs* var;
@@ -121,6 +130,7 @@ struct MpcR16 {
 
   FB_DEV void bind(double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d, const VarBatchPtrs* x,
                    long q_, int N_, int lane16) {
+    lds_off = -1;
     poff = reinterpret_cast<int*>(ws_row);
     pack = ws_row + hdr_doubles(N_) + 2 * lane16;
     rec = pack + (long)kPack * (N_ + 1);
@@ -163,6 +173,37 @@ struct MpcR16 {
       *reinterpret_cast<dbl2*>(R + (S0 / 2 + pr) * 32) = t;
     });
     if constexpr (CNT & 1) R[(S0 / 2 + CNT / 2) * 32] = in[CNT - 1];
+  }
+
+  // Makes the matrix copy at offset `off` the one resident in LDS (row-uniform).
+  FB_DEV void stage_pack(const C& c, int off) { stage_pack_s(c, pack, lds + 2 * c.tid, lds_off, off); }
+  static FB_DEV void stage_pack_s(const C& c, const double* pack0, lds_ptr dst, int& cur, int off) {
+    if (off == cur) return;
+    cur = off;
+    const double* src = pack0 + off;
+    c.sync();  // earlier readers of the previous copy
+    constexpr int kPairs = kPackLdsSlots / 2, kChunk = 13;
+    sfor<0, (kPairs + kChunk - 1) / kChunk>([&](auto Ch) {
+      constexpr int c0 = decltype(Ch)::value * kChunk;
+      constexpr int cn = c0 + kChunk < kPairs ? kChunk : kPairs - c0;
+      dbl2 t[kChunk];
+      sfor<0, cn>([&](auto I) { t[decltype(I)::value] = *reinterpret_cast<const dbl2*>(src + (c0 + decltype(I)::value) * 32); });
+      sfor<0, cn>([&](auto I) {
+        *reinterpret_cast<FB_LDS dbl2*>(dst + (c0 + decltype(I)::value) * 32) = t[decltype(I)::value];
+      });
+    });
+    c.sync();
+  }
+  // slots [S0, S0 + CNT) of the LDS-resident copy into out[0..CNT)
+  template <int S0, int CNT, int NOUT>
+  static FB_DEV void ldl(lds_ptr L, double (&out)[NOUT]) {
+    static_assert((S0 & 1) == 0 && S0 + CNT <= kPackLdsSlots, "inside the LDS image, on a pair");
+    sfor<0, (CNT + 1) / 2>([&](auto P_) {
+      constexpr int pr = decltype(P_)::value;
+      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + (S0 / 2 + pr) * 32);
+      out[2 * pr] = t[0];
+      if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
+    });
   }
 
   // (A zz)_k for the constraints k = r + 16 s of this lane, zz given in every
@@ -210,7 +251,7 @@ struct MpcR16 {
     const bool rx = r < NX, rs_ = r < NS;
     const int ru = r - NX;
     double* const R0 = rec;
-    lds_ptr Cl = lds;
+    lds_ptr Cl = lds + kPackLds;
     const double *Q = arr(FBSTAB_MPC_Q), *Rm = arr(FBSTAB_MPC_R), *S = arr(FBSTAB_MPC_S),
                  *pq = arr(FBSTAB_MPC_q), *pr = arr(FBSTAB_MPC_r), *A = arr(FBSTAB_MPC_A),
                  *B = arr(FBSTAB_MPC_B), *pc = arr(FBSTAB_MPC_c), *E = arr(FBSTAB_MPC_E),
@@ -275,6 +316,7 @@ struct MpcR16 {
         if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) canon = i * kPack;
       }
       po[i] = canon;  // every lane: each later reads its own store
+      lds_off = -1;
       // constants f, h, b (mpc_data.cc:240-289)
       const double f = rx ? pq[(long)i * NX + r] : (rs_ ? pr[(long)i * NU + ru] : 0.0);
       const double h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * NX + r]) : 0.0;
@@ -304,20 +346,22 @@ struct MpcR16 {
 
   // Natural residual blocks at x: rz = Hz + f + G'l + A'v, rl = h - Gz
   // (full_residual.cc:79-91; mpc_data.cc:28-63, :127-152, :171-198, :217-237).
-  FB_DEV void residual(const C& c) const {
+  FB_DEV void residual(const C& c) {
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
+    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      const double* PK = P0 + po[i];
+      const int pofs = po[i];
+      stage_pack(c, pofs);
       double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-      ldv<pK, NS>(PK, Kr);
-      ldv<pC, NC>(PK, Cc);
-      ldv<pABr, NS>(PK, ABr);
-      ldv<pABc, NX>(PK, ABc);
+      ldl<pK, NS>(Lp, Kr);
+      ldl<pC, NC>(Lp, Cc);
+      ldl<pABr, NS>(Lp, ABr);
+      ldv<pABc, NX>(P0 + pofs, ABc);
       const double zz = ld(R, sZ), ll = ld(R, sL);
       const dbl2 fh = ld2(R, sF);
       double vs[KS];
@@ -472,7 +516,8 @@ struct MpcR16 {
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
-    lds_ptr Cl = lds;
+    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
+    lds_ptr Cl = lds + kPackLds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
     double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
     ZL cur = stepped_zl(R0, t);
@@ -505,12 +550,13 @@ struct MpcR16 {
         s_dx = fma(dvs[sl], dvs[sl], s_dx);
       });
       if (check) {
-        const double* PK = P0 + po[i];
+        const int pofs = po[i];
+        stage_pack(c, pofs);
         double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-        ldv<pK, NS>(PK, Kr);
-        ldv<pC, NC>(PK, Cc);
-        ldv<pABr, NS>(PK, ABr);
-        ldv<pABc, NX>(PK, ABc);
+        ldl<pK, NS>(Lp, Kr);
+        ldl<pC, NC>(Lp, Cc);
+        ldl<pABr, NS>(Lp, ABr);
+        ldv<pABc, NX>(P0 + pofs, ABc);
         const dbl2 fh = ld2(R, sF);
         double bs[KS];
         sfor<0, KS>([&](auto S_) { bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value); });
@@ -569,23 +615,25 @@ struct MpcR16 {
   //   Ek  = ||(rz, rl, pnr(y, v))||                 (impl:146, :216)
   //   Ei0 = ||(rz, rl, pfb(y, v))||, the inner residual norm at x = xbar, where
   //         the sigma terms vanish identically      (impl:239-243)
-  FB_DEV void open_prox(const C& c, double sigma, double alpha, double* Ek, double* Ei0) const {
+  FB_DEV void open_prox(const C& c, double sigma, double alpha, double* Ek, double* Ei0) {
     (void)sigma;
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
+    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
     double s_nat = 0.0, s_vo = 0.0, s_vi = 0.0;
     dbl2 zl = {ld(R0, sZ), ld(R0, sL)};  // (z, l) of stage i, handed on
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      const double* PK = P0 + po[i];
+      const int pofs = po[i];
+      stage_pack(c, pofs);
       double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-      ldv<pK, NS>(PK, Kr);
-      ldv<pC, NC>(PK, Cc);
-      ldv<pABr, NS>(PK, ABr);
-      ldv<pABc, NX>(PK, ABc);
+      ldl<pK, NS>(Lp, Kr);
+      ldl<pC, NC>(Lp, Cc);
+      ldl<pABr, NS>(Lp, ABr);
+      ldv<pABc, NX>(P0 + pofs, ABc);
       const dbl2 fh = ld2(R, sF);
       dbl2 vy[KS];
       sfor<0, KS>([&](auto S_) { vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
@@ -734,9 +782,8 @@ struct MpcR16 {
     dbl2 zr, bb, dw, lr, dwl;
     dbl2 vy[KS], da[KS];
     double vb[KS];
-    double Cc[NC], K[NS];
   };
-  static FB_DEV void load_fwd(const double* R, const double* PK, FwdIn& in) {
+  static FB_DEV void load_fwd(const double* R, FwdIn& in) {
     in.zr = ld2(R, sZ);
     in.bb = ld2(R, sZB);
     in.dw = ld2(R, sDZ);
@@ -748,8 +795,6 @@ struct MpcR16 {
       in.da[s] = ld2(R, sDV + 2 * s);
       in.vb[s] = ld(R, sVB + 2 * s);
     });
-    ldv<pC, NC>(PK, in.Cc);
-    ldv<pK, NS>(PK, in.K);
   }
 
   FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
@@ -760,8 +805,9 @@ struct MpcR16 {
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
-    lds_ptr Tr = lds;
-    lds_ptr Cl = lds;
+    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
+    lds_ptr Tr = lds + kPackLds;
+    lds_ptr Cl = lds + kPackLds;
     const bool rx = r < NX;
     const double tp = pend_t;  // pending step length
     pend_t = 0.0;
@@ -776,23 +822,23 @@ struct MpcR16 {
     // Cholesky chain (hand software pipelining, for one wave per SIMD); without
     // it each stage loads at its top and a second resident wave covers the wait.
     FwdIn cur;
-    // offsets of the matrix copies of stages i, i+1 (and i+2 in flight)
+    // offsets of the matrix copies of stages i and i+1 (fetched a stage ahead)
     int pcur = po[0], pnxt = po[N_ > 0 ? 1 : 0];
-    if (kPrefetch) load_fwd(R0, P0 + pcur, cur);
+    int loff = lds_off;  // copy resident in LDS
+    if (kPrefetch) load_fwd(R0, cur);
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      const double* PK = P0 + pcur;
       const int pnn = po[i + 2 <= N_ ? i + 2 : N_];
-      if (!kPrefetch) load_fwd(R, PK, cur);
+      if (!kPrefetch) load_fwd(R, cur);
+      stage_pack_s(c, P0, Lp, loff, pcur);
       // Lane id made opaque per iteration: (ro == j) selects are then recomputed
       // where used instead of being hoisted out of the loop as 16+ live masks.
       int ro = r;
       asm volatile("" : "+v"(ro));
-      double Cc_[NC];
-      sfor<0, NC>([&](auto Kk) { Cc_[decltype(Kk)::value] = cur.Cc[decltype(Kk)::value]; });
-      double K[NS];
-      sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = cur.K[decltype(Cc)::value]; });
+      double Cc_[NC], K[NS];
+      ldl<pC, NC>(Lp, Cc_);
+      ldl<pK, NS>(Lp, K);
       // ---- pending step (tp = 0: no-op), PFB gradient (riccati_linear_solver.cc:91-99)
       double Gam[KS], Rvm[KS];
       sfor<0, KS>([&](auto S_) {
@@ -851,10 +897,10 @@ struct MpcR16 {
       FB_STAMP_LAP(2);
       // [A B] row r for W, requested now so that it arrives behind the chains
       double AB[NS];
-      ldv<pABr, NS>(PK, AB);
+      ldl<pABr, NS>(Lp, AB);
       // ---- Lc = chol(K), columns of inv(Lc)
       ok = chol_rows<NS>(K, ro, sigma) && ok;
-      if (!ok) return false;
+      if (!ok) { lds_off = loff; return false; }
       double XC[NS];
       FB_STAMP_LAP(3);
       FB_SB();
@@ -889,7 +935,7 @@ struct MpcR16 {
                               [&](auto I, double t) { W[k + decltype(I)::value] = fma(AB[k], t, W[k + decltype(I)::value]); });
         });
         // next stage's inputs: in flight during the second chain below
-        if (kPrefetch) load_fwd(R + kRec, P0 + pnxt, cur);
+        if (kPrefetch) load_fwd(R + kRec, cur);
         FB_SB();
         FB_STAMP_LAP(6);
         // theta(i+1) partial = -W t
@@ -906,7 +952,7 @@ struct MpcR16 {
         FB_SB();
         FB_STAMP_LAP(7);
         ok = chol_rows<NX>(Pn, ro, sigma) && ok;
-        if (!ok) return false;
+        if (!ok) { lds_off = loff; return false; }
         FB_SB();
         double T[NX];
         tri_inv_cols<NX>(Pn, T, ro);
@@ -934,6 +980,7 @@ struct MpcR16 {
     for (int i = N_; i >= 0; i--) {
       double* R = R0 + (long)i * kRec;
       const double* PK = P0 + pcur;
+      stage_pack_s(c, P0, Lp, loff, pcur);
       pcur = po[i > 0 ? i - 1 : 0];
       int ro = r;
       asm volatile("" : "+v"(ro));
@@ -950,7 +997,7 @@ struct MpcR16 {
       auto load_g1 = [&]() {};
       auto load_g2 = [&]() { ldv<fPinv, NX>(R, Pinv); };
       auto load_g3 = [&]() {
-        ldv<pC, NC>(PK, Cc_);
+        ldl<pC, NC>(Lp, Cc_);
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
           vy[sl] = ld2(R, sV + 2 * sl);
@@ -959,12 +1006,12 @@ struct MpcR16 {
         });
       };
       auto load_g4 = [&]() {
-        ldv<pK, NS>(PK, Hr);
+        ldl<pK, NS>(Lp, Hr);
         zr = ld2(R, sZ);
         bb = ld2(R, sZB);
       };
       auto load_g5 = [&]() {
-        ldv<pABr, NS>(PK, AB);
+        ldl<pABr, NS>(Lp, AB);
         if (i < N_) {
           lrn = ld2(R + kRec, sL);
           lbn = ld(R + kRec, sLB);
@@ -1062,6 +1109,7 @@ struct MpcR16 {
       dzn = rx ? dzu : 0.0;
       FB_STAMP_LAP(10);
     }
+    lds_off = loff;
     *trial_inner2 = row_reduce<OpSum16>(s_in);
     *trial_outer2 = row_reduce<OpSum16>(s_out);
     return true;
