@@ -331,17 +331,19 @@ struct Solver {
   }
 
   // The whole solve as ONE flat loop over "Newton iterations of this row", for
-  // policies that host several QPs per wavefront (fb_mpc_g16.h): every trip of
-  // the loop runs at most one Newton step, and the proximal-level bookkeeping
-  // (impl:158-216) and the fetch of the next QP happen inside the same loop
-  // under per-row predicates.  Rows of a wavefront therefore meet at every
-  // Newton step instead of waiting for each other at the end of each proximal
-  // subproblem and of each QP (nested loops reconverge at their exits).
+  // policies that host several QPs per wavefront (fb_mpc_r16.h).  Each trip of the
+  // outer loop first lets every row run the bookkeeping between two Newton
+  // steps as a small state machine - subproblem exit tests, the proximal-level
+  // passes (impl:158-216), finishing a QP and fetching the next - until the row
+  // stands in front of a Newton step (or the queue is empty), and then all rows
+  // take their Newton step and line search together.  Rows therefore never wait
+  // for each other at the end of a subproblem or of a QP (nested loops reconverge
+  // at their exits), and a row loses no Newton slot to its bookkeeping.
   // Same statements, same order per QP as solve()/subproblem_fused().
   // `next(p)` binds the policy to the next QP and returns its index or -1.
   template <class Next>
   FB_DEV void solve_stream(Next&& next, fbstab_solver_out_t* out_base) const {
-    enum { kFetch = 0, kProxTop = 1, kInner = 2 };
+    enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5 };
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -350,171 +352,185 @@ struct Solver {
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
     for (;;) {
-      if (phase == kFetch) {
-        const int q = next(p);
-        if (q < 0) break;
-        out = out_base + q;
-        combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
-        p.load_guess(c);
-        dx_norm = sqrt((double)p.num_primal_dual());
-        open_prox(sigma, &Ek, &Ei0);
-        E0 = Ek;
-        rk_last = Ek;
-        newton = 0;
-        prox = 0;
-        k = 0;
-        if (o.inner_tol_min > o.inner_tol_max) {
-          p.write_x(c);
-          finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
-          continue;  // phase stays kFetch
-        }
-        inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
-        phase = kProxTop;
-      }
-      if (phase == kProxTop) {
-        if (k >= o.max_prox_iters) {  // impl:219-223
-          p.write_x(c);
-          finish(out, FBSTAB_MAXITERATIONS, rk_last, newton, prox, E0);
-          phase = kFetch;
-          continue;
-        }
-        rk_last = Ek;
-        if (Ek <= combo_tol || dx_norm <= o.stall_tol) {
-          p.write_x(c);
-          finish(out, FBSTAB_SUCCESS, rk_last, newton, prox, E0);
-          phase = kFetch;
-          continue;
-        }
-        if (o.inner_tol_min > Ek) {
-          p.write_x(c);
-          finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
-          phase = kFetch;
-          continue;
-        }
-        inner_tol = sat(inner_tol * o.delta, o.inner_tol_min, Ek);
-        // SolveProximalSubproblem prologue (impl:233-243)
-        for (int m = 0; m < 5; m++) merit[m] = 0.0;
-        if constexpr (P::kOwnVectorOps) {
-          Ei = Ei0;
-          Eo = Ek;
-        } else {
-          norms_at(0.0, sigma, true, &Ei, &Eo);
-        }
-        Eo_top = Eo;
-        inner_i = 0;
-        phase = kInner;
-      }
-      // phase == kInner: top of one inner iteration (impl:237-260)
-      bool leave = inner_i >= o.max_inner_iters;
-      if (!leave) {
-        Eo_top = Eo;
-        rk_last = Eo;
-        leave = ((Ei <= inner_tol && Eo < Ek) || (Ei <= o.inner_tol_min)) ||
-                (newton >= o.max_newton_iters);
-      }
-      if (!leave) {
-        double ti2, to2;
-        if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2)) {
-          p.flush(c);
-          p.write_x(c);
-          finish(out, FBSTAB_DIVERGENCE, rk_last, newton, prox, E0);
-          phase = kFetch;
-          continue;
-        }
-        newton++;
-        const double cm = 0.5 * Ei * Ei;
-        merit[4] = merit[3];
-        merit[3] = merit[2];
-        merit[2] = merit[1];
-        merit[1] = merit[0];
-        merit[0] = cm;
-        double m0 = cm;
-        if (o.nonmonotone_linesearch) {
-          for (int m = 1; m < 5; m++) m0 = merit[m] > m0 ? merit[m] : m0;
-        }
-        double t = 1.0;
-        double Et = sqrt(ti2), Eot = sqrt(to2);
-        bool known = true;
-        constexpr int KT = 4;
-        double Em[KT], Eom[KT];
-        int have = 0, used = 0;
-        for (int j = 0; j < o.max_linesearch_iters; j++) {
-          if (j > 0) {
-            if (used == have) {
-              norms_at_multi<KT>(t, o.beta, sigma, Em, Eom);
-              have = KT;
-              used = 0;
-            }
-            Et = Em[0];
-            Eot = Eom[0];
-#pragma unroll
-            for (int m = 1; m < KT; m++) {
-              if (used == m) { Et = Em[m]; Eot = Eom[m]; }
-            }
-            used++;
-            known = true;
+      while (phase != kNewton && phase != kDone) {
+        if (phase == kFetch) {
+          const int q = next(p);
+          if (q < 0) {
+            phase = kDone;
+            continue;
           }
-          const double mp = 0.5 * Et * Et;
-          if (mp <= m0 - 2.0 * t * o.eta * cm) break;
-          t *= o.beta;
-          known = false;
-        }
-        if (!known) {
-          if (used < have) {
-            Et = Em[0];
-            Eot = Eom[0];
-#pragma unroll
-            for (int m = 1; m < KT; m++) {
-              if (used == m) { Et = Em[m]; Eot = Eom[m]; }
-            }
-          } else {
-            norms_at(t, sigma, true, &Et, &Eot);
-          }
-        }
-        p.pend_t = t;
-        Ei = Et;
-        Eo = Eot;
-        inner_i++;
-      } else {
-        // subproblem epilogue (impl:301-303) and the rest of the proximal
-        // iteration (impl:186-216)
-        int feas = kFeasible;
-        if constexpr (P::kOwnVectorOps) {
-          feas = close_subproblem(&dx_norm);
-        } else {
-          p.flush(c);
-          for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
-          c.sync();
-        }
-        const double Eo_ret = Eo_top;
-        if (newton >= o.max_newton_iters) {
-          if (Eo_ret < Ek) {
-            p.residual(c);
-            rk_last = pnr_norm();
+          out = out_base + q;
+          combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
+          p.load_guess(c);
+          dx_norm = sqrt((double)p.num_primal_dual());
+          open_prox(sigma, &Ek, &Ei0);
+          E0 = Ek;
+          rk_last = Ek;
+          newton = 0;
+          prox = 0;
+          k = 0;
+          if (o.inner_tol_min > o.inner_tol_max) {
             p.write_x(c);
-          } else {
-            rk_last = Ek;
-            p.write_xbar(c);
+            finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
+            continue;  // phase stays kFetch
           }
-          finish(out, FBSTAB_MAXITERATIONS, rk_last, newton, prox, E0);
-          phase = kFetch;
-          continue;
+          inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
+          phase = kProxTop;
+        } else if (phase == kProxTop) {
+          if (k >= o.max_prox_iters) {  // impl:219-223
+            p.write_x(c);
+            finish(out, FBSTAB_MAXITERATIONS, rk_last, newton, prox, E0);
+            phase = kFetch;
+            continue;
+          }
+          rk_last = Ek;
+          if (Ek <= combo_tol || dx_norm <= o.stall_tol) {
+            p.write_x(c);
+            finish(out, FBSTAB_SUCCESS, rk_last, newton, prox, E0);
+            phase = kFetch;
+            continue;
+          }
+          if (o.inner_tol_min > Ek) {
+            p.write_x(c);
+            finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
+            phase = kFetch;
+            continue;
+          }
+          inner_tol = sat(inner_tol * o.delta, o.inner_tol_min, Ek);
+          // SolveProximalSubproblem prologue (impl:233-243)
+          for (int m = 0; m < 5; m++) merit[m] = 0.0;
+          if constexpr (P::kOwnVectorOps) {
+            Ei = Ei0;
+            Eo = Ek;
+          } else {
+            norms_at(0.0, sigma, true, &Ei, &Eo);
+          }
+          Eo_top = Eo;
+          inner_i = 0;
+          phase = kInnerTop;
+        } else if (phase == kInnerTop) {
+          // top of one inner iteration (impl:237-260)
+          bool leave = inner_i >= o.max_inner_iters;
+          if (!leave) {
+            Eo_top = Eo;
+            rk_last = Eo;
+            leave = ((Ei <= inner_tol && Eo < Ek) || (Ei <= o.inner_tol_min)) ||
+                    (newton >= o.max_newton_iters);
+          }
+          phase = leave ? kEpilogue : kNewton;
+        } else {
+          // kEpilogue: subproblem epilogue (impl:301-303) and the rest of the
+          // proximal iteration (impl:186-216)
+          int feas = kFeasible;
+          if constexpr (P::kOwnVectorOps) {
+            feas = close_subproblem(&dx_norm);
+          } else {
+            p.flush(c);
+            for (int i = c.tid; i < p.nv; i += C::nt) p.v[i] = fmax0(p.v[i]);
+            c.sync();
+          }
+          const double Eo_ret = Eo_top;
+          if (newton >= o.max_newton_iters) {
+            if (Eo_ret < Ek) {
+              p.residual(c);
+              rk_last = pnr_norm();
+              p.write_x(c);
+            } else {
+              rk_last = Ek;
+              p.write_xbar(c);
+            }
+            finish(out, FBSTAB_MAXITERATIONS, rk_last, newton, prox, E0);
+            phase = kFetch;
+            continue;
+          }
+          if constexpr (!P::kOwnVectorOps) feas = close_subproblem(&dx_norm);
+          if (feas != kFeasible) {
+            const int eflag = feas == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
+                              : feas == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
+                                                        : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
+            p.write_certificate(c);
+            finish(out, eflag, rk_last, newton, prox, E0);
+            phase = kFetch;
+            continue;
+          }
+          prox++;
+          k++;
+          open_prox(sigma, &Ek, &Ei0);
+          phase = kProxTop;
         }
-        if constexpr (!P::kOwnVectorOps) feas = close_subproblem(&dx_norm);
-        if (feas != kFeasible) {
-          const int eflag = feas == kPrimalInfeasible ? FBSTAB_PRIMAL_INFEASIBLE
-                            : feas == kDualInfeasible ? FBSTAB_DUAL_INFEASIBLE
-                                                      : FBSTAB_PRIMAL_DUAL_INFEASIBLE;
-          p.write_certificate(c);
-          finish(out, eflag, rk_last, newton, prox, E0);
-          phase = kFetch;
-          continue;
-        }
-        prox++;
-        k++;
-        open_prox(sigma, &Ek, &Ei0);
-        phase = kProxTop;
       }
+      if (phase == kDone) break;
+      // ---- one Newton step and its line search (impl:262-298), all rows together
+      double ti2, to2;
+      if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2)) {
+        p.flush(c);
+        p.write_x(c);
+        finish(out, FBSTAB_DIVERGENCE, rk_last, newton, prox, E0);
+        phase = kFetch;
+        continue;
+      }
+      newton++;
+      const double cm = 0.5 * Ei * Ei;
+      merit[4] = merit[3];
+      merit[3] = merit[2];
+      merit[2] = merit[1];
+      merit[1] = merit[0];
+      merit[0] = cm;
+      double m0 = cm;
+      if (o.nonmonotone_linesearch) {
+        for (int m = 1; m < 5; m++) m0 = merit[m] > m0 ? merit[m] : m0;
+      }
+      double t = 1.0;
+      double Et = sqrt(ti2), Eot = sqrt(to2);
+      bool known = true;
+      constexpr int KT = 4;
+      double Em[KT], Eom[KT];
+      int have = 0, used = 0;
+      for (int j = 0; j < o.max_linesearch_iters; j++) {
+        if (j > 0) {
+          if (used == have) {
+            norms_at_multi<KT>(t, o.beta, sigma, Em, Eom);
+            have = KT;
+            used = 0;
+          }
+          Et = Em[0];
+          Eot = Eom[0];
+#pragma unroll
+          for (int m = 1; m < KT; m++) {
+            if (used == m) { Et = Em[m]; Eot = Eom[m]; }
+          }
+          used++;
+          known = true;
+        }
+        const double mp = 0.5 * Et * Et;
+        if (mp <= m0 - 2.0 * t * o.eta * cm) break;
+        t *= o.beta;
+        known = false;
+      }
+      if (!known) {
+        if (used < have) {
+          Et = Em[0];
+          Eot = Eom[0];
+#pragma unroll
+          for (int m = 1; m < KT; m++) {
+            if (used == m) { Et = Em[m]; Eot = Eom[m]; }
+          }
+        } else {
+          norms_at(t, sigma, true, &Et, &Eot);
+        }
+      }
+#if defined(FB_CLOCKSTAMP) && !defined(FB_HOSTSIM)
+      {  // histogram of backtracking depth (row level), diagnostic builds only
+        int depth = 0;
+        for (double tq = t; tq < 0.999; tq /= o.beta) depth++;
+        if (c.tid == 0) atomicAdd(&g_stamps[8 + (depth < 7 ? depth : 7)], 1ull);
+      }
+#endif
+      p.pend_t = t;
+      Ei = Et;
+      Eo = Eot;
+      inner_i++;
+      phase = kInnerTop;
     }
   }
 

@@ -57,6 +57,29 @@ struct StampClock {
 #define FB_STAMP_COUNT(k)
 #endif
 
+// Wave-level event counters of the light diagnostic build (-DFB_CLOCKSTAMP).
+#if (defined(FB_STAMP) || defined(FB_CLOCKSTAMP)) && !defined(FB_HOSTSIM)
+#if !defined(FB_STAMP)
+extern __device__ unsigned long long g_stamps[32];
+#endif
+#define FB_WAVE_COUNT(k) do { if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_read_exec())) atomicAdd(&g_stamps[k], 1ull); } while (0)
+// Shader cycles the wavefront spends inside a scope (first active lane reports).
+struct WaveTimer {
+  int k;
+  long long t0;
+  __device__ __forceinline__ explicit WaveTimer(int k_) : k(k_), t0(__builtin_readcyclecounter()) {}
+  __device__ __forceinline__ ~WaveTimer() {
+    const long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_read_exec()))
+      atomicAdd(&g_stamps[k], (unsigned long long)(t1 - t0));
+  }
+};
+#define FB_WAVE_TIMER(k) WaveTimer fb_wave_timer_##k(k)
+#else
+#define FB_WAVE_COUNT(k)
+#define FB_WAVE_TIMER(k)
+#endif
+
 // Maximum number of values reduced together by one block_reduce call.
 constexpr int kMaxReduce = 12;
 

@@ -247,6 +247,7 @@ struct MpcR16 {
   // x <- caller's guess, y = b - A z (impl:334-347, full_variable.cc:47-53), and
   // the one-off copies of the problem data into the records.
   FB_DEV void load_guess(const C& c) {
+    FB_WAVE_TIMER(19);
     const int r = c.tid, N_ = N;
     const bool rx = r < NX, rs_ = r < NS;
     const int ru = r - NX;
@@ -261,6 +262,10 @@ struct MpcR16 {
     double* const P0 = pack;
     int* const po = poff;
     int canon = 0;  // offset of the copy the previous stage uses (row-uniform)
+    double lastKr[16], lastABr[16], lastCc[NC], lastABc[NX];  // that copy's values, this lane's share
+    sfor<0, 16>([&](auto Cc_) { lastKr[decltype(Cc_)::value] = lastABr[decltype(Cc_)::value] = 0.0; });
+    sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = 0.0; });
+    sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = 0.0; });
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
       double* PK = P0 + (long)i * kPack;
@@ -291,29 +296,30 @@ struct MpcR16 {
                                : B + (long)i * NX * NU + (long)(rs_ ? ru : 0) * NX;
         sfor<0, NX>([&](auto J) { ABc[decltype(J)::value] = (rs_ && has_ab) ? src[decltype(J)::value] : 0.0; });
       }
-      stv<pK, 16>(PK, Kr);
-      stv<pABr, 16>(PK, ABr);
-      stv<pC, NC>(PK, Cc);
-      stv<pABc, NX>(PK, ABc);
-      if (i > 0) {
-        // bitwise comparison with the copy the previous stage uses
-        const double* PC = P0 + canon;
-        double K0[16], AB0[16], C0[NC], Ac0[NX];
-        ldv<pK, 16>(PC, K0);
-        ldv<pABr, 16>(PC, AB0);
-        ldv<pC, NC>(PC, C0);
-        ldv<pABc, NX>(PC, Ac0);
-        bool differs = false;
-        sfor<0, 16>([&](auto Cc_) {
-          constexpr int cc = decltype(Cc_)::value;
-          differs = differs || !(Kr[cc] == K0[cc]) || !(ABr[cc] == AB0[cc]);
-        });
-        sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == C0[decltype(Kk)::value]); });
-        sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == Ac0[decltype(J)::value]); });
+      // A stage whose matrices equal (bitwise) those of the previous stage
+      // shares its copy: nothing is written for it.
+      bool differs = i == 0;
+      sfor<0, 16>([&](auto Cc_) {
+        constexpr int cc = decltype(Cc_)::value;
+        differs = differs || !(Kr[cc] == lastKr[cc]) || !(ABr[cc] == lastABr[cc]);
+      });
+      sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == lastCc[decltype(Kk)::value]); });
+      sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == lastABc[decltype(J)::value]); });
 #if defined(FB_R16_NO_SHARED_PACK)
-        differs = true;
+      differs = true;
 #endif
-        if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) canon = i * kPack;
+      if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) {
+        canon = i * kPack;
+        stv<pK, 16>(PK, Kr);
+        stv<pABr, 16>(PK, ABr);
+        stv<pC, NC>(PK, Cc);
+        stv<pABc, NX>(PK, ABc);
+        sfor<0, 16>([&](auto Cc_) {
+          lastKr[decltype(Cc_)::value] = Kr[decltype(Cc_)::value];
+          lastABr[decltype(Cc_)::value] = ABr[decltype(Cc_)::value];
+        });
+        sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
+        sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = ABc[decltype(J)::value]; });
       }
       po[i] = canon;  // every lane: each later reads its own store
       lds_off = -1;
@@ -419,9 +425,31 @@ struct MpcR16 {
 
   // (Ei, Eo) at x + t dx for the K step lengths t0 beta^k in one pass
   // (full_residual.cc:49-74 and :99-109).  A pending step is applied first.
+  // The light passes below are bound by load latency, not arithmetic: each keeps
+  // the loads of stage i+1 in flight while stage i is processed.
+  struct TrialIn {
+    dbl2 zr, bb, dw, lr, dwl;
+    dbl2 vy[KS], da[KS];
+    double vb[KS];
+  };
+  static FB_DEV void load_trial(const double* R, TrialIn& in) {
+    in.zr = ld2(R, sZ);
+    in.bb = ld2(R, sZB);
+    in.dw = ld2(R, sDZ);
+    in.lr = ld2(R, sL);
+    in.dwl = ld2(R, sDL);
+    sfor<0, KS>([&](auto S_) {
+      constexpr int sl = decltype(S_)::value;
+      in.vy[sl] = ld2(R, sV + 2 * sl);
+      in.da[sl] = ld2(R, sDV + 2 * sl);
+      in.vb[sl] = ld(R, sVB + 2 * sl);
+    });
+  }
   template <int K>
   FB_DEV void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
                              double (&Ei)[K], double (&Eo)[K]) {
+    FB_WAVE_COUNT(24);
+    FB_WAVE_TIMER(23);
     flush(c);
     const int N_ = N;
     const double* const R0 = rec;
@@ -429,15 +457,17 @@ struct MpcR16 {
     tt[0] = t0;
     sfor<1, K>([&](auto Kk) { tt[decltype(Kk)::value] = tt[decltype(Kk)::value - 1] * beta; });
     sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
+    TrialIn in;
+    load_trial(R0, in);
     for (int i = 0; i <= N_; i++) {
-      const double* R = R0 + (long)i * kRec;
-      const dbl2 zr = ld2(R, sZ), bb = ld2(R, sZB), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+      const TrialIn cu = in;
+      if (i < N_) load_trial(R0 + (long)(i + 1) * kRec, in);
       sfor<0, K>([&](auto Kk) {
         constexpr int k = decltype(Kk)::value;
-        const double rzt = fma(tt[k], dw[1], zr[1]);
-        const double rzi = rzt + sigma * (fma(tt[k], dw[0], zr[0]) - bb[0]);
-        const double rlt = fma(tt[k], dwl[1], lr[1]);
-        const double rli = rlt + sigma * (fma(tt[k], dwl[0], lr[0]) - bb[1]);
+        const double rzt = fma(tt[k], cu.dw[1], cu.zr[1]);
+        const double rzi = rzt + sigma * (fma(tt[k], cu.dw[0], cu.zr[0]) - cu.bb[0]);
+        const double rlt = fma(tt[k], cu.dwl[1], cu.lr[1]);
+        const double rli = rlt + sigma * (fma(tt[k], cu.dwl[0], cu.lr[0]) - cu.bb[1]);
         s[k] = fma(rzi, rzi, s[k]);
         s[k] = fma(rli, rli, s[k]);
         s[K + k] = fma(rzt, rzt, s[K + k]);
@@ -445,13 +475,11 @@ struct MpcR16 {
       });
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        const dbl2 vy = ld2(R, sV + 2 * sl), da = ld2(R, sDV + 2 * sl);
-        const double vb = ld(R, sVB + 2 * sl);
         sfor<0, K>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          const double vi = fma(tt[k], da[0], vy[0]);
-          const double yi = fma(-tt[k], da[1], vy[1]);
-          const double ys = yi + sigma * (vi - vb);
+          const double vi = fma(tt[k], cu.da[sl][0], cu.vy[sl][0]);
+          const double yi = fma(-tt[k], cu.da[sl][1], cu.vy[sl][1]);
+          const double ys = yi + sigma * (vi - cu.vb[sl]);
           const double ph = pfb(ys, vi, alpha);
           const double pn = pnr(yi, vi, alpha);
           s[k] = fma(ph, ph, s[k]);
@@ -509,6 +537,8 @@ struct MpcR16 {
     return o;
   }
   FB_DEV int close_subproblem(const C& c, double tol, bool check, double* dx_norm) {
+    FB_WAVE_COUNT(26);
+    FB_WAVE_TIMER(21);
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
     const double t = pend_t;
@@ -520,19 +550,39 @@ struct MpcR16 {
     lds_ptr Cl = lds + kPackLds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
     double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
-    ZL cur = stepped_zl(R0, t);
-    for (int i = 0; i <= N_; i++) {
-      double* R = R0 + (long)i * kRec;
-      ZL nxt;
-      nxt.z = nxt.rz = nxt.l = nxt.rl = nxt.dz = nxt.dl = 0.0;
-      if (i < N_) nxt = stepped_zl(R + kRec, t);
+    struct VIn {
       dbl2 vy[KS], da[KS], vb[KS];
+      dbl2 fh;
+      double bs[KS], ABc[NX];
+    };
+    auto load_v = [&](int i, VIn& in) {
+      const double* R = R0 + (long)i * kRec;
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        vy[sl] = ld2(R, sV + 2 * sl);
-        da[sl] = ld2(R, sDV + 2 * sl);
-        vb[sl] = ld2(R, sVB + 2 * sl);
+        in.vy[sl] = ld2(R, sV + 2 * sl);
+        in.da[sl] = ld2(R, sDV + 2 * sl);
+        in.vb[sl] = ld2(R, sVB + 2 * sl);
       });
+      if (check) {
+        in.fh = ld2(R, sF);
+        sfor<0, KS>([&](auto S_) { in.bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value); });
+        ldv<pABc, NX>(P0 + po[i], in.ABc);
+      }
+    };
+    ZL cur = stepped_zl(R0, t);
+    ZL nxt = cur;
+    if (N_ > 0) nxt = stepped_zl(R0 + kRec, t);
+    VIn vin;
+    load_v(0, vin);
+    for (int i = 0; i <= N_; i++) {
+      double* R = R0 + (long)i * kRec;
+      // (z, l) of stage i+2 and the v group of stage i+1, in flight during this stage
+      ZL nn;
+      nn.z = nn.rz = nn.l = nn.rl = nn.dz = nn.dl = 0.0;
+      if (i + 2 <= N_) nn = stepped_zl(R + 2 * kRec, t);
+      const VIn vc = vin;
+      if (i < N_) load_v(i + 1, vin);
+      if (i == N_) nxt.z = nxt.rz = nxt.l = nxt.rl = nxt.dz = nxt.dl = 0.0;
       st2(R, sZ, cur.z, cur.rz);
       st2(R, sL, cur.l, cur.rl);
       st2(R, sDZ, cur.dz, 0.0);
@@ -542,24 +592,22 @@ struct MpcR16 {
       double dvs[KS];
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        const double vv = fmax0(fma(t, da[sl][0], vy[sl][0]));
-        const double yy = fma(-t, da[sl][1], vy[sl][1]);
-        dvs[sl] = vv - vb[sl][0];
+        const double vv = fmax0(fma(t, vc.da[sl][0], vc.vy[sl][0]));
+        const double yy = fma(-t, vc.da[sl][1], vc.vy[sl][1]);
+        dvs[sl] = vv - vc.vb[sl][0];
         st2(R, sV + 2 * sl, vv, yy);
         st2(R, sDV + 2 * sl, dvs[sl], 0.0);
         s_dx = fma(dvs[sl], dvs[sl], s_dx);
       });
       if (check) {
-        const int pofs = po[i];
-        stage_pack(c, pofs);
-        double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+        stage_pack(c, po[i]);
+        double Kr[NS], Cc[NC], ABr[NS];
         ldl<pK, NS>(Lp, Kr);
         ldl<pC, NC>(Lp, Cc);
         ldl<pABr, NS>(Lp, ABr);
-        ldv<pABc, NX>(P0 + pofs, ABc);
-        const dbl2 fh = ld2(R, sF);
-        double bs[KS];
-        sfor<0, KS>([&](auto S_) { bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value); });
+        const dbl2 fh = vc.fh;
+        const double (&bs)[KS] = vc.bs;
+        const double (&ABc)[NX] = vc.ABc;
         double dzb[NS], dlnb[NX];
         bc_all<NS>(cur.dz, dzb);
         bc_all<NX>(nxt.dl, dlnb);
@@ -592,6 +640,7 @@ struct MpcR16 {
         });
       }
       cur = nxt;
+      nxt = nn;
     }
     c.sync();
     *dx_norm = sqrt(row_reduce<OpSum16>(s_dx));
@@ -616,6 +665,8 @@ struct MpcR16 {
   //   Ei0 = ||(rz, rl, pfb(y, v))||, the inner residual norm at x = xbar, where
   //         the sigma terms vanish identically      (impl:239-243)
   FB_DEV void open_prox(const C& c, double sigma, double alpha, double* Ek, double* Ei0) {
+    FB_WAVE_COUNT(25);
+    FB_WAVE_TIMER(22);
     (void)sigma;
     const int r = c.tid, N_ = N;
     const bool rx = r < NX;
@@ -624,26 +675,41 @@ struct MpcR16 {
     const int* const po = poff;
     lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
     double s_nat = 0.0, s_vo = 0.0, s_vi = 0.0;
+    struct OIn {
+      dbl2 fh, vy[KS];
+      double zn, ln, hn;  // z, l, h of the following stage
+      double ABc[NX];
+    };
+    auto load_o = [&](int i, OIn& in) {
+      const double* R = R0 + (long)i * kRec;
+      in.fh = ld2(R, sF);
+      sfor<0, KS>([&](auto S_) { in.vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
+      in.zn = in.ln = in.hn = 0.0;
+      if (i < N_) {
+        in.zn = ld(R + kRec, sZ);
+        in.ln = ld(R + kRec, sL);
+        in.hn = ld(R + kRec, sH);
+      }
+      ldv<pABc, NX>(P0 + po[i], in.ABc);
+    };
     dbl2 zl = {ld(R0, sZ), ld(R0, sL)};  // (z, l) of stage i, handed on
+    OIn oin;
+    load_o(0, oin);
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      const int pofs = po[i];
-      stage_pack(c, pofs);
-      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+      const OIn oc = oin;
+      if (i < N_) load_o(i + 1, oin);
+      stage_pack(c, po[i]);
+      double Kr[NS], Cc[NC], ABr[NS];
       ldl<pK, NS>(Lp, Kr);
       ldl<pC, NC>(Lp, Cc);
       ldl<pABr, NS>(Lp, ABr);
-      ldv<pABc, NX>(P0 + pofs, ABc);
-      const dbl2 fh = ld2(R, sF);
+      const double (&ABc)[NX] = oc.ABc;
+      const dbl2 fh = oc.fh;
       dbl2 vy[KS];
-      sfor<0, KS>([&](auto S_) { vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
-      dbl2 zln = {0.0, 0.0};
-      double hn = 0.0;
-      if (i < N_) {
-        zln[0] = ld(R + kRec, sZ);
-        zln[1] = ld(R + kRec, sL);
-        hn = ld(R + kRec, sH);
-      }
+      sfor<0, KS>([&](auto S_) { vy[decltype(S_)::value] = oc.vy[decltype(S_)::value]; });
+      const dbl2 zln = {oc.zn, oc.ln};
+      const double hn = oc.hn;
       const double zz = zl[0], ll = zl[1];
       st2(R, sZB, zz, ll);
       double zb[NS], lnb[NX];
@@ -799,6 +865,8 @@ struct MpcR16 {
 
   FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
                           double* trial_outer2) {
+    FB_WAVE_COUNT(27);  // Newton steps executed by the wavefront (any row active)
+    FB_WAVE_TIMER(20);
     // Locals only below: lambdas must not capture `this`.
     const int N_ = N;
     const int r = c.tid;

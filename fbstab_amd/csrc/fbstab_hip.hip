@@ -21,8 +21,9 @@
 #include "fb_mpc_g16.h"
 #include "fb_mpc_r16.h"
 
-#if defined(FB_STAMP)
+#if defined(FB_STAMP) || defined(FB_CLOCKSTAMP)
 namespace fbk { __device__ unsigned long long g_stamps[32]; }
+#define FB_ANY_STAMP 1
 #endif
 
 namespace {
@@ -212,8 +213,9 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
 // Build knobs (measured on the BASELINE workload):
 //   FB_R16_MIN_WAVES  1: 512 registers per wave, loads prefetched a stage ahead
 //                     2: two waves per SIMD, loads at the point of use
-//   FB_R16_FLAT       rows never wait for each other (solve_stream) instead of
-//                     the four rows of a wavefront running solve() in step
+//   FB_R16_NESTED     the four rows of a wavefront run solve() in step instead of
+//                     the per-row state machine of solve_stream (rows never wait
+//                     for each other; +11 % QP/s with two batches in flight)
 #ifndef FB_R16_MIN_WAVES
 #define FB_R16_MIN_WAVES 1
 #endif
@@ -225,6 +227,9 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     int* counter, int batch, int N, double* dbg) {
   typedef MpcR16<NX, NU, NC> P;
   extern __shared__ __attribute__((aligned(16))) double smem[];
+#if defined(FB_ANY_STAMP)
+  const long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+#endif
   const int lane = threadIdx.x, row = lane >> 4;
   Ctx16 ctx;
   ctx.tid = lane & 15;
@@ -244,16 +249,23 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
     Solver<P, Ctx16> solver(p, ctx, opts);
-#ifdef FB_R16_FLAT
-    solver.solve_stream(next, out);
-#else
+#ifdef FB_R16_NESTED
     for (;;) {
       const int q = next(p);
       if (q < 0) break;
       solver.solve(out + q);
     }
+#else
+    solver.solve_stream(next, out);
 #endif
   }
+#if defined(FB_ANY_STAMP)
+  // shader clock actually delivered to this wavefront: s_memtime vs the 100 MHz counter
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_stamps[28], (unsigned long long)(__builtin_readcyclecounter() - clk0));
+    atomicAdd(&g_stamps[29], (unsigned long long)(wall_clock64() - rt0));
+  }
+#endif
 }
 
 template <int NT>
@@ -696,7 +708,7 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
 int fbstab_hip_debug_stamps(unsigned long long* out32, int reset) {
   if (!out32) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
   memset(out32, 0, 32 * sizeof(unsigned long long));
-#if defined(FB_STAMP)
+#if defined(FB_ANY_STAMP)
   HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(fbk::g_stamps), 32 * sizeof(unsigned long long)));
   if (reset) {
     unsigned long long z[32] = {0};

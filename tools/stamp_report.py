@@ -36,3 +36,20 @@ for k in sorted(names):
     per = st[k] / stages if k < 16 else st[k] / newton
     unit = "cyc/stage" if k < 16 else "cyc/newton-iter"
     print(f"   [{k:2d}] {names[k]:22s} {per:12.0f} {unit}")
+
+if st[27]:
+    useful = int(out["newton_iters"].sum())
+    print(f"wave-level calls: newton_step {st[27]} (useful row-steps {useful}, packing {useful / (4.0 * st[27]):.2f}), "
+          f"close_subproblem {st[26]}, open_prox {st[25]}")
+if sum(st[8:16]):
+    h = [int(x) for x in st[8:16]]
+    print("   backtracking depth histogram (row level, 0 = full step ... 7+):", h, f"mean {sum(i * x for i, x in enumerate(h)) / max(sum(h), 1):.2f}")
+if st[20]:
+    tot = float(st[28])
+    for k, nm, cnt in ((20, "newton_step", st[27]), (21, "close_subproblem", st[26]), (22, "open_prox", st[25]),
+                       (23, "norms_at_multi", st[24]), (19, "load_guess", 0)):
+        per = f"{st[k] / cnt:10.0f} cyc/call x {cnt}" if cnt else ""
+        print(f"   wave cycles in {nm:18s} {100.0 * st[k] / tot:5.1f} %  {per}")
+if st[29]:
+    print(f"mean shader clock over the wavefronts' lifetimes: {st[28] / (st[29] * 0.01):.0f} MHz "
+          f"(sum of wave lifetimes {st[29] * 1e-5:.1f} ms)")
