@@ -110,7 +110,16 @@ struct MpcR16 {
   //                   buffer (forward sweep); odd strides.
   static constexpr int CS = NC | 1, TS = 17;
   static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
-  static constexpr int kPackLds = 16 * kPackLdsSlots;
+#if defined(FB_R16_PACK_GLOBAL)
+  // (build knob for the two-waves-per-SIMD experiments: the copy stays in
+  // global memory / L2 and LDS holds the transposes only, 11.5 KB per wavefront)
+  static constexpr bool kPackInLds = false;
+#else
+  static constexpr bool kPackInLds = true;
+#endif
+  static constexpr int kPackLds = kPackInLds ? 16 * kPackLdsSlots : 0;
+  // this lane's view of the matrix copy in use
+  typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
   static constexpr int kLdsDoubles = kPackLds + 16 * (CS > TS ? CS : TS);
   static constexpr int kLdsPerRow = ((kLdsDoubles + 31) & ~31) + 16;
 
@@ -176,10 +185,20 @@ struct MpcR16 {
   }
 
   // Makes the matrix copy at offset `off` the one resident in LDS (row-uniform).
-  FB_DEV void stage_pack(const C& c, int off) { stage_pack_s(c, pack, lds + 2 * c.tid, lds_off, off); }
-  static FB_DEV void stage_pack_s(const C& c, const double* pack0, lds_ptr dst, int& cur, int off) {
+  template <bool L = kPackInLds>
+  FB_DEV auto pack_view(const C& c) const {
+    if constexpr (L) return lds + 2 * c.tid;
+    else return static_cast<const double*>(pack);
+  }
+  FB_DEV void stage_pack(const C& c, pk_ptr& view, int off) { stage_pack_s(c, pack, view, lds_off, off); }
+  static FB_DEV void stage_pack_s(const C&, const double* pack0, const double*& view, int& cur, int off) {
+    view = pack0 + off;
+    cur = off;
+  }
+  static FB_DEV void stage_pack_s(const C& c, const double* pack0, lds_ptr& view, int& cur, int off) {
     if (off == cur) return;
     cur = off;
+    lds_ptr dst = view;
     const double* src = pack0 + off;
     c.sync();  // earlier readers of the previous copy
     constexpr int kPairs = kPackLdsSlots / 2, kChunk = 13;
@@ -195,6 +214,10 @@ struct MpcR16 {
     c.sync();
   }
   // slots [S0, S0 + CNT) of the LDS-resident copy into out[0..CNT)
+  template <int S0, int CNT, int NOUT>
+  static FB_DEV void ldl(const double* G, double (&out)[NOUT]) {
+    ldv<S0, CNT>(G, out);
+  }
   template <int S0, int CNT, int NOUT>
   static FB_DEV void ldl(lds_ptr L, double (&out)[NOUT]) {
     static_assert((S0 & 1) == 0 && S0 + CNT <= kPackLdsSlots, "inside the LDS image, on a pair");
@@ -358,11 +381,11 @@ struct MpcR16 {
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
-    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
+    pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
       const int pofs = po[i];
-      stage_pack(c, pofs);
+      stage_pack(c, Lp, pofs);
       double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
       ldl<pK, NS>(Lp, Kr);
       ldl<pC, NC>(Lp, Cc);
@@ -546,7 +569,7 @@ struct MpcR16 {
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
-    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
+    pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     lds_ptr Cl = lds + kPackLds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
     double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
@@ -600,7 +623,7 @@ struct MpcR16 {
         s_dx = fma(dvs[sl], dvs[sl], s_dx);
       });
       if (check) {
-        stage_pack(c, po[i]);
+        stage_pack(c, Lp, po[i]);
         double Kr[NS], Cc[NC], ABr[NS];
         ldl<pK, NS>(Lp, Kr);
         ldl<pC, NC>(Lp, Cc);
@@ -673,7 +696,7 @@ struct MpcR16 {
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
-    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
+    pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     double s_nat = 0.0, s_vo = 0.0, s_vi = 0.0;
     struct OIn {
       dbl2 fh, vy[KS];
@@ -699,7 +722,7 @@ struct MpcR16 {
       double* R = R0 + (long)i * kRec;
       const OIn oc = oin;
       if (i < N_) load_o(i + 1, oin);
-      stage_pack(c, po[i]);
+      stage_pack(c, Lp, po[i]);
       double Kr[NS], Cc[NC], ABr[NS];
       ldl<pK, NS>(Lp, Kr);
       ldl<pC, NC>(Lp, Cc);
@@ -873,7 +896,7 @@ struct MpcR16 {
     double* const R0 = rec;
     const double* const P0 = pack;
     const int* const po = poff;
-    lds_ptr Lp = lds + 2 * c.tid;  // this lane's view of the LDS-resident matrix copy
+    pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     lds_ptr Tr = lds + kPackLds;
     lds_ptr Cl = lds + kPackLds;
     const bool rx = r < NX;
