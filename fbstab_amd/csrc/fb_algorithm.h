@@ -56,6 +56,7 @@ struct Solver {
   // (Ei, Eo) at x + t*dx for the proximal subproblem centred at xbar
   // (full_residual.cc:49-74 and :99-109).  t == 0 never touches dx/W.
   FB_DEV void norms_at(double t, double sigma, bool want_outer, double* Ei, double* Eo) const {
+    FB_WAVE_TIMER(17);
     if constexpr (P::kOwnVectorOps) {
       double e[1], f[1];
       p.template norms_at_multi<1>(c, t, 1.0, sigma, o.alpha, e, f);
@@ -164,6 +165,7 @@ struct Solver {
   // x <- x + t*dx and the matching residual update (impl:298,
   // full_variable.cc:55-65: y += t*(dy - b) with dy = b - A dz).
   FB_DEV void accept(double t) const {
+    FB_WAVE_TIMER(18);
     for (int i = c.tid; i < p.nz; i += C::nt) {
       p.z[i] += t * p.dz[i];
       p.rz[i] += t * p.wz[i];

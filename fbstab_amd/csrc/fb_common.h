@@ -75,7 +75,21 @@ struct WaveTimer {
   }
 };
 #define FB_WAVE_TIMER(k) WaveTimer fb_wave_timer_##k(k)
+struct WaveLap {
+  long long t0;
+  __device__ __forceinline__ WaveLap() : t0(__builtin_readcyclecounter()) {}
+  __device__ __forceinline__ void lap(int k) {
+    const long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_read_exec()))
+      atomicAdd(&g_stamps[k], (unsigned long long)(t1 - t0));
+    t0 = __builtin_readcyclecounter();
+  }
+};
+#define FB_WAVE_LAP_DECL WaveLap fb_wave_lap_
+#define FB_WAVE_LAP(k) fb_wave_lap_.lap(k)
 #else
+#define FB_WAVE_LAP_DECL
+#define FB_WAVE_LAP(k)
 #define FB_WAVE_COUNT(k)
 #define FB_WAVE_TIMER(k)
 #endif

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, Dense
                                                           fbstab_options_t opts, int* counter,
                                                           int batch) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  FB_WAVE_TIMER(28);  // total wave cycles (diagnostic builds)
   lds_ptr lds = (lds_ptr)smem;
   typedef Ctx<NT> C;
   C ctx;
