@@ -163,18 +163,45 @@ struct Ctx {
   }
   // argmax with ties resolved to the SMALLEST index (Eigen's maxCoeff(&index)
   // returns the first maximum): one pass over (value, index) pairs.
+  // (value, index) of the better of two candidates: larger value, then smaller index
+  static FB_DEV void better(double& v, int& ix, double ov, int oi) {
+    const bool take = (ov > v) || (ov == v && oi < ix);
+    v = take ? ov : v;
+    ix = take ? oi : ix;
+  }
+#if !defined(FB_HOSTSIM)
+  template <int CTRL>
+  static FB_DEV void better_dpp(double& v, int& ix) {
+    const double ov = __builtin_amdgcn_update_dpp(0.0, v, CTRL, 0xf, 0xf, true);
+    const int oi = __builtin_amdgcn_update_dpp(0, ix, CTRL, 0xf, 0xf, true);
+    better(v, ix, ov, oi);
+  }
+  // Wave-wide argmax without LDS shuffles: rotations inside the 16-lane rows
+  // (DPP), then the four row results through v_readlane.  Every lane returns
+  // the same pair.
+  static FB_DEV void wave_argmax_first(double& v, int& ix) {
+    better_dpp<0x128>(v, ix);  // row_ror:8
+    better_dpp<0x124>(v, ix);  // row_ror:4
+    better_dpp<0x122>(v, ix);  // row_ror:2
+    better_dpp<0x121>(v, ix);  // row_ror:1
+    double bv = v;
+    int bi = ix;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+      const double ov = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * row),
+                                         __builtin_amdgcn_readlane(__double2loint(v), 16 * row));
+      const int oi = __builtin_amdgcn_readlane(ix, 16 * row);
+      if (row == 0) { bv = ov; bi = oi; } else better(bv, bi, ov, oi);
+    }
+    v = bv;
+    ix = bi;
+  }
+#endif
   FB_DEV void argmax_first(double* val, int* idx) const {
 #if !defined(FB_HOSTSIM)
     double v = *val;
     int ix = *idx;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const double ov = __shfl_xor(v, m, 64);
-      const int oi = __shfl_xor(ix, m, 64);
-      const bool take = (ov > v) || (ov == v && oi < ix);
-      v = take ? ov : v;
-      ix = take ? oi : ix;
-    }
+    wave_argmax_first(v, ix);
     if (NT > 64) {
       const int wave = tid >> 6;
       const int nw = NT / 64;

@@ -380,8 +380,22 @@ struct DenseProblem {
         const double a = fabs(K[i + i * n]);
         if (a > best) { best = a; p = i; }  // i ascending: first maximum kept
       }
-      c.argmax_first(&best, &p);
-      if (c.tid == 0) perm[k] = p;
+#if !defined(FB_HOSTSIM)
+      if (W::nt > 64 && n - k <= 64) {
+        // every candidate sits in the first wavefront: it decides, the others
+        // read the result after the barrier below
+        if (c.tid < 64) {
+          W::wave_argmax_first(best, p);
+          if (c.tid == 0) perm[k] = p;
+        }
+        c.sync();
+        p = perm[k];
+      } else
+#endif
+      {
+        c.argmax_first(&best, &p);
+        if (c.tid == 0) perm[k] = p;
+      }
       if (p != k) {
         c.sync();
         const int s = n - p - 1;
