@@ -133,12 +133,22 @@ struct MpcR16 {
   const VarBatchPtrs* var;
   long q;  // QP index
   int N;
+  // The problem's own sizes, nx <= NX, nu <= NU, nc <= NC: a smaller problem runs
+  // zero-padded (states in lanes [0, nx), inputs in lanes [NX, NX + nu),
+  // constraints k < nc).  Padded rows and columns are exact zeros everywhere;
+  // their pivots are sigma (+ 1/sigma), their steps are zero, and only the passes
+  // that touch the caller's arrays (load_guess, write_out, forcing_norm, the
+  // test probe) know about it.
+  int nx, nu, nc;
   // Step length of an accepted but not yet applied Newton step (0 = none); the
   // next forward sweep applies it stage by stage, everything else flushes first.
   double pend_t;
 
   FB_DEV void bind(double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d, const VarBatchPtrs* x,
-                   long q_, int N_, int lane16) {
+                   long q_, int N_, int nx_, int nu_, int nc_, int lane16) {
+    nx = nx_;
+    nu = nu_;
+    nc = nc_;
     lds_off = -1;
     poff = reinterpret_cast<int*>(ws_row);
     pack = ws_row + hdr_doubles(N_) + 2 * lane16;
@@ -150,7 +160,7 @@ struct MpcR16 {
     N = N_;
     pend_t = 0.0;
   }
-  FB_DEV int num_primal_dual() const { return (N + 1) * (NS + NX + NC); }
+  FB_DEV int num_primal_dual() const { return (N + 1) * (2 * nx + nu + nc); }
 
   // ---- record access -------------------------------------------------------------
   static FB_DEV double ld(const double* R, int slot) { return R[off(slot)]; }
@@ -259,11 +269,12 @@ struct MpcR16 {
     const double *pq = arr(FBSTAB_MPC_q), *pr = arr(FBSTAB_MPC_r), *pd = arr(FBSTAB_MPC_d),
                  *px0 = arr(FBSTAB_MPC_x0), *pc = arr(FBSTAB_MPC_c);
     double s = 0.0;
-    for (int i = c.tid; i < (N_ + 1) * NX; i += 16) s += pq[i] * pq[i];
-    for (int i = c.tid; i < (N_ + 1) * NU; i += 16) s += pr[i] * pr[i];
-    for (int i = c.tid; i < (N_ + 1) * NC; i += 16) s += pd[i] * pd[i];
-    for (int i = c.tid; i < NX; i += 16) s += px0[i] * px0[i];
-    for (int i = c.tid; i < N_ * NX; i += 16) s += pc[i] * pc[i];
+    const int nx_ = nx, nu_ = nu, nc_ = nc;
+    for (int i = c.tid; i < (N_ + 1) * nx_; i += 16) s += pq[i] * pq[i];
+    for (int i = c.tid; i < (N_ + 1) * nu_; i += 16) s += pr[i] * pr[i];
+    for (int i = c.tid; i < (N_ + 1) * nc_; i += 16) s += pd[i] * pd[i];
+    for (int i = c.tid; i < nx_; i += 16) s += px0[i] * px0[i];
+    for (int i = c.tid; i < N_ * nx_; i += 16) s += pc[i] * pc[i];
     return sqrt(row_reduce<OpSum16>(s));
   }
 
@@ -272,8 +283,11 @@ struct MpcR16 {
   FB_DEV void load_guess(const C& c) {
     FB_WAVE_TIMER(19);
     const int r = c.tid, N_ = N;
-    const bool rx = r < NX, rs_ = r < NS;
+    const int nx_ = nx, nu_ = nu, nc_ = nc;
     const int ru = r - NX;
+    const bool rx = r < nx_;                   // lane holds a real state row
+    const bool rin = r >= NX && ru < nu_;      // lane holds a real input row
+    const bool rs_ = rx || rin;
     double* const R0 = rec;
     lds_ptr Cl = lds + kPackLds;
     const double *Q = arr(FBSTAB_MPC_Q), *Rm = arr(FBSTAB_MPC_R), *S = arr(FBSTAB_MPC_S),
@@ -293,31 +307,41 @@ struct MpcR16 {
       double* R = R0 + (long)i * kRec;
       double* PK = P0 + (long)i * kPack;
       const bool has_ab = i < N_;
-      // matrices
+      // matrices (the caller's arrays have the problem's own strides nx, nu, nc)
       double Kr[16], ABr[16], Cc[NC], ABc[NX];
       sfor<0, 16>([&](auto Cc_) {
         constexpr int cc = decltype(Cc_)::value;
         double kv = 0.0, ab = 0.0;
         if constexpr (cc < NX) {
-          if (rx) kv = Q[(long)i * NX * NX + r + cc * NX];
-          else if (rs_) kv = S[(long)i * NU * NX + ru + cc * NU];
-          if (rx && has_ab) ab = A[(long)i * NX * NX + r + cc * NX];
+          if (cc < nx_) {  // a real state column
+            if (rx) kv = Q[(long)i * nx_ * nx_ + r + cc * nx_];
+            else if (rin) kv = S[(long)i * nu_ * nx_ + ru + cc * nu_];
+            if (rx && has_ab) ab = A[(long)i * nx_ * nx_ + r + cc * nx_];
+          }
         } else if constexpr (cc < NS) {
-          if (rx) kv = S[(long)i * NU * NX + (long)r * NU + (cc - NX)];
-          else if (rs_) kv = Rm[(long)i * NU * NU + ru + (cc - NX) * NU];
-          if (rx && has_ab) ab = B[(long)i * NX * NU + r + (cc - NX) * NX];
+          if (cc - NX < nu_) {  // a real input column
+            if (rx) kv = S[(long)i * nu_ * nx_ + (long)r * nu_ + (cc - NX)];
+            else if (rin) kv = Rm[(long)i * nu_ * nu_ + ru + (cc - NX) * nu_];
+            if (rx && has_ab) ab = B[(long)i * nx_ * nu_ + r + (cc - NX) * nx_];
+          }
         }
         Kr[cc] = kv;
         ABr[cc] = ab;
       });
       {
-        const double* src = rx ? E + ((long)i * NX + r) * NC : L + ((long)i * NU + (rs_ ? ru : 0)) * NC;
-        sfor<0, NC>([&](auto Kk) { Cc[decltype(Kk)::value] = rs_ ? src[decltype(Kk)::value] : 0.0; });
+        const double* src = rx ? E + ((long)i * nx_ + r) * nc_ : L + ((long)i * nu_ + (rin ? ru : 0)) * nc_;
+        sfor<0, NC>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          Cc[k] = (rs_ && k < nc_) ? src[k] : 0.0;
+        });
       }
       {
-        const double* src = rx ? A + (long)i * NX * NX + (long)r * NX
-                               : B + (long)i * NX * NU + (long)(rs_ ? ru : 0) * NX;
-        sfor<0, NX>([&](auto J) { ABc[decltype(J)::value] = (rs_ && has_ab) ? src[decltype(J)::value] : 0.0; });
+        const double* src = rx ? A + (long)i * nx_ * nx_ + (long)r * nx_
+                               : B + (long)i * nx_ * nu_ + (long)(rin ? ru : 0) * nx_;
+        sfor<0, NX>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          ABc[j] = (rs_ && has_ab && j < nx_) ? src[j] : 0.0;
+        });
       }
       // A stage whose matrices equal (bitwise) those of the previous stage
       // shares its copy: nothing is written for it.
@@ -347,12 +371,12 @@ struct MpcR16 {
       po[i] = canon;  // every lane: each later reads its own store
       lds_off = -1;
       // constants f, h, b (mpc_data.cc:240-289)
-      const double f = rx ? pq[(long)i * NX + r] : (rs_ ? pr[(long)i * NU + ru] : 0.0);
-      const double h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * NX + r]) : 0.0;
+      const double f = rx ? pq[(long)i * nx_ + r] : (rin ? pr[(long)i * nu_ + ru] : 0.0);
+      const double h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * nx_ + r]) : 0.0;
       st2(R, sF, f, h);
       // the guess and y = b - A z
-      const double zz = rs_ ? uz[(long)i * NS + r] : 0.0;
-      const double ll = rx ? ul[(long)i * NX + r] : 0.0;
+      const double zz = rx ? uz[(long)i * (nx_ + nu_) + r] : (rin ? uz[(long)i * (nx_ + nu_) + nx_ + ru] : 0.0);
+      const double ll = rx ? ul[(long)i * nx_ + r] : 0.0;
       st2(R, sZ, zz, 0.0);
       st2(R, sL, ll, 0.0);
       st2(R, sDZ, 0.0, 0.0);
@@ -363,10 +387,11 @@ struct MpcR16 {
       rows_of_C_times(Cl, zb, r, [&](auto S_, bool valid, double az) {
         constexpr int s = decltype(S_)::value;
         const int k = r + 16 * s;
-        const double b = valid ? -pd[(long)i * NC + k] : 0.0;
-        const double vv = valid ? uv[(long)i * NC + k] : 0.0;
+        const bool real = valid && k < nc_;
+        const double b = real ? -pd[(long)i * nc_ + k] : 0.0;
+        const double vv = real ? uv[(long)i * nc_ + k] : 0.0;
         st(R, sB + s, b);
-        st2(R, sV + 2 * s, vv, valid ? b - az : 0.0);
+        st2(R, sV + 2 * s, vv, real ? b - az : 0.0);
         st2(R, sDV + 2 * s, 0.0, 0.0);
       });
     }
@@ -784,14 +809,16 @@ struct MpcR16 {
   template <int WHICH>
   FB_DEV void write_out(const C& c) const {
     const int r = c.tid, N_ = N;
+    const int nx_ = nx, nu_ = nu, nc_ = nc;
     const double* const R0 = rec;
     double *uz = xarr(0), *ul = xarr(1), *uv = xarr(2), *uy = xarr(3);
     for (int i = 0; i <= N_; i++) {
       const double* R = R0 + (long)i * kRec;
       const double zz = ld(R, WHICH == 0 ? sZ : (WHICH == 1 ? sZB : sDZ));
       const double ll = ld(R, WHICH == 0 ? sL : (WHICH == 1 ? sLB : sDL));
-      if (r < NS) uz[(long)i * NS + r] = zz;
-      if (r < NX) ul[(long)i * NX + r] = ll;
+      if (r < nx_) uz[(long)i * (nx_ + nu_) + r] = zz;
+      else if (r >= NX && r - NX < nu_) uz[(long)i * (nx_ + nu_) + nx_ + (r - NX)] = zz;
+      if (r < nx_) ul[(long)i * nx_ + r] = ll;
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
         const int k = r + 16 * sl;
@@ -805,9 +832,9 @@ struct MpcR16 {
           vv = ld(R, sDV + 2 * sl);
           yy = (vy[1] - ld(R, sVB + 2 * sl + 1)) + ld(R, sB + sl);
         }
-        if (k < NC) {
-          uv[(long)i * NC + k] = vv;
-          uy[(long)i * NC + k] = yy;
+        if (k < nc_) {
+          uv[(long)i * nc_ + k] = vv;
+          uy[(long)i * nc_ + k] = yy;
         }
       });
     }
@@ -817,43 +844,53 @@ struct MpcR16 {
   FB_DEV void write_certificate(const C& c) const { write_out<2>(c); }
 
   // ---- diagnostics (tests): xbar in, one Newton step's vectors out ------------------
+  // index of this lane's z element of stage i in the caller's z, or -1
+  FB_DEV long z_index(int i, int r) const {
+    if (r < nx) return (long)i * (nx + nu) + r;
+    if (r >= NX && r - NX < nu) return (long)i * (nx + nu) + nx + (r - NX);
+    return -1;
+  }
   FB_DEV void probe_set_xbar(const C& c, const double* dbg) const {
     const int r = c.tid, N_ = N;
+    const int nx_ = nx, nu_ = nu, nc_ = nc;
     double* const R0 = rec;
-    const int nz = (N_ + 1) * NS, nl = (N_ + 1) * NX;
+    const long nz = (long)(N_ + 1) * (nx_ + nu_), nl = (long)(N_ + 1) * nx_;
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
-      st2(R, sZB, r < NS ? dbg[(long)i * NS + r] : 0.0, r < NX ? dbg[nz + (long)i * NX + r] : 0.0);
+      const long zi = z_index(i, r);
+      st2(R, sZB, zi >= 0 ? dbg[zi] : 0.0, r < nx_ ? dbg[nz + (long)i * nx_ + r] : 0.0);
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
         const int k = r + 16 * sl;
-        st(R, sVB + 2 * sl, k < NC ? dbg[nz + nl + (long)i * NC + k] : 0.0);
+        st(R, sVB + 2 * sl, k < nc_ ? dbg[nz + nl + (long)i * nc_ + k] : 0.0);
       });
     }
     c.sync();
   }
   FB_DEV void probe_dump(const C& c, double* o, bool ok) const {
     const int r = c.tid, N_ = N;
+    const int nx_ = nx, nu_ = nu, nc_ = nc;
     const double* const R0 = rec;
-    const long nz = (N_ + 1) * NS, nl = (N_ + 1) * NX, nv = (N_ + 1) * NC;
+    const long nz = (long)(N_ + 1) * (nx_ + nu_), nl = (long)(N_ + 1) * nx_, nv = (long)(N_ + 1) * nc_;
     for (int i = 0; i <= N_; i++) {
       const double* R = R0 + (long)i * kRec;
-      if (r < NS) {
-        o[(long)i * NS + r] = ld(R, sDZ);
-        o[nz + nl + 2 * nv + (long)i * NS + r] = ld(R, sWZ);
-        o[2 * nz + 2 * nl + 2 * nv + (long)i * NS + r] = ld(R, sRZ);
+      const long zi = z_index(i, r);
+      if (zi >= 0) {
+        o[zi] = ld(R, sDZ);
+        o[nz + nl + 2 * nv + zi] = ld(R, sWZ);
+        o[2 * nz + 2 * nl + 2 * nv + zi] = ld(R, sRZ);
       }
-      if (r < NX) {
-        o[nz + (long)i * NX + r] = ld(R, sDL);
-        o[2 * nz + nl + 2 * nv + (long)i * NX + r] = ld(R, sWL);
-        o[3 * nz + 2 * nl + 2 * nv + (long)i * NX + r] = ld(R, sRL);
+      if (r < nx_) {
+        o[nz + (long)i * nx_ + r] = ld(R, sDL);
+        o[2 * nz + nl + 2 * nv + (long)i * nx_ + r] = ld(R, sWL);
+        o[3 * nz + 2 * nl + 2 * nv + (long)i * nx_ + r] = ld(R, sRL);
       }
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
         const int k = r + 16 * sl;
-        if (k < NC) {
-          o[nz + nl + (long)i * NC + k] = ld(R, sDV + 2 * sl);
-          o[nz + nl + nv + (long)i * NC + k] = ld(R, sDV + 2 * sl + 1);
+        if (k < nc_) {
+          o[nz + nl + (long)i * nc_ + k] = ld(R, sDV + 2 * sl);
+          o[nz + nl + nv + (long)i * nc_ + k] = ld(R, sDV + 2 * sl + 1);
         }
       });
     }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
 template <int NX, int NU, int NC, bool DBG>
 __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
-    int* counter, int batch, int N, double* dbg) {
+    int* counter, int batch, int N, int nx, int nu, int nc, double* dbg) {
   typedef MpcR16<NX, NU, NC> P;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 #if defined(FB_ANY_STAMP)
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     if (ctx.tid == 0) q = atomicAdd(counter, 1);
     q = bci<0>(q);
     if (q >= batch) return -1;
-    pp.bind(ws, lds, &data, &x, q, N, ctx.tid);
+    pp.bind(ws, lds, &data, &x, q, N, nx, nu, nc, ctx.tid);
     return q;
   };
   if constexpr (DBG) {
@@ -441,8 +441,11 @@ struct fbstab_mpc_solver : SolverBase {
 };
 
 namespace {
-// The specialised shapes compiled into the library.
+// The specialised shapes compiled into the library: the flat-layout register
+// kernel needs the exact shape, the record kernel runs anything that fits its
+// (12, 4, 20) instance zero-padded.
 bool g16_shape(int nx, int nu, int nc) { return nx == 12 && nu == 4 && nc == 20; }
+bool r16_fits(int nx, int nu, int nc) { return nx <= 12 && nu <= 4 && nc <= 20; }
 
 template <class... A>
 void launch_mpc(fbstab_mpc_solver* h, int grid, hipStream_t s, A... args) {
@@ -464,7 +467,7 @@ void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArg
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { d.base[i] = a.base[i]; d.stride[i] = a.stride[i]; }
   for (int i = 0; i < 4; i++) { x.base[i] = v.base[i]; x.stride[i] = v.stride[i]; }
   hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG>), dim3(grid), dim3(64), h->lds_bytes, s, d, x, out,
-                     h->opts, h->scratch, h->counter, batch, h->lay.N, dbg);
+                     h->opts, h->scratch, h->counter, batch, h->lay.N, h->lay.nx, h->lay.nu, h->lay.nc, dbg);
 }
 }  // namespace
 struct fbstab_dense_solver : SolverBase {
@@ -499,7 +502,8 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   s->g16 = g16_shape(nx, nu, nc) && !(force_generic && atoi(force_generic) > 0);
   // FBSTAB_HIP_MPC_KERNEL=g16 selects the previous register kernel (comparisons)
   const char* which = getenv("FBSTAB_HIP_MPC_KERNEL");
-  s->r16 = s->g16 && !(which && strcmp(which, "g16") == 0);
+  s->r16 = r16_fits(nx, nu, nc) && !(force_generic && atoi(force_generic) > 0) &&
+           !(which && strcmp(which, "g16") == 0);
   typedef fbk::MpcR16<12, 4, 20> R16;
   if (s->r16) {
     s->g16 = false;

@@ -231,6 +231,50 @@ def test_time_varying_stage_data(hip, oracle, monkeypatch, kernel):
     _assert_parity(gpu, cpu, o.abs_tol)
 
 
+@pytest.mark.parametrize("problem", ["DoubleIntegrator", "ServoMotor", "SpacecraftRelativeMotion"])
+def test_smaller_shapes_run_padded_on_the_record_kernel(hip, oracle, monkeypatch, problem):
+    """Shapes with nx <= 12, nu <= 4, nc <= 20 (the reference's OcpGenerator
+    problems except the reactor) run zero-padded on the record kernel's
+    (12, 4, 20) instance: a batch with perturbed initial states must meet the
+    parity definition, and a Newton step must match the oracle's."""
+    _select_kernel(monkeypatch, "r16")
+    gen = fx.OcpGenerator()
+    getattr(gen, problem)()
+    one = gen.GetFBstabInput()
+    N, nx, nu, nc = one.sizes()
+    B = 40
+    rng = np.random.default_rng(11)
+    p = fx.MpcProblem(N, nx, nu, nc)
+    p.arrays = {k: np.ascontiguousarray(np.broadcast_to(a, (B, a.shape[1]))).copy() for k, a in one.arrays.items()}
+    p.arrays["x0"] = p.arrays["x0"] * (1.0 + 0.3 * rng.standard_normal((B, nx)))
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    assert s.query()["lds_bytes"] == 38400, "the record kernel was not selected"
+    s.close()
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+    # one Newton step at a random point
+    q = fx.MpcProblem(N, nx, nu, nc)
+    q.arrays = {k: a[:1].copy() for k, a in p.arrays.items()}
+    z, l = rng.standard_normal(q.nz), rng.standard_normal(q.nl)
+    v = np.abs(rng.standard_normal(q.nv))
+    zb, lb, vb = 0.5 * z, 0.5 * l, 0.5 * v
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=1)
+    s.UpdateOptions(hip.DefaultOptions(sigma0=1e-4, sigma_max=100.0))
+    g = s.debug_newton({k: a[0] for k, a in q.arrays.items()}, z, l, v, zb, lb, vb)
+    s.close()
+    assert g["ok"]
+    pr = oracle.probe(q, z, l, v, zb, lb, vb, 1e-4)
+    np.testing.assert_allclose(g["rz"], pr["natural"][:q.nz], atol=1e-10)
+    pr = oracle.probe(q, z, l, v, zb, lb, vb, 1e-4, r=-pr["inner"], want_dx=True)
+    odz, odl, odv, ody = np.split(pr["dx"], [q.nz, q.nz + q.nl, q.nz + q.nl + q.nv])
+    # (the spacecraft problem's KKT matrix is the worst conditioned of the three:
+    # summation order shows at 1e-7 relative)
+    for a_, b_ in ((g["dz"], odz), (g["dl"], odl), (g["dv"], odv)):
+        assert np.abs(a_ - b_).max() <= 1e-6 * (1 + np.abs(b_).max())
+
+
 def test_dense_synthetic_batch_parity(hip, oracle):
     for (nz, nl, nv, B) in ((20, 5, 40, 64), (50, 10, 100, 256)):
         p = fx.synthetic_dense_batch(B, nz, nl, nv)
