@@ -43,13 +43,17 @@ namespace fbk {
 struct MpcBatchPtrs {
   const double* base[12];
   long long stride[12];
+  int nx, nu, nc;  // the problem's own sizes (<= the kernel instance's)
 };
 struct VarBatchPtrs {
   double* base[4];
   long long stride[4];
 };
 
-template <int NX, int NU, int NC>
+// EXACT: the problem has exactly the instance's shape (compile-time strides in
+// the passes over the caller's arrays); otherwise it may be smaller and runs
+// zero-padded.
+template <int NX, int NU, int NC, bool EXACT = true>
 struct MpcR16 {
   typedef Ctx16 C;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -138,17 +142,17 @@ struct MpcR16 {
   // constraints k < nc).  Padded rows and columns are exact zeros everywhere;
   // their pivots are sigma (+ 1/sigma), their steps are zero, and only the passes
   // that touch the caller's arrays (load_guess, write_out, forcing_norm, the
-  // test probe) know about it.
-  int nx, nu, nc;
+  // test probe) know about it.  Read from the launch descriptor where needed
+  // rather than held in registers across the sweeps.
+  FB_DEV int prob_nx() const { return EXACT ? NX : data->nx; }
+  FB_DEV int prob_nu() const { return EXACT ? NU : data->nu; }
+  FB_DEV int prob_nc() const { return EXACT ? NC : data->nc; }
   // Step length of an accepted but not yet applied Newton step (0 = none); the
   // next forward sweep applies it stage by stage, everything else flushes first.
   double pend_t;
 
   FB_DEV void bind(double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d, const VarBatchPtrs* x,
-                   long q_, int N_, int nx_, int nu_, int nc_, int lane16) {
-    nx = nx_;
-    nu = nu_;
-    nc = nc_;
+                   long q_, int N_, int lane16) {
     lds_off = -1;
     poff = reinterpret_cast<int*>(ws_row);
     pack = ws_row + hdr_doubles(N_) + 2 * lane16;
@@ -160,7 +164,7 @@ struct MpcR16 {
     N = N_;
     pend_t = 0.0;
   }
-  FB_DEV int num_primal_dual() const { return (N + 1) * (2 * nx + nu + nc); }
+  FB_DEV int num_primal_dual() const { return (N + 1) * (2 * prob_nx() + prob_nu() + prob_nc()); }
 
   // ---- record access -------------------------------------------------------------
   static FB_DEV double ld(const double* R, int slot) { return R[off(slot)]; }
@@ -269,7 +273,7 @@ struct MpcR16 {
     const double *pq = arr(FBSTAB_MPC_q), *pr = arr(FBSTAB_MPC_r), *pd = arr(FBSTAB_MPC_d),
                  *px0 = arr(FBSTAB_MPC_x0), *pc = arr(FBSTAB_MPC_c);
     double s = 0.0;
-    const int nx_ = nx, nu_ = nu, nc_ = nc;
+    const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
     for (int i = c.tid; i < (N_ + 1) * nx_; i += 16) s += pq[i] * pq[i];
     for (int i = c.tid; i < (N_ + 1) * nu_; i += 16) s += pr[i] * pr[i];
     for (int i = c.tid; i < (N_ + 1) * nc_; i += 16) s += pd[i] * pd[i];
@@ -283,7 +287,7 @@ struct MpcR16 {
   FB_DEV void load_guess(const C& c) {
     FB_WAVE_TIMER(19);
     const int r = c.tid, N_ = N;
-    const int nx_ = nx, nu_ = nu, nc_ = nc;
+    const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
     const int ru = r - NX;
     const bool rx = r < nx_;                   // lane holds a real state row
     const bool rin = r >= NX && ru < nu_;      // lane holds a real input row
@@ -809,7 +813,7 @@ struct MpcR16 {
   template <int WHICH>
   FB_DEV void write_out(const C& c) const {
     const int r = c.tid, N_ = N;
-    const int nx_ = nx, nu_ = nu, nc_ = nc;
+    const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
     const double* const R0 = rec;
     double *uz = xarr(0), *ul = xarr(1), *uv = xarr(2), *uy = xarr(3);
     for (int i = 0; i <= N_; i++) {
@@ -846,13 +850,14 @@ struct MpcR16 {
   // ---- diagnostics (tests): xbar in, one Newton step's vectors out ------------------
   // index of this lane's z element of stage i in the caller's z, or -1
   FB_DEV long z_index(int i, int r) const {
+    const int nx = prob_nx(), nu = prob_nu();
     if (r < nx) return (long)i * (nx + nu) + r;
     if (r >= NX && r - NX < nu) return (long)i * (nx + nu) + nx + (r - NX);
     return -1;
   }
   FB_DEV void probe_set_xbar(const C& c, const double* dbg) const {
     const int r = c.tid, N_ = N;
-    const int nx_ = nx, nu_ = nu, nc_ = nc;
+    const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
     double* const R0 = rec;
     const long nz = (long)(N_ + 1) * (nx_ + nu_), nl = (long)(N_ + 1) * nx_;
     for (int i = 0; i <= N_; i++) {
@@ -869,7 +874,7 @@ struct MpcR16 {
   }
   FB_DEV void probe_dump(const C& c, double* o, bool ok) const {
     const int r = c.tid, N_ = N;
-    const int nx_ = nx, nu_ = nu, nc_ = nc;
+    const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
     const double* const R0 = rec;
     const long nz = (long)(N_ + 1) * (nx_ + nu_), nl = (long)(N_ + 1) * nx_, nv = (long)(N_ + 1) * nc_;
     for (int i = 0; i <= N_; i++) {

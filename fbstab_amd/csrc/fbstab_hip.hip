@@ -221,11 +221,11 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
 #endif
 // Record-based 16-lane kernel (fb_mpc_r16.h): four QPs per wavefront, rows pull
 // QP indices from the shared counter.  scratch: rows * ws_doubles(N).
-template <int NX, int NU, int NC, bool DBG>
+template <int NX, int NU, int NC, bool DBG, bool EXACT>
 __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
-    int* counter, int batch, int N, int nx, int nu, int nc, double* dbg) {
-  typedef MpcR16<NX, NU, NC> P;
+    int* counter, int batch, int N, double* dbg) {
+  typedef MpcR16<NX, NU, NC, EXACT> P;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 #if defined(FB_ANY_STAMP)
   const long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     if (ctx.tid == 0) q = atomicAdd(counter, 1);
     q = bci<0>(q);
     if (q >= batch) return -1;
-    pp.bind(ws, lds, &data, &x, q, N, nx, nu, nc, ctx.tid);
+    pp.bind(ws, lds, &data, &x, q, N, ctx.tid);
     return q;
   };
   if constexpr (DBG) {
@@ -466,8 +466,15 @@ void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArg
   VarBatchPtrs x;
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { d.base[i] = a.base[i]; d.stride[i] = a.stride[i]; }
   for (int i = 0; i < 4; i++) { x.base[i] = v.base[i]; x.stride[i] = v.stride[i]; }
-  hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG>), dim3(grid), dim3(64), h->lds_bytes, s, d, x, out,
-                     h->opts, h->scratch, h->counter, batch, h->lay.N, h->lay.nx, h->lay.nu, h->lay.nc, dbg);
+  d.nx = h->lay.nx;
+  d.nu = h->lay.nu;
+  d.nc = h->lay.nc;
+  if (g16_shape(h->lay.nx, h->lay.nu, h->lay.nc))
+    hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG, true>), dim3(grid), dim3(64), h->lds_bytes, s, d, x, out,
+                       h->opts, h->scratch, h->counter, batch, h->lay.N, dbg);
+  else
+    hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG, false>), dim3(grid), dim3(64), h->lds_bytes, s, d, x,
+                       out, h->opts, h->scratch, h->counter, batch, h->lay.N, dbg);
 }
 }  // namespace
 struct fbstab_dense_solver : SolverBase {
@@ -525,10 +532,13 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  const void* kern = s->r16   ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false>)
+  const bool exact = g16_shape(nx, nu, nc);
+  const void* kern = s->r16   ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true>)
+                                       : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false>))
                      : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, false>)
                               : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>);
-  const void* kern_dbg = s->r16   ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true>)
+  const void* kern_dbg = s->r16   ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true, true>)
+                                           : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true, false>))
                          : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, true>)
                                   : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>);
   hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
