@@ -218,21 +218,81 @@ struct DenseProblem {
     }
   }
   FB_DEV bool ldlt(const C& c) const {
-#if defined(FB_DENSE_LDLT_ONE_WAVE)
-    FB_LDS int* flag = perm + lay.nk;  // spare slot behind the permutation
-    on_first_wave(c, [&](const auto& w) {
-      typedef typename std::remove_cv<typename std::remove_reference<decltype(w)>::type>::type W;
-      bool ok;
-      if constexpr (W::nt == 64) ok = lay.nk <= 64 ? ldlt_wave(w) : ldlt_impl(w);
-      else ok = ldlt_impl(w);
-      if (w.tid == 0) *flag = ok ? 1 : 0;
-      w.sync();
-    });
-    return *flag != 0;
-#else
-    return ldlt_impl(c);  // measured faster than the one-wave variant (23.3 vs 27.3 ms, config 2)
+#if !defined(FB_HOSTSIM)
+    if (C::nt > 64 && lay.nk <= 64) return ldlt_fused(c);
 #endif
+    // (running the whole factorisation on one wavefront was measured too: 27.3 ms
+    // against 23.3 on config 2 - the trailing update wants the four of them)
+    return ldlt_impl(c);
   }
+
+#if !defined(FB_HOSTSIM)
+  // ldlt_impl for n <= 64 on a multi-wavefront workgroup with its phases fused:
+  // the scaling of column k-1 rides along with the pivot search of step k (they
+  // touch different entries), the search itself is DPP + v_readlane in the first
+  // wavefront, and barriers that only separated reads are gone: two per pivot
+  // (three with a swap) instead of five.
+  FB_DEV bool ldlt_fused(const C& c) const {
+    const int n = lay.nk;
+    bool found_zero_pivot = false;
+    double id_prev = 0.0;  // 1 / d of the previous pivot, 0 = nothing to scale
+    for (int k = 0; k < n; k++) {
+      if (id_prev != 0.0)
+        for (int i = k + c.tid; i < n; i += C::nt) K[i + (k - 1) * n] *= id_prev;
+      if (c.tid < 64) {
+        int p = k + c.tid;
+        double best = p < n ? fabs(K[p + p * n]) : -1.0;
+        if (p >= n) p = n;
+        C::wave_argmax_first(best, p);  // largest |diagonal|, the first maximum wins
+        if (c.tid == 0) perm[k] = p;
+      }
+      c.sync();
+      const int p = perm[k];
+      if (p != k) {
+        const int s = n - p - 1;
+        for (int j = c.tid; j < k; j += C::nt) {
+          const double t = K[k + j * n];
+          K[k + j * n] = K[p + j * n];
+          K[p + j * n] = t;
+        }
+        for (int i = c.tid; i < s; i += C::nt) {
+          const double t = K[(p + 1 + i) + k * n];
+          K[(p + 1 + i) + k * n] = K[(p + 1 + i) + p * n];
+          K[(p + 1 + i) + p * n] = t;
+        }
+        for (int i = k + 1 + c.tid; i < p; i += C::nt) {
+          const double t = K[i + k * n];
+          K[i + k * n] = K[p + i * n];
+          K[p + i * n] = t;
+        }
+        if (c.tid == 0) {
+          const double t = K[k + k * n];
+          K[k + k * n] = K[p + p * n];
+          K[p + p * n] = t;
+        }
+        c.sync();
+      }
+      const double d = K[k + k * n];
+      const bool valid = fabs(d) > 0.0;
+      if (found_zero_pivot && valid) return false;
+      if (!valid) found_zero_pivot = true;
+      id_prev = 0.0;
+      if (n - k - 1 > 0 && valid) {
+        // trailing update of the lower triangle: K(i,j) -= K(i,k) K(j,k) / d
+        const double id = 1.0 / d;
+        constexpr int TW = 16, TH = C::nt / TW;
+        const int ti = c.tid % TW, tj = c.tid / TW;
+        for (int j = k + 1 + tj; j < n; j += TH) {
+          const double ljk = K[j + k * n] * id;
+          for (int i = j + ti; i < n; i += TW) K[i + j * n] -= K[i + k * n] * ljk;
+        }
+        id_prev = id;
+        c.sync();
+      }
+    }
+    return true;
+  }
+#endif
   FB_DEV void ldlt_solve(const C& c) const {
     on_first_wave(c, [&](const auto& w) {
       typedef typename std::remove_cv<typename std::remove_reference<decltype(w)>::type>::type W;
@@ -246,71 +306,10 @@ struct DenseProblem {
   }
 
 #if !defined(FB_HOSTSIM)
-  // One-wavefront versions for n <= 64 (same pivot rule and update formulas as
-  // ldlt_impl / ldlt_solve_impl).  Lane t owns column k+1+t of the trailing
-  // block; every LDS access of a phase is issued before the first use (batches
-  // of 8 rows), so a pivot costs a few LDS round trips instead of one per
-  // element, and the substitutions keep the right-hand side in registers with
-  // the solved entry handed round by v_readlane.
-  FB_DEV bool ldlt_wave(const Ctx<64>& c) const {
-    const int n = lay.nk, t = c.tid;
-    bool found_zero_pivot = false;
-    for (int k = 0; k < n; k++) {
-      int p = k + t;
-      double best = p < n ? fabs(K[p + p * n]) : -1.0;
-      if (p >= n) p = n;
-      c.argmax_first(&best, &p);  // largest |diagonal|, first maximum wins
-      p = __builtin_amdgcn_readfirstlane(p);
-      if (t == 0) perm[k] = p;
-      if (p != k) {
-        c.sync();
-        // rows k and p left of the block, columns k and p below p, the L-shaped middle part
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0;
-        const int s = n - p - 1;
-        const bool ua = t < k, ub = t < s, uc = k + 1 + t < p;
-        if (ua) { a0 = K[k + t * n]; a1 = K[p + t * n]; }
-        if (ub) { b0 = K[(p + 1 + t) + k * n]; b1 = K[(p + 1 + t) + p * n]; }
-        if (uc) { c0 = K[(k + 1 + t) + k * n]; c1 = K[p + (k + 1 + t) * n]; }
-        const double dk = K[k + k * n], dp = K[p + p * n];
-        if (ua) { K[k + t * n] = a1; K[p + t * n] = a0; }
-        if (ub) { K[(p + 1 + t) + k * n] = b1; K[(p + 1 + t) + p * n] = b0; }
-        if (uc) { K[(k + 1 + t) + k * n] = c1; K[p + (k + 1 + t) * n] = c0; }
-        if (t == 0) { K[k + k * n] = dp; K[p + p * n] = dk; }
-      }
-      c.sync();
-      const double d = K[k + k * n];
-      const bool valid = fabs(d) > 0.0;
-      if (found_zero_pivot && valid) return false;
-      if (!valid) found_zero_pivot = true;
-      const int rs = n - k - 1;
-      if (rs > 0 && valid) {
-        // trailing update of the lower triangle: K(i,j) -= K(i,k) K(j,k) / d
-        const double id = 1.0 / d;
-        const int j = k + 1 + t;
-        if (j < n) {
-          const double ljk = K[j + k * n] * id;
-          lds_ptr ck = K + k * n, cj = K + j * n;
-          for (int i0 = j; i0 < n; i0 += 8) {
-            double a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const int ii = i0 + u < n ? i0 + u : n - 1;
-              a[u] = ck[ii];
-              b[u] = cj[ii];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-              if (i0 + u < n) cj[i0 + u] = b[u] - a[u] * ljk;
-          }
-        }
-        c.sync();
-        if (j < n) K[j + k * n] *= id;
-      }
-      c.sync();
-    }
-    return true;
-  }
-
+  // One-wavefront substitutions for n <= 64 (same formulas as ldlt_solve_impl):
+  // the right-hand side stays in registers, lane t owning entry t, the solved
+  // entry is handed round by v_readlane, and the L columns are fetched from LDS
+  // eight steps ahead of their use.
   FB_DEV void ldlt_solve_wave(const Ctx<64>& c) const {
     const int n = lay.nk, t = c.tid;
     const bool in = t < n;
@@ -361,8 +360,6 @@ struct DenseProblem {
     c.sync();
   }
 #else
-  template <class W>
-  FB_DEV bool ldlt_wave(const W& c) const { return ldlt_impl(c); }
   template <class W>
   FB_DEV void ldlt_solve_wave(const W& c) const { ldlt_solve_impl(c); }
 #endif
