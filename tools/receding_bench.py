@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Developer tool: BASELINE config 5 in short form on one GPU - T closed-loop
+trajectories x S warm-started MPC steps (N=30, nx=12, nu=4, nc=20), problem
+data resident on the device, only x0 changing (fbstab_amd/receding_horizon.py).
+argv: trajectories steps [retire]
+
+With "retire", a trajectory whose QP did not return SUCCESS (the closed loop
+has no terminal constraint, so a few run into infeasible states) is parked at
+the origin with a zero guess from then on - what a controller's fallback would
+do - so that the step time shows the warm-started bulk rather than the handful
+of QPs that run to the iteration limit."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from fbstab_amd import fixtures as fx, hip_api, receding_horizon as rh  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+RETIRE = len(sys.argv) > 3 and sys.argv[3] == "retire"
+p = fx.synthetic_mpc_batch(T)
+N, nx, nu, nc = p.sizes()
+A, B = fx.quadrotor_model()
+dev = torch.device("cuda:0")
+s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=T)
+data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+y = mk(p.nv)
+out_dev = torch.zeros((T, 40), dtype=torch.uint8, device=dev)
+kernel_ms = []
+
+
+retired = torch.zeros(T, dtype=torch.bool, device=dev)
+
+
+def solve(x0, z, l, v):
+    if RETIRE and bool(retired.any()):
+        x0[retired] = 0.0
+        z[retired] = 0.0
+        l[retired] = 0.0
+        v[retired] = 0.0
+    data["x0"] = x0.contiguous()
+    s.Solve(data, z, l, v, y, out=out_dev)
+    kernel_ms.append(s.last_kernel_ms())
+    o = hip_api.out_to_numpy(out_dev)
+    if RETIRE:
+        retired.logical_or_(torch.from_numpy(o["eflag"] != 0).to(dev))
+    return z, l, v, y, o
+
+
+x0 = data["x0"].clone()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+log = rh.closed_loop(solve, x0, mk(p.nz), mk(p.nl), mk(p.nv), torch.from_numpy(A).to(dev),
+                     torch.from_numpy(B).to(dev), nx, nu, S)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+it = np.array([r["out"]["newton_iters"].mean() for r in log])
+ok = all((r["out"]["eflag"] == 0).all() for r in log)
+for k in (0, 1, 2, 5, 10, S - 1):
+    if k < S:
+        o = log[k]["out"]
+        print(f"   step {k:3d}: eflag counts {np.bincount(o['eflag'], minlength=6).tolist()} newton mean {o['newton_iters'].mean():.2f} "
+              f"max {o['newton_iters'].max()} prox max {o['prox_iters'].max()} kernel {kernel_ms[k]:.2f} ms")
+print(f"trajectories={T} steps={S}: {T * S / dt:.0f} QP/s wall ({dt / S * 1e3:.2f} ms per closed-loop step), "
+      f"kernel ms first/median/last {kernel_ms[0]:.2f}/{np.median(kernel_ms):.2f}/{kernel_ms[-1]:.2f}, "
+      f"mean Newton iterations first/last step {it[0]:.2f}/{it[-1]:.2f}, all converged {ok}, "
+      f"retired {int(retired.sum())}")
