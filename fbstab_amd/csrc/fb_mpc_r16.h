@@ -14,23 +14,26 @@
 //     owning element r of every slot:
 //       iterate vectors  z rz zb lb dz wz l rl dl wl | v y vb yb dv adz gam rvm
 //       constants        f h b                        (mpc_data.cc:240-289)
-//       matrix copy      row r of [Q S';S R], column r of [E L], row r and
-//                        column r of [A B]            (built once per QP)
-//       factor record    inv(Lc) by columns and by rows, inv(Pi), t, theta
+//       factor record    inv(Lc) (rows and columns folded into one triangle
+//                        pair), inv(Pi), t, theta
+//     and, in a region of its own, the matrix copy of the stage: row r of
+//     [Q S';S R], column r of [E L], row r and column r of [A B], built once per
+//     QP, shared between neighbouring stages with identical matrices and kept in
+//     LDS while in use.
 //     Slots are interleaved in pairs ((s>>1)*32 + 2r + (s&1)): one 16-byte
 //     access per lane moves two slots and every memory instruction of a row
 //     covers 256 contiguous bytes.  Lanes without an element hold zeros, so the
-//     sweeps carry no lane predicates on loads.
+//     sweeps carry no lane predicates on loads (and smaller problems run padded).
 //   * residual, feasibility, norms, the variable updates and the I/O passes are
-//     written for this layout too (one pass over the records each) instead of
-//     borrowing the workgroup-generic LDS-tile code: they cost a fraction of a
-//     Newton step, which is what lets rows of a wavefront run out of step.
-//   * the barrier Hessian C'Gamma C is accumulated with DPP broadcasts (no LDS
-//     round trip); LDS only transposes inv(Lc) (forward) and C (backward, for
-//     A dz): 2.9 KB per QP.
-//   * inv(Lc) is recorded by rows as well, so that the backward sweep forms
-//     W'dl = inv(Lc)([A B]'dl) from the already needed [A B]'dl instead of
-//     reading W by columns.
+//     written for this layout too (fused into two passes per proximal
+//     iteration) instead of borrowing the workgroup-generic LDS-tile code: they
+//     cost a fraction of a Newton step, which is what lets the rows of a
+//     wavefront run out of step (Solver::solve_stream).
+//   * the barrier Hessian C'Gamma C is accumulated with DPP broadcasts; LDS
+//     holds the matrix copy in use (6.5 KB per QP) and transposes inv(Lc)
+//     (forward) and C (backward, for A dz) in 2.7 KB more.
+//   * the backward sweep forms W'dl = inv(Lc)([A B]'dl) from the already needed
+//     [A B]'dl and the row triangle of inv(Lc) instead of reading W by columns.
 #pragma once
 
 #include "fb_mpc_g16.h"
