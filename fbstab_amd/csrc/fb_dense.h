@@ -493,6 +493,57 @@ struct DenseProblem {
     FB_WAVE_LAP(10);
     // K = [H + sigma I + A'Gamma A  .; G  -sigma I] (lower; :52-69) and the
     // eliminated right-hand side (:98-104).
+#if !defined(FB_HOSTSIM) && !defined(FB_DENSE_NO_MFMA)
+    if (lay.a_lds && C::nt == 256 && nz <= 64 && (nv & 3) == 0) {
+      // E = H + sigma I + A' Gamma A on the matrix cores: one QP per workgroup, so
+      // v_mfma_f64_16x16x4 fits - the 16x16 tiles of the lower triangle of the
+      // (padded) 64x64 product are dealt to the four wavefronts, each tile
+      // accumulates over nv/4 steps with both operands read from the LDS copy
+      // of A (A operand lane l: A[k0 + l/16][16 I + l%16], B operand the same
+      // entry of block column J times Gamma).  Accumulation order differs from
+      // the scalar loop below (rounding only).
+      typedef double d4 __attribute__((ext_vector_type(4)));
+      const int wave = c.tid >> 6, lane = c.tid & 63;
+      const int kq = lane >> 4, ij = lane & 15;
+      const int nt16 = (nz + 15) >> 4;
+      const int ntiles = nt16 * (nt16 + 1) / 2;
+      for (int t0 = wave; t0 < ntiles; t0 += 4) {
+        // tile index -> (I, J), I >= J (row-major over the lower triangle)
+        int I = 0, rem = t0;
+        while (rem > I) { rem -= I + 1; I++; }
+        const int J = rem;
+        const int ci = 16 * I + ij < nz ? 16 * I + ij : nz - 1;  // padded columns re-read the last one
+        const int cj = 16 * J + ij < nz ? 16 * J + ij : nz - 1;
+        lds_ptr ai = Al + ci * lay.lda + kq;
+        lds_ptr aj = Al + cj * lay.lda + kq;
+        lds_ptr gk = gam + kq;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < nv; k0 += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[k0], gk[k0] * aj[k0], acc, 0, 0, 0);
+        // D layout: column = lane % 16, row = lane / 16 + 4 * register
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = 16 * I + kq + 4 * q, j = 16 * J + ij;
+          if (i < nz && j <= i) K[i + j * n] = D.H[i + (long)j * nz] + (i == j ? sigma : 0.0) + acc[q];
+        }
+      }
+      for (int e = c.tid; e < nl * n + n; e += C::nt) {
+        if (e < nl * n) {
+          const int i = nz + e % nl, j = e / nl;  // rows of [G  -sigma I]
+          if (j < nz) K[i + j * n] = D.G[(i - nz) + (long)j * nl];
+          else if (i >= j) K[i + j * n] = (i == j) ? -sigma : 0.0;
+        } else {
+          const int j = e - nl * n;
+          if (j < nz) {
+            rhs[j] = -(rz[j] + sigma * (z[j] - zb[j])) - A_col_dot(j, rvm);
+          } else {
+            const int q = j - nz;
+            rhs[j] = rl[q] + sigma * (l[q] - lb[q]);
+          }
+        }
+      }
+    } else
+#endif
     if (lay.a_lds) {
       // E = H + sigma I + A' Gamma A (lower), A from LDS: a task is row i and a
       // chunk of JC columns, so that Gamma_k A[k][i] is reused JC times
