@@ -311,6 +311,42 @@ def test_mpc_device_pointers_match_host_pointers(hip):
     assert np.array_equal(v.cpu().numpy(), host[2])
 
 
+def test_two_batches_in_flight_equal_one_at_a_time(hip):
+    """What bench.py does by default: two handles on two HIP streams, launches
+    asynchronous on device pointers, consecutive batches overlapping on the GPU.
+    Every batch must come out bitwise as when it is solved alone."""
+    import torch
+    dev = torch.device("cuda:0")
+    B, rounds = 1024, 4
+    batches = [fx.synthetic_mpc_batch(B, first_id=20000 + 5000 * r) for r in range(rounds)]
+    sizes = batches[0].sizes()
+    mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+    lanes = []
+    for _ in range(2):
+        lanes.append(dict(solver=hip.FBstabMpcBatch(*sizes, max_batch=B), stream=torch.cuda.Stream(device=dev)))
+    data = [{k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in b.arrays.items()} for b in batches]
+    p = batches[0]
+    res = []
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        ln = lanes[r % 2]
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(ln["stream"]):
+            ln["solver"].Solve(data[r], z, l, v, y, out=out, stream=ln["stream"].cuda_stream, async_=True)
+        res.append((z, l, v, y, out))
+    torch.cuda.synchronize()
+    alone = hip.FBstabMpcBatch(*sizes, max_batch=B)
+    for r in range(rounds):
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        out = hip.out_to_numpy(alone.Solve(data[r], z, l, v, y))
+        got = hip.out_to_numpy(res[r][4])
+        assert (out["eflag"] == 0).all()
+        assert np.array_equal(got["newton_iters"], out["newton_iters"]), r
+        assert np.array_equal(got["eflag"], out["eflag"]), r
+        assert torch.equal(res[r][0], z) and torch.equal(res[r][2], v) and torch.equal(res[r][3], y), r
+
+
 # -- edge cases -----------------------------------------------------------------
 def test_warm_start_and_iteration_limits(hip, oracle):
     p = fx.synthetic_mpc_batch(8, first_id=77)
