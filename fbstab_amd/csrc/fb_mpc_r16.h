@@ -56,7 +56,9 @@ struct VarBatchPtrs {
 // EXACT: the problem has exactly the instance's shape (compile-time strides in
 // the passes over the caller's arrays); otherwise it may be smaller and runs
 // zero-padded.
-template <int NX, int NU, int NC, bool EXACT = true>
+// KEEP: instance for FBSTAB_HIP_KEEP_MATRICES (QP q lives in slot q from call to
+// call; with `reuse` set the matrix copies of the previous call are still valid).
+template <int NX, int NU, int NC, bool EXACT = true, bool KEEP = false>
 struct MpcR16 {
   typedef Ctx16 C;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -135,6 +137,7 @@ struct MpcR16 {
   double* pack;  // this row's matrix copies, lane offset included
   int* poff;     // per stage: offset (doubles) of the copy it reads
   int lds_off;   // offset of the copy currently in LDS (-1: none)
+  bool reuse = false;  // (KEEP instances) the slot's matrix copies are those of this QP already
   lds_ptr lds;
   const MpcBatchPtrs* data;  // kernel arguments (uniform)
   const VarBatchPtrs* var;
@@ -314,68 +317,75 @@ struct MpcR16 {
       double* R = R0 + (long)i * kRec;
       double* PK = P0 + (long)i * kPack;
       const bool has_ab = i < N_;
-      // matrices (the caller's arrays have the problem's own strides nx, nu, nc)
-      double Kr[16], ABr[16], Cc[NC], ABc[NX];
-      sfor<0, 16>([&](auto Cc_) {
-        constexpr int cc = decltype(Cc_)::value;
-        double kv = 0.0, ab = 0.0;
-        if constexpr (cc < NX) {
-          if (cc < nx_) {  // a real state column
-            if (rx) kv = Q[(long)i * nx_ * nx_ + r + cc * nx_];
-            else if (rin) kv = S[(long)i * nu_ * nx_ + ru + cc * nu_];
-            if (rx && has_ab) ab = A[(long)i * nx_ * nx_ + r + cc * nx_];
-          }
-        } else if constexpr (cc < NS) {
-          if (cc - NX < nu_) {  // a real input column
-            if (rx) kv = S[(long)i * nu_ * nx_ + (long)r * nu_ + (cc - NX)];
-            else if (rin) kv = Rm[(long)i * nu_ * nu_ + ru + (cc - NX) * nu_];
-            if (rx && has_ab) ab = B[(long)i * nx_ * nu_ + r + (cc - NX) * nx_];
-          }
-        }
-        Kr[cc] = kv;
-        ABr[cc] = ab;
-      });
-      {
-        const double* src = rx ? E + ((long)i * nx_ + r) * nc_ : L + ((long)i * nu_ + (rin ? ru : 0)) * nc_;
-        sfor<0, NC>([&](auto Kk) {
-          constexpr int k = decltype(Kk)::value;
-          Cc[k] = (rs_ && k < nc_) ? src[k] : 0.0;
-        });
-      }
-      {
-        const double* src = rx ? A + (long)i * nx_ * nx_ + (long)r * nx_
-                               : B + (long)i * nx_ * nu_ + (long)(rin ? ru : 0) * nx_;
-        sfor<0, NX>([&](auto J) {
-          constexpr int j = decltype(J)::value;
-          ABc[j] = (rs_ && has_ab && j < nx_) ? src[j] : 0.0;
-        });
-      }
-      // A stage whose matrices equal (bitwise) those of the previous stage
-      // shares its copy: nothing is written for it.
-      bool differs = i == 0;
-      sfor<0, 16>([&](auto Cc_) {
-        constexpr int cc = decltype(Cc_)::value;
-        differs = differs || !(Kr[cc] == lastKr[cc]) || !(ABr[cc] == lastABr[cc]);
-      });
-      sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == lastCc[decltype(Kk)::value]); });
-      sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == lastABc[decltype(J)::value]); });
-#if defined(FB_R16_NO_SHARED_PACK)
-      differs = true;
-#endif
-      if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) {
-        canon = i * kPack;
-        stv<pK, 16>(PK, Kr);
-        stv<pABr, 16>(PK, ABr);
-        stv<pC, NC>(PK, Cc);
-        stv<pABc, NX>(PK, ABc);
+      double Cc[NC];
+      bool fresh = true;
+      if constexpr (KEEP) fresh = !reuse;
+      if (!fresh) {
+        ldv<pC, NC>(P0 + po[i], Cc);  // only C is needed here (y = b - A z)
+      } else {
+        // matrices (the caller's arrays have the problem's own strides nx, nu, nc)
+        double Kr[16], ABr[16], ABc[NX];
         sfor<0, 16>([&](auto Cc_) {
-          lastKr[decltype(Cc_)::value] = Kr[decltype(Cc_)::value];
-          lastABr[decltype(Cc_)::value] = ABr[decltype(Cc_)::value];
+          constexpr int cc = decltype(Cc_)::value;
+          double kv = 0.0, ab = 0.0;
+          if constexpr (cc < NX) {
+            if (cc < nx_) {  // a real state column
+              if (rx) kv = Q[(long)i * nx_ * nx_ + r + cc * nx_];
+              else if (rin) kv = S[(long)i * nu_ * nx_ + ru + cc * nu_];
+              if (rx && has_ab) ab = A[(long)i * nx_ * nx_ + r + cc * nx_];
+            }
+          } else if constexpr (cc < NS) {
+            if (cc - NX < nu_) {  // a real input column
+              if (rx) kv = S[(long)i * nu_ * nx_ + (long)r * nu_ + (cc - NX)];
+              else if (rin) kv = Rm[(long)i * nu_ * nu_ + ru + (cc - NX) * nu_];
+              if (rx && has_ab) ab = B[(long)i * nx_ * nu_ + r + (cc - NX) * nx_];
+            }
+          }
+          Kr[cc] = kv;
+          ABr[cc] = ab;
         });
-        sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
-        sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = ABc[decltype(J)::value]; });
+        {
+          const double* src = rx ? E + ((long)i * nx_ + r) * nc_ : L + ((long)i * nu_ + (rin ? ru : 0)) * nc_;
+          sfor<0, NC>([&](auto Kk) {
+            constexpr int k = decltype(Kk)::value;
+            Cc[k] = (rs_ && k < nc_) ? src[k] : 0.0;
+          });
+        }
+        {
+          const double* src = rx ? A + (long)i * nx_ * nx_ + (long)r * nx_
+                                 : B + (long)i * nx_ * nu_ + (long)(rin ? ru : 0) * nx_;
+          sfor<0, NX>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            ABc[j] = (rs_ && has_ab && j < nx_) ? src[j] : 0.0;
+          });
+        }
+        // A stage whose matrices equal (bitwise) those of the previous stage
+        // shares its copy: nothing is written for it.
+        bool differs = i == 0;
+        sfor<0, 16>([&](auto Cc_) {
+          constexpr int cc = decltype(Cc_)::value;
+          differs = differs || !(Kr[cc] == lastKr[cc]) || !(ABr[cc] == lastABr[cc]);
+        });
+        sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == lastCc[decltype(Kk)::value]); });
+        sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == lastABc[decltype(J)::value]); });
+  #if defined(FB_R16_NO_SHARED_PACK)
+        differs = true;
+  #endif
+        if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) {
+          canon = i * kPack;
+          stv<pK, 16>(PK, Kr);
+          stv<pABr, 16>(PK, ABr);
+          stv<pC, NC>(PK, Cc);
+          stv<pABc, NX>(PK, ABc);
+          sfor<0, 16>([&](auto Cc_) {
+            lastKr[decltype(Cc_)::value] = Kr[decltype(Cc_)::value];
+            lastABr[decltype(Cc_)::value] = ABr[decltype(Cc_)::value];
+          });
+          sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
+          sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = ABc[decltype(J)::value]; });
+        }
+        po[i] = canon;  // every lane: each later reads its own store
       }
-      po[i] = canon;  // every lane: each later reads its own store
       lds_off = -1;
       // constants f, h, b (mpc_data.cc:240-289)
       const double f = rx ? pq[(long)i * nx_ + r] : (rin ? pr[(long)i * nu_ + ru] : 0.0);

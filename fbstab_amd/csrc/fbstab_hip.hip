@@ -221,11 +221,13 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
 #endif
 // Record-based 16-lane kernel (fb_mpc_r16.h): four QPs per wavefront, rows pull
 // QP indices from the shared counter.  scratch: rows * ws_doubles(N).
-template <int NX, int NU, int NC, bool DBG, bool EXACT>
+// KEEP (FBSTAB_HIP_KEEP_MATRICES): QP q is solved in slot q, so that the slot's
+// matrix copies survive from call to call; `reuse` says they are valid already.
+template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false>
 __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
-    int* counter, int batch, int N, double* dbg) {
-  typedef MpcR16<NX, NU, NC, EXACT> P;
+    int* counter, int batch, int N, int reuse, double* dbg) {
+  typedef MpcR16<NX, NU, NC, EXACT, KEEP> P;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 #if defined(FB_ANY_STAMP)
   const long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
@@ -237,12 +239,20 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
   double* const ws = scratch + ((long)blockIdx.x * 4 + row) * P::ws_doubles(N);
   lds_ptr const lds = (lds_ptr)smem + row * P::kLdsPerRow;
   // Binds the policy to the next QP of the shared queue; -1 when it is empty.
+  bool taken = false;  // (KEEP) this row has had its one QP
   auto next = [&](P& pp) -> int {
     int q = 0;
-    if (ctx.tid == 0) q = atomicAdd(counter, 1);
-    q = bci<0>(q);
+    if constexpr (KEEP) {
+      q = blockIdx.x * 4 + row;
+      if (taken) return -1;
+      taken = true;
+    } else {
+      if (ctx.tid == 0) q = atomicAdd(counter, 1);
+      q = bci<0>(q);
+    }
     if (q >= batch) return -1;
     pp.bind(ws, lds, &data, &x, q, N, ctx.tid);
+    if constexpr (KEEP) pp.reuse = reuse != 0;
     return q;
   };
   if constexpr (DBG) {
@@ -436,6 +446,7 @@ struct fbstab_mpc_solver : SolverBase {
   fbk::MpcLayout lay;
   bool g16 = false;       // 16-lane register kernel (four QPs per wavefront)
   bool r16 = false;       // record-based 16-lane kernel (fb_mpc_r16.h), the default for its shapes
+  int kept_batch = -1;    // batch size of the last FBSTAB_HIP_KEEP_MATRICES call whose copies are still in the slots
   int lds_per_row = 0;
   int qps_per_wg = 1;
 };
@@ -461,7 +472,7 @@ void launch_mpc(fbstab_mpc_solver* h, int grid, hipStream_t s, A... args) {
 }
 template <bool DBG>
 void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArgs& a, const VarBatchArgs& v,
-                fbstab_solver_out_t* out, int batch, double* dbg) {
+                fbstab_solver_out_t* out, int batch, double* dbg, bool keep = false, bool reuse = false) {
   MpcBatchPtrs d;
   VarBatchPtrs x;
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { d.base[i] = a.base[i]; d.stride[i] = a.stride[i]; }
@@ -469,12 +480,25 @@ void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArg
   d.nx = h->lay.nx;
   d.nu = h->lay.nu;
   d.nc = h->lay.nc;
-  if (g16_shape(h->lay.nx, h->lay.nu, h->lay.nc))
+  const bool exact = g16_shape(h->lay.nx, h->lay.nu, h->lay.nc);
+  const int ru = reuse ? 1 : 0;
+  if constexpr (!DBG) {
+    if (keep) {
+      if (exact)
+        hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, true, true>), dim3(grid), dim3(64), h->lds_bytes,
+                           s, d, x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, ru, dbg);
+      else
+        hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, false, true>), dim3(grid), dim3(64), h->lds_bytes,
+                           s, d, x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, ru, dbg);
+      return;
+    }
+  }
+  if (exact)
     hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG, true>), dim3(grid), dim3(64), h->lds_bytes, s, d, x, out,
-                       h->opts, h->scratch, h->counter, batch, h->lay.N, dbg);
+                       h->opts, h->scratch, h->counter, batch, h->lay.N, 0, dbg);
   else
     hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG, false>), dim3(grid), dim3(64), h->lds_bytes, s, d, x,
-                       out, h->opts, h->scratch, h->counter, batch, h->lay.N, dbg);
+                       out, h->opts, h->scratch, h->counter, batch, h->lay.N, 0, dbg);
 }
 }  // namespace
 struct fbstab_dense_solver : SolverBase {
@@ -542,6 +566,11 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
                          : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, true>)
                                   : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>);
   hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  if (e == hipSuccess && s->r16) {
+    const void* kk = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, true>)
+                           : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, true>);
+    e = hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  }
   if (e == hipSuccess) e = hipFuncSetAttribute(kern_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0, cus = 0;
   if (e == hipSuccess)
@@ -646,7 +675,11 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mp
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
   if (h->r16) {
-    launch_r16<false>(h, grid, s, a, v, d_out, batch, nullptr);
+    // FBSTAB_HIP_KEEP_MATRICES: one QP per slot, slot = QP index
+    const bool keep = (flags & FBSTAB_HIP_KEEP_MATRICES) && dev_ptrs && batch <= h->workgroups * h->qps_per_wg;
+    const bool reuse = keep && h->kept_batch == batch;
+    launch_r16<false>(h, keep ? (batch + 3) / 4 : grid, s, a, v, d_out, batch, nullptr, keep, reuse);
+    h->kept_batch = keep ? batch : -1;
   } else {
     launch_mpc(h, grid, s, h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
   }

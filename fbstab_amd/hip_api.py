@@ -22,6 +22,7 @@ DENSE_ARR = ("H", "f", "G", "h", "A", "b")
 HOST_POINTERS = 0
 DEVICE_POINTERS = 1
 ASYNC = 2
+KEEP_MATRICES = 4
 
 EXIT_FLAGS = {0: "SUCCESS", 1: "DIVERGENCE", 2: "MAXITERATIONS", 3: "PRIMAL_INFEASIBLE",
               4: "DUAL_INFEASIBLE", 5: "PRIMAL_DUAL_INFEASIBLE", 6: "SATURATE_ERROR"}
@@ -194,7 +195,7 @@ class _SolverBase:
                     threads=th.value)
 
     def _solve(self, batch_struct, names: Sequence[str], lens: Sequence[int], arrays,
-               var_lens, z, l, v, y, out, stream, async_):
+               var_lens, z, l, v, y, out, stream, async_, keep_matrices=False):
         dev_flags = []
         B = None
         for i, (k, n) in enumerate(zip(names, lens)):
@@ -226,7 +227,7 @@ class _SolverBase:
             if out is None:
                 out = torch.zeros((B, 40), dtype=torch.uint8, device=z.device)
             out_ptr = out.data_ptr()
-            flags = DEVICE_POINTERS | (ASYNC if async_ else 0)
+            flags = DEVICE_POINTERS | (ASYNC if async_ else 0) | (KEEP_MATRICES if keep_matrices else 0)
         else:
             if out is None:
                 out = np.zeros(B, dtype=OUT_DTYPE)
@@ -265,13 +266,15 @@ class FBstabMpcBatch(_SolverBase):
                         (N + 1) * nc * nx, (N + 1) * nc * nu, (N + 1) * nc, nx]
 
     def Solve(self, data: Dict[str, object], z, l, v, y, out=None, stream: int = 0,
-              async_: bool = False):
+              async_: bool = False, keep_matrices: bool = False):
         """``data``: dict of the 12 sequences, each ``(batch, len)`` float64
         (all numpy, or all torch CUDA tensors); ``z,l,v``: initial guess,
-        overwritten with the solution, ``y`` overwritten (fbstab_mpc.h:181-195)."""
+        overwritten with the solution, ``y`` overwritten (fbstab_mpc.h:181-195).
+        ``keep_matrices``: FBSTAB_HIP_KEEP_MATRICES (receding horizon: only
+        q, r, c, d, x0 and the guess changed since the previous flagged call)."""
         return self._solve(_MpcBatch(), MPC_SEQ, self.seq_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
-                           stream, async_)
+                           stream, async_, keep_matrices)
 
 
     def debug_newton(self, data, z, l, v, zb, lb, vb):

@@ -58,7 +58,17 @@ enum fbstab_hip_status {
 enum fbstab_hip_flags {
   FBSTAB_HIP_HOST_POINTERS = 0,
   FBSTAB_HIP_DEVICE_POINTERS = 1,
-  FBSTAB_HIP_ASYNC = 2
+  FBSTAB_HIP_ASYNC = 2,
+  /* Receding-horizon hint (MPC, device pointers): the matrix sequences
+   * Q, R, S, A, B, E, L of every QP of this call are the ones of the previous
+   * call on this handle that carried the flag (same batch size); only
+   * q, r, c, d, x0 and the initial guess may have changed.  The library then
+   * keeps its per-QP copies of the matrices between calls instead of
+   * rebuilding them.  The first flagged call, and a flagged call after an
+   * unflagged one, build them.  Ignored where it cannot be honoured (batch
+   * larger than the resident QP slots, kernels without such copies); results
+   * are the same with or without it. */
+  FBSTAB_HIP_KEEP_MATRICES = 4
 };
 
 /* Index of each MPC sequence in fbstab_mpc_batch_t (FBstabMpc::ProblemData

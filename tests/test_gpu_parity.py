@@ -347,6 +347,51 @@ def test_two_batches_in_flight_equal_one_at_a_time(hip):
         assert torch.equal(res[r][0], z) and torch.equal(res[r][2], v) and torch.equal(res[r][3], y), r
 
 
+def test_keep_matrices_flag_changes_nothing_but_time(hip):
+    """FBSTAB_HIP_KEEP_MATRICES (receding horizon): a closed loop that re-solves
+    with new x0 and the previous solution as the guess gives bitwise the same
+    results whether or not the library keeps its matrix copies between calls,
+    also after an unflagged call in between and after a change of the matrices
+    that is announced by dropping the flag once."""
+    import torch
+    from fbstab_amd import receding_horizon as rh
+    T, S = 96, 5
+    p = fx.synthetic_mpc_batch(T, first_id=31000)
+    N, nx, nu, nc = p.sizes()
+    A, B = fx.quadrotor_model()
+    dev = torch.device("cuda:0")
+    mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+    At, Bt = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+
+    def run(keep_pattern):
+        s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=T)
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        step = [0]
+
+        def solve(x0, z, l, v):
+            k = step[0]
+            step[0] += 1
+            if k == 3:  # the cost changes here; the caller drops the flag for this call
+                data["Q"] = data["Q"] * 1.25
+            data["x0"] = x0.contiguous()
+            y = mk(p.nv)
+            out = hip.out_to_numpy(s.Solve(data, z, l, v, y, keep_matrices=keep_pattern[k]))
+            return z, l, v, y, out
+
+        log = rh.closed_loop(solve, torch.from_numpy(p.arrays["x0"].copy()).to(dev), mk(p.nz), mk(p.nl),
+                             mk(p.nv), At, Bt, nx, nu, S)
+        s.close()
+        return log
+
+    ref = run([False] * S)
+    for pattern in ([True, True, True, False, True], [True, False, True, False, True]):
+        got = run(pattern)
+        for k in range(S):
+            assert np.array_equal(got[k]["out"]["newton_iters"], ref[k]["out"]["newton_iters"]), (pattern, k)
+            assert np.array_equal(got[k]["out"]["eflag"], ref[k]["out"]["eflag"]), (pattern, k)
+            assert torch.equal(got[k]["u0"], ref[k]["u0"]), (pattern, k)
+
+
 # -- edge cases -----------------------------------------------------------------
 def test_warm_start_and_iteration_limits(hip, oracle):
     p = fx.synthetic_mpc_batch(8, first_id=77)

@@ -2,7 +2,7 @@
 """Developer tool: BASELINE config 5 in short form on one GPU - T closed-loop
 trajectories x S warm-started MPC steps (N=30, nx=12, nu=4, nc=20), problem
 data resident on the device, only x0 changing (fbstab_amd/receding_horizon.py).
-argv: trajectories steps [retire]
+argv: trajectories steps [retire] [keep]
 
 With "retire", a trajectory whose QP did not return SUCCESS (the closed loop
 has no terminal constraint, so a few run into infeasible states) is parked at
@@ -21,7 +21,8 @@ from fbstab_amd import fixtures as fx, hip_api, receding_horizon as rh  # noqa: 
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-RETIRE = len(sys.argv) > 3 and sys.argv[3] == "retire"
+RETIRE = "retire" in sys.argv[3:]
+KEEP = "keep" in sys.argv[3:]  # FBSTAB_HIP_KEEP_MATRICES: the matrices do not change between steps
 p = fx.synthetic_mpc_batch(T)
 N, nx, nu, nc = p.sizes()
 A, B = fx.quadrotor_model()
@@ -44,7 +45,7 @@ def solve(x0, z, l, v):
         l[retired] = 0.0
         v[retired] = 0.0
     data["x0"] = x0.contiguous()
-    s.Solve(data, z, l, v, y, out=out_dev)
+    s.Solve(data, z, l, v, y, out=out_dev, keep_matrices=KEEP)
     kernel_ms.append(s.last_kernel_ms())
     o = hip_api.out_to_numpy(out_dev)
     if RETIRE:
