@@ -514,6 +514,36 @@ def test_mixed_outcome_batch(hip, oracle, kats):
     assert np.array_equal(gpu[4]["newton_iters"], cpu[4]["newton_iters"])
 
 
+@pytest.mark.parametrize("kernel", ["r16", "generic"])
+def test_mpc_mixed_outcome_batch(hip, oracle, monkeypatch, kernel):
+    """An MPC batch mixing solvable QPs, one whose factorisation fails (negative
+    input cost: the reference throws out of Solve, fbstab_algorithm-impl.h:263-274;
+    here that QP alone reports DIVERGENCE) and one with contradictory input
+    bounds (primal infeasible): outcomes are per QP, the neighbours are untouched."""
+    _select_kernel(monkeypatch, kernel)
+    p = fx.synthetic_mpc_batch(6, first_id=4242)
+    N, nx, nu, nc = p.sizes()
+    a = {k: v.copy() for k, v in p.arrays.items()}
+    a["R"][1] = -5.0 * a["R"][1]                      # QP 1: R = -0.5 I
+    dd = a["d"].reshape(6, N + 1, nc)
+    dd[3, :, 0] = 1.0                                 # QP 3: u0 <= -1 ...
+    dd[3, :, 4] = 1.0                                 #       ... and -u0 <= -1
+    q = fx.MpcProblem(N, nx, nu, nc)
+    q.arrays = a
+    o = default_options()
+    z, l, v, y, out = _solve_mpc_host(hip, q, o)
+    assert out["eflag"].tolist() == [0, 1, 0, 3, 0, 0]
+    keep = [0, 2, 3, 4, 5]
+    sub = fx.MpcProblem(N, nx, nu, nc)
+    sub.arrays = {k: np.ascontiguousarray(v_[keep]) for k, v_ in a.items()}
+    cpu = oracle.solve_mpc(sub, opts=o)
+    _assert_parity((z[keep], l[keep], v[keep], y[keep], out[keep]), cpu, o.abs_tol)
+    zs, ls, vs, ys, outs = _solve_mpc_host(hip, sub, o)
+    assert np.array_equal(zs, z[keep]) and np.array_equal(outs["newton_iters"], out["newton_iters"][keep])
+    with pytest.raises(RuntimeError):
+        oracle.solve_mpc(q, opts=o)                   # the oracle, like the reference, throws
+
+
 def test_error_behaviour(hip):
     """Constructor / size validation errors of the reference
     (fbstab_mpc.cc:62-65, fbstab_dense.cc:19-23, fbstab_mpc.h:229-242)."""
