@@ -25,6 +25,11 @@
 
 #include "fb_common.h"
 
+// Step lengths evaluated per line-search pass (build knob).
+#ifndef FB_LS_KT
+#define FB_LS_KT 4
+#endif
+
 namespace fbk {
 
 template <class P, class C>
@@ -280,7 +285,7 @@ struct Solver {
       double t = 1.0;
       double Et = sqrt(ti2), Eot = sqrt(to2);
       bool known = true;  // (Et, Eot) belong to the current t
-      constexpr int KT = 4;
+      constexpr int KT = FB_LS_KT;
       double Em[KT], Eom[KT];
       int have = 0, used = 0;  // batch of trial norms for t, t*beta, ...
       for (int j = 0; j < o.max_linesearch_iters; j++) {
@@ -485,7 +490,7 @@ struct Solver {
       double t = 1.0;
       double Et = sqrt(ti2), Eot = sqrt(to2);
       bool known = true;
-      constexpr int KT = 4;
+      constexpr int KT = FB_LS_KT;
       double Em[KT], Eom[KT];
       int have = 0, used = 0;
       for (int j = 0; j < o.max_linesearch_iters; j++) {

@@ -98,7 +98,10 @@ struct Ctx16 {
 // products below spell the order out and fence it.
 #define FB_SB() __builtin_amdgcn_sched_barrier(0)
 
-constexpr int kBcAhead = 4;  // broadcasts in flight ahead of their consumers
+#ifndef FB_BC_AHEAD
+#define FB_BC_AHEAD 4
+#endif
+constexpr int kBcAhead = FB_BC_AHEAD;  // broadcasts in flight ahead of their consumers
 
 // Runs consume(I, mov(I)) for I in [0, CNT) with the mov of I + kBcAhead issued
 // before the consumer of I.
