@@ -138,6 +138,11 @@ struct MpcR16 {
   int* poff;     // per stage: offset (doubles) of the copy it reads
   int lds_off;   // offset of the copy currently in LDS (-1: none)
   bool reuse = false;  // (KEEP instances) the slot's matrix copies are those of this QP already
+  // Every constraint row of every stage has at most one nonzero (bounds on single
+  // states / inputs, the usual MPC constraints): C'Gamma C is then diagonal and
+  // the forward sweep adds it as such.  The skipped products are exact zeros, so
+  // the result equals the general path bit for bit.  Detected while packing.
+  bool bounds = false;
   lds_ptr lds;
   const MpcBatchPtrs* data;  // kernel arguments (uniform)
   const VarBatchPtrs* var;
@@ -308,6 +313,7 @@ struct MpcR16 {
     pend_t = 0.0;
     double* const P0 = pack;
     int* const po = poff;
+    bool single = true;  // no constraint row with two nonzeros seen so far (row-uniform)
     int canon = 0;  // offset of the copy the previous stage uses (row-uniform)
     double lastKr[16], lastABr[16], lastCc[NC], lastABc[NX];  // that copy's values, this lane's share
     sfor<0, 16>([&](auto Cc_) { lastKr[decltype(Cc_)::value] = lastABr[decltype(Cc_)::value] = 0.0; });
@@ -359,6 +365,15 @@ struct MpcR16 {
             ABc[j] = (rs_ && has_ab && j < nx_) ? src[j] : 0.0;
           });
         }
+#if !defined(FB_R16_NO_BOUNDS_PATH)
+        {
+          const int rowsh = 16 * ((threadIdx.x & 63) >> 4);
+          sfor<0, NC>([&](auto Kk) {
+            const unsigned long long m = __ballot(Cc[decltype(Kk)::value] != 0.0);
+            single = single && __popc((unsigned)(m >> rowsh) & 0xffffu) <= 1;
+          });
+        }
+#endif
         // A stage whose matrices equal (bitwise) those of the previous stage
         // shares its copy: nothing is written for it.
         bool differs = i == 0;
@@ -412,6 +427,14 @@ struct MpcR16 {
         st2(R, sDV + 2 * s, 0.0, 0.0);
       });
     }
+#if !defined(FB_R16_NO_BOUNDS_PATH)
+    {
+      bool fresh_all = true;
+      if constexpr (KEEP) fresh_all = !reuse;
+      if (fresh_all) po[N_ + 1] = single ? 1 : 0;  // (kept with the copies for FBSTAB_HIP_KEEP_MATRICES)
+      bounds = po[N_ + 1] != 0;
+    }
+#endif
     c.sync();
   }
 
@@ -955,6 +978,7 @@ struct MpcR16 {
     lds_ptr Tr = lds + kPackLds;
     lds_ptr Cl = lds + kPackLds;
     const bool rx = r < NX;
+    const bool bnd = bounds;
     const double tp = pend_t;  // pending step length
     pend_t = 0.0;
 
@@ -1023,12 +1047,24 @@ struct MpcR16 {
                         });
         r1 = (p[0] + p[1]) + (p[2] + p[3]);
       }
-      sfor<0, NC>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        const double gc = bc<(k & 15)>(Gam[k >> 4]) * Cc_[k];  // Gamma_k C[k][r]
-        bc_pipeline<NS>([&](auto I) { return bc<decltype(I)::value>(Cc_[k]); },
-                        [&](auto I, double t) { K[decltype(I)::value] = fma(gc, t, K[decltype(I)::value]); });
-      });
+      if (bnd) {
+        // one nonzero per constraint row: only the diagonal entry K[r][r] changes
+        double s = 0.0;
+        sfor<0, NS>([&](auto Cc) { s = (ro == decltype(Cc)::value) ? K[decltype(Cc)::value] : s; });
+        sfor<0, NC>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          const double gc = bc<(k & 15)>(Gam[k >> 4]) * Cc_[k];  // Gamma_k C[k][r]
+          s = fma(gc, Cc_[k], s);
+        });
+        sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = (ro == decltype(Cc)::value) ? s : K[decltype(Cc)::value]; });
+      } else {
+        sfor<0, NC>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          const double gc = bc<(k & 15)>(Gam[k >> 4]) * Cc_[k];  // Gamma_k C[k][r]
+          bc_pipeline<NS>([&](auto I) { return bc<decltype(I)::value>(Cc_[k]); },
+                          [&](auto I, double t) { K[decltype(I)::value] = fma(gc, t, K[decltype(I)::value]); });
+        });
+      }
       FB_SB();
       FB_STAMP_LAP(1);
       // theta(i), h(i) = inv(Pi) theta - rx, g = [-h; ru] (:231-236, :252-261)
