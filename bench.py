@@ -100,7 +100,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # under torch.distributed.run the process group (RCCL) is set up even for one
+    # rank, so `--nproc-per-node 1` exercises the same gather path as N > 1
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -131,7 +133,7 @@ def main():
             self.y = self.x[:, p.nz + p.nl + p.nv:]
             self.out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
             self.gx = self.go = None
-            if world > 1 and rank == 0:
+            if dist is not None and rank == 0:
                 self.gx = [torch.empty_like(self.x) for _ in range(world)]
                 self.go = [torch.empty_like(self.out) for _ in range(world)]
             self.events = []
@@ -150,13 +152,13 @@ def main():
             e1.record(ln.stream)
             if timed:
                 ln.events.append((e0, e1))
-            if world > 1:
+            if dist is not None:
                 dist.gather(ln.x, ln.gx, dst=0)
                 dist.gather(ln.out, ln.go, dst=0)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,7 +170,7 @@ def main():
         step(k, True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -193,7 +195,7 @@ def main():
                                    "N=30 nx=12 nu=4 nc=20, cold start, default options",
                        "batch_per_gpu": B, "global_batch": world * B, "steps_in_flight": P,
                        "parallelism": f"batch sharded over {world} GPU(s)" +
-                                      (", RCCL gather to rank 0" if world > 1 else "")},
+                                      (", RCCL gather to rank 0" if dist is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(B),
@@ -214,7 +216,7 @@ def main():
         elif world > 1:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
