@@ -32,13 +32,100 @@
 
 namespace fbk {
 
-template <class P, class C>
-struct Solver {
+// TRACE: the kernel instance behind fbstab_hip_*_solve_traced.  It records the
+// numbers of every display line of the reference (PrintIterLine,
+// PrintDetailed*, PrintFinal; impl:411-541) into `tr` as fbstab_trace_record_t,
+// in the order the reference prints them.  tr[0] counts records, tr[1] is the
+// capacity, records start at tr + 8.  The component norms need extra passes over
+// the vectors, so only the flat-vector policies (fb_mpc.h, fb_dense.h) have a
+// traced instance; the batch kernels are compiled without any of it.
+template <bool TRACE>
+struct TraceState {};
+template <>
+struct TraceState<true> {
+  double* tr = nullptr;
+  // |rz|, |rl|, |rv| of the reference's rk_ and ri_ objects and ri_->Norm() as the
+  // reference would hold them at this point (line-search trials overwrite ri_, impl:289)
+  mutable double rkc[3] = {0.0, 0.0, 0.0}, ric[3] = {0.0, 0.0, 0.0}, ri_norm = 0.0;
+  mutable double step_t = 1.0, combo = 0.0;
+};
+// Kernel argument carrying the trace buffer (empty for the untraced instances).
+template <bool TRACE>
+struct TraceArg {
+  FB_DEV double* get() const { return nullptr; }
+};
+template <>
+struct TraceArg<true> {
+  double* p;
+  FB_DEV double* get() const { return p; }
+};
+
+template <class P, class C, bool TRACE = false>
+struct Solver : TraceState<TRACE> {
   P& p;
   const C& c;
   const fbstab_options_t& o;
 
-  FB_DEV Solver(P& p_, const C& c_, const fbstab_options_t& o_) : p(p_), c(c_), o(o_) {}
+  FB_DEV Solver(P& p_, const C& c_, const fbstab_options_t& o_, double* tr_ = nullptr)
+      : p(p_), c(c_), o(o_) {
+    static_assert(!TRACE || (!P::kOwnVectorOps && !P::kFusedTrial), "no traced instance of this policy");
+    if constexpr (TRACE) this->tr = tr_;
+  }
+
+  FB_DEV void emit(int kind, int i0, int i1, double v0 = 0.0, double v1 = 0.0, double v2 = 0.0,
+                   double v3 = 0.0, double v4 = 0.0) const {
+    if constexpr (TRACE) {
+      if (c.tid == 0) {
+        double* tr = this->tr;
+        const int n = (int)tr[0];
+        if (n < (int)tr[1]) {
+          double* r = tr + 8 + 8 * (long)n;
+          r[0] = kind; r[1] = i0; r[2] = i1;
+          r[3] = v0; r[4] = v1; r[5] = v2; r[6] = v3; r[7] = v4;
+        }
+        tr[0] = n + 1;
+      }
+    }
+  }
+  // Component norms of the penalised natural residual at x (rk_, full_residual.cc:99-109).
+  FB_DEV void trace_rk() const {
+    if constexpr (TRACE) {
+      double s[3] = {0.0, 0.0, 0.0};
+      for (int i = c.tid; i < p.nz; i += C::nt) s[0] += p.rz[i] * p.rz[i];
+      for (int i = c.tid; i < p.nl; i += C::nt) s[1] += p.rl[i] * p.rl[i];
+      for (int i = c.tid; i < p.nv; i += C::nt) {
+        const double r = pnr(p.y[i], p.v[i], o.alpha);
+        s[2] += r * r;
+      }
+      c.sum(s);
+      for (int k = 0; k < 3; k++) this->rkc[k] = sqrt(s[k]);
+    }
+  }
+  // Component norms of the inner residual at x (ri_, full_residual.cc:49-74).
+  FB_DEV void trace_ri(double sigma) const {
+    if constexpr (TRACE) {
+      double s[3] = {0.0, 0.0, 0.0};
+      for (int i = c.tid; i < p.nz; i += C::nt) {
+        const double r = p.rz[i] + sigma * (p.z[i] - p.zb[i]);
+        s[0] += r * r;
+      }
+      for (int i = c.tid; i < p.nl; i += C::nt) {
+        const double r = p.rl[i] + sigma * (p.l[i] - p.lb[i]);
+        s[1] += r * r;
+      }
+      for (int i = c.tid; i < p.nv; i += C::nt) {
+        const double r = pfb(p.y[i] + sigma * (p.v[i] - p.vb[i]), p.v[i], o.alpha);
+        s[2] += r * r;
+      }
+      c.sum(s);
+      for (int k = 0; k < 3; k++) this->ric[k] = sqrt(s[k]);
+    }
+  }
+  FB_DEV void emit_iter_line(int prox, int newton, double inner_tol) const {  // impl:411-426
+    if constexpr (TRACE)
+      emit(FBSTAB_TRACE_ITER_LINE, prox, newton, this->rkc[0], this->rkc[1], this->rkc[2], this->ri_norm,
+           inner_tol);
+  }
 
   // sqrt(sum rz^2 + sum rl^2 + sum pnr(y,v)^2): norm of the penalised natural
   // residual at the current x (full_residual.cc:99-109, :40-42).
@@ -196,10 +283,19 @@ struct Solver {
       double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       double Eo = 0.0;
       FB_STAMP_DECL;
+      if constexpr (TRACE) this->step_t = 1.0;  // impl:236
       for (int i = 0; i < o.max_inner_iters; i++) {
         double Ei;
         norms_at(0.0, sigma, true, &Ei, &Eo);
         *rk_last = Eo;
+        if constexpr (TRACE) {  // impl:250-257
+          trace_ri(sigma);
+          trace_rk();
+          this->ri_norm = Ei;
+          emit(FBSTAB_TRACE_DETAILED_LINE, i, 0, this->step_t, this->ric[0], this->ric[1], this->ric[2]);
+          if ((Ei <= tol && Eo < Ek) || (Ei <= o.inner_tol_min))
+            emit(FBSTAB_TRACE_DETAILED_FOOTER, 0, 0, Ei, tol);
+        }
         if ((Ei <= tol && Eo < Ek) || (Ei <= o.inner_tol_min)) break;
         if (*newton_iters >= o.max_newton_iters) break;
         FB_STAMP_LAP(16);
@@ -223,10 +319,12 @@ struct Solver {
         for (int j = 0; j < o.max_linesearch_iters; j++) {
           double Et, unused;
           norms_at(t, sigma, false, &Et, &unused);
+          if constexpr (TRACE) this->ri_norm = Et;
           const double mp = 0.5 * Et * Et;
           if (mp <= m0 - 2.0 * t * o.eta * cm) break;
           t *= o.beta;
         }
+        if constexpr (TRACE) this->step_t = t;
         accept(t);
         FB_STAMP_LAP(18);
       }
@@ -549,6 +647,10 @@ struct Solver {
     double dx_norm = sqrt((double)p.num_primal_dual());  // dx.Fill(1) (impl:142)
     double Ek, Ei0;
     open_prox(sigma, &Ek, &Ei0);
+    if constexpr (TRACE) {
+      this->combo = combo_tol;
+      trace_rk();
+    }
     const double E0 = Ek;
     double rk_last = Ek;
     int newton = 0, prox = 0;
@@ -565,12 +667,19 @@ struct Solver {
     bool done = false;
     for (int k = 0; k < o.max_prox_iters && !done; k++) {
       rk_last = Ek;
+      [[maybe_unused]] double rk_top[3];
+      if constexpr (TRACE) {
+        for (int j = 0; j < 3; j++) rk_top[j] = this->rkc[j];
+      }
       if (Ek <= combo_tol || dx_norm <= o.stall_tol) {
+        emit_iter_line(prox, newton, inner_tol);  // impl:165
         eflag = FBSTAB_SUCCESS;
         p.write_x(c);
         done = true;
         break;
       }
+      if constexpr (TRACE) emit(FBSTAB_TRACE_DETAILED_HEADER, prox, newton, Ek);  // impl:171
+      emit_iter_line(prox, newton, inner_tol);                                    // impl:172
       if (o.inner_tol_min > Ek) {  // tools::saturate(lo > hi) throws (impl:179-180)
         eflag = FBSTAB_SATURATE_ERROR;
         p.write_x(c);
@@ -594,9 +703,13 @@ struct Solver {
         if (Eo < Ek) {
           p.residual(c);
           rk_last = pnr_norm();
+          trace_rk();
           p.write_x(c);
         } else {
           rk_last = Ek;
+          if constexpr (TRACE) {
+            for (int j = 0; j < 3; j++) this->rkc[j] = rk_top[j];
+          }
           p.write_xbar(c);
         }
         done = true;
@@ -617,6 +730,7 @@ struct Solver {
       // xbar <- x and the residual at the projected x(k+1): serves the next
       // loop-top test (impl:162-163) and the first inner iteration (impl:239-243).
       open_prox(sigma, &Ek, &Ei0);
+      trace_rk();
     }
     if (!done) {
       // Timeout exit (impl:219-223): residual is whatever rk last held.
@@ -691,6 +805,8 @@ struct Solver {
   }
   FB_DEV void finish(fbstab_solver_out_t* out, int eflag, double residual, int newton,
                      int prox, double E0) const {
+    if constexpr (TRACE)  // impl:381, :493-541
+      emit(FBSTAB_TRACE_FINAL, eflag, 0, this->rkc[0], this->rkc[1], this->rkc[2], this->combo);
     if (c.tid == 0) {
       out->eflag = eflag;
       out->pad_ = 0;

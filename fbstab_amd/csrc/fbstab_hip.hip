@@ -132,7 +132,9 @@ __device__ __forceinline__ MpcData mpc_data_of(const MpcBatchArgs& data, long q)
 #ifndef FB_MPC_MIN_WAVES
 #define FB_MPC_MIN_WAVES 1
 #endif
-template <int NT, bool DBG>
+// DBG: the Newton-step probe; TRACE: `dbg` is the trace buffer of
+// fbstab_hip_mpc_solve_traced (see Solver in fb_algorithm.h).
+template <int NT, bool DBG, bool TRACE = false>
 __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLayout lay, MpcBatchArgs data,
                                                         VarBatchArgs x,
                                                         fbstab_solver_out_t* out,
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
     if constexpr (DBG) {
       newton_probe(p, ctx, opts, dbg);
     } else {
-      Solver<MpcProblem<C>, C> solver(p, ctx, opts);
+      Solver<MpcProblem<C>, C, TRACE> solver(p, ctx, opts, dbg);
       solver.solve(out + q);
     }
     ctx.sync();
@@ -278,12 +280,12 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
 #endif
 }
 
-template <int NT>
+template <int NT, bool TRACE = false>
 __global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, DenseBatchArgs data,
                                                           VarBatchArgs x,
                                                           fbstab_solver_out_t* out,
                                                           fbstab_options_t opts, int* counter,
-                                                          int batch) {
+                                                          int batch, TraceArg<TRACE> trace) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   FB_WAVE_TIMER(28);  // total wave cycles (diagnostic builds)
   lds_ptr lds = (lds_ptr)smem;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, Dense
     DenseProblem<C> p;
     p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
            x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds);
-    Solver<DenseProblem<C>, C> solver(p, ctx, opts);
+    Solver<DenseProblem<C>, C, TRACE> solver(p, ctx, opts, trace.get());
     solver.solve(out + q);
     ctx.sync();
   }
@@ -428,6 +430,42 @@ struct SolverBase {
     if (hipEventSynchronize(ev1) != hipSuccess) return -1.0;
     if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.0;
     return (double)ms;
+  }
+};
+
+// Device allocation released at scope exit.
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// Device side of fbstab_hip_*_solve_traced: 8 header doubles (record count,
+// capacity) followed by the records (see Solver::emit in fb_algorithm.h).
+struct TraceBuf {
+  DevBuf buf;
+  double* dev() const { return static_cast<double*>(buf.p); }
+  int open(int device, const fbstab_trace_record_t* trace, int capacity, const int* count) {
+    static_assert(sizeof(fbstab_trace_record_t) == 8 * sizeof(double), "record = 8 doubles");
+    if (!trace || !count || capacity < 1)
+      return fail(FBSTAB_HIP_ERR_ARGUMENT, "trace buffer, its capacity and the count pointer are required");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(&buf.p, sizeof(double) * 8 * ((size_t)capacity + 1)));
+    const double hdr[8] = {0.0, (double)capacity, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    HIP_TRY(hipMemcpy(buf.p, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+    return FBSTAB_HIP_OK;
+  }
+  // the solve has synchronised its stream by now (host-pointer call)
+  int close(fbstab_trace_record_t* trace, int capacity, int* count) {
+    double hdr[8];
+    HIP_TRY(hipMemcpy(hdr, buf.p, sizeof(hdr), hipMemcpyDeviceToHost));
+    *count = (int)hdr[0];
+    const int n = *count < capacity ? *count : capacity;
+    if (n > 0)
+      HIP_TRY(hipMemcpy(trace, dev() + 8, sizeof(fbstab_trace_record_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return FBSTAB_HIP_OK;
   }
 };
 
@@ -628,9 +666,11 @@ int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t h, fbstab_options_t* o) {
   return FBSTAB_HIP_OK;
 }
 
-int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
-                               const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
-                               void* stream) {
+// solve_batch; with d_trace != nullptr the ONE QP of the call runs on the traced
+// instance of the flat-vector kernel instead (fbstab_hip_mpc_solve_traced).
+static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
+                          const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
+                          void* stream, double* d_trace) {
   int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
   if (rc != FBSTAB_HIP_OK) return rc;
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
@@ -674,7 +714,18 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mp
   int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  if (h->r16) {
+  DevBuf tmp_ws;
+  if (d_trace) {
+    const int lds = h->lay.lds_doubles * (int)sizeof(double);
+    if (h->lay.nx > kMpcThreads || lds > kLdsLimitBytes)
+      return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "stage matrices do not fit the 160 KiB LDS budget");
+    auto kern = fbstab_mpc_kernel<kMpcThreads, false, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipMalloc(&tmp_ws.p, sizeof(double) * (size_t)h->lay.ws_doubles));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kMpcThreads), lds, s, h->lay, a, v, d_out, h->opts,
+                       static_cast<double*>(tmp_ws.p), h->counter, 1, d_trace);
+  } else if (h->r16) {
     // FBSTAB_HIP_KEEP_MATRICES: one QP per slot, slot = QP index
     const bool keep = (flags & FBSTAB_HIP_KEEP_MATRICES) && dev_ptrs && batch <= h->workgroups * h->qps_per_wg;
     const bool reuse = keep && h->kept_batch == batch;
@@ -700,6 +751,24 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mp
     HIP_TRY(hipStreamSynchronize(s));
   }
   return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
+                               const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
+                               void* stream) {
+  return mpc_solve_impl(h, batch, data, x, out, flags, stream, nullptr);
+}
+
+int fbstab_hip_mpc_solve_traced(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t* data,
+                                const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                fbstab_trace_record_t* trace, int capacity, int* count) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  TraceBuf tb;
+  int rc = tb.open(h->device, trace, capacity, count);
+  if (rc != FBSTAB_HIP_OK) return rc;
+  rc = mpc_solve_impl(h, 1, data, x, out, FBSTAB_HIP_HOST_POINTERS, nullptr, tb.dev());
+  if (rc != FBSTAB_HIP_OK) return rc;
+  return tb.close(trace, capacity, count);
 }
 
 // Diagnostics for the tests: one Newton step of the device path at (x, xbar,
@@ -846,9 +915,9 @@ int fbstab_hip_dense_get_options(fbstab_dense_handle_t h, fbstab_options_t* o) {
   return FBSTAB_HIP_OK;
 }
 
-int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t h, int batch,
-                                 const fbstab_dense_batch_t* data, const fbstab_var_batch_t* x,
-                                 fbstab_solver_out_t* out, int flags, void* stream) {
+static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_dense_batch_t* data,
+                            const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
+                            void* stream, double* d_trace) {
   int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
   if (rc != FBSTAB_HIP_OK) return rc;
   for (int i = 0; i < FBSTAB_DENSE_NARR; i++)
@@ -892,8 +961,16 @@ int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t h, int batch,
   HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
   int grid = h->workgroups < batch ? h->workgroups : batch;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(fbstab_dense_kernel<kDenseThreads>, dim3(grid), dim3(h->threads), h->lds_bytes, s,
-                     h->lay, a, v, d_out, h->opts, h->counter, batch);
+  if (d_trace) {
+    auto kern = fbstab_dense_kernel<kDenseThreads, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a, v, d_out, h->opts,
+                       h->counter, 1, TraceArg<true>{d_trace});
+  } else {
+    hipLaunchKernelGGL(fbstab_dense_kernel<kDenseThreads>, dim3(grid), dim3(h->threads), h->lds_bytes, s,
+                       h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>());
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
@@ -911,6 +988,24 @@ int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t h, int batch,
     HIP_TRY(hipStreamSynchronize(s));
   }
   return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t h, int batch,
+                                 const fbstab_dense_batch_t* data, const fbstab_var_batch_t* x,
+                                 fbstab_solver_out_t* out, int flags, void* stream) {
+  return dense_solve_impl(h, batch, data, x, out, flags, stream, nullptr);
+}
+
+int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t h, const fbstab_dense_batch_t* data,
+                                  const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                  fbstab_trace_record_t* trace, int capacity, int* count) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  TraceBuf tb;
+  int rc = tb.open(h->device, trace, capacity, count);
+  if (rc != FBSTAB_HIP_OK) return rc;
+  rc = dense_solve_impl(h, 1, data, x, out, FBSTAB_HIP_HOST_POINTERS, nullptr, tb.dev());
+  if (rc != FBSTAB_HIP_OK) return rc;
+  return tb.close(trace, capacity, count);
 }
 
 double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t h) { return h ? h->last_kernel_ms() : -1.0; }

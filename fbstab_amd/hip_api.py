@@ -112,6 +112,8 @@ def load_library() -> C.CDLL:
             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         getattr(lib, f"fbstab_hip_{kind}_query").argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_solve_traced").argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
     lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
     _lib = lib
@@ -122,9 +124,10 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_last_error", "fbstab_hip_device_count",
     "fbstab_hip_mpc_create", "fbstab_hip_mpc_destroy", "fbstab_hip_mpc_set_options",
     "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch",
+    "fbstab_hip_mpc_solve_traced",
     "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
-    "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch",
+    "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_traced",
     "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
 
 
@@ -240,6 +243,35 @@ class _SolverBase:
         return out
 
 
+def _solve_traced(self, batch_struct, names, lens, arrays, var_lens, z, l, v, y, capacity):
+    """fbstab_hip_*_solve_traced for ONE QP in (1, n) numpy arrays.  Returns
+    ``(out, records)``; records is ``(n, 8)``: kind, i0, i1, v0..v4
+    (fbstab_trace_record_t, include/fbstab_types.h)."""
+    for i, (k, n) in enumerate(zip(names, lens)):
+        if n == 0:
+            batch_struct.base[i], batch_struct.stride[i] = None, 0
+            continue
+        p, st, d = _ptr_stride(arrays[k], n)
+        assert not d and arrays[k].shape[0] == 1
+        batch_struct.base[i], batch_struct.stride[i] = p, st
+    vb = _VarBatch()
+    for i, (a, n) in enumerate(zip((z, l, v, y), var_lens)):
+        if n == 0:
+            vb.base[i], vb.stride[i] = None, 0
+            continue
+        p, st, d = _ptr_stride(a, n)
+        assert not d and a.shape[0] == 1
+        vb.base[i], vb.stride[i] = p, st
+    out = np.zeros(1, dtype=OUT_DTYPE)
+    rec = np.zeros((capacity, 8))
+    count = C.c_int(0)
+    rc = getattr(self._lib, f"fbstab_hip_{self._kind}_solve_traced")(
+        self._h, C.byref(batch_struct), C.byref(vb), out.ctypes.data, rec.ctypes.data, capacity,
+        C.byref(count))
+    _check(self._lib, rc)
+    return out, rec[:min(count.value, capacity)].copy()
+
+
 def out_to_numpy(out) -> np.ndarray:
     """SolverOut records (numpy structured array) from a solve's ``out``."""
     if _is_torch(out):
@@ -275,6 +307,12 @@ class FBstabMpcBatch(_SolverBase):
         return self._solve(_MpcBatch(), MPC_SEQ, self.seq_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
                            stream, async_, keep_matrices)
+
+    def SolveTraced(self, data, z, l, v, y, capacity: int = 4096):
+        """One QP (``(1, n)`` numpy arrays) with the reference's per-iteration
+        display returned as records (fbstab_hip_mpc_solve_traced)."""
+        return _solve_traced(self, _MpcBatch(), MPC_SEQ, self.seq_len, data,
+                             (self.nz, self.nl, self.nv, self.nv), z, l, v, y, capacity)
 
 
     def debug_newton(self, data, z, l, v, zb, lb, vb):
@@ -326,3 +364,9 @@ class FBstabDenseBatch(_SolverBase):
         return self._solve(_DenseBatch(), DENSE_ARR, self.arr_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
                            stream, async_)
+
+    def SolveTraced(self, data, z, l, v, y, capacity: int = 4096):
+        """One QP (``(1, n)`` numpy arrays) with the reference's per-iteration
+        display returned as records (fbstab_hip_dense_solve_traced)."""
+        return _solve_traced(self, _DenseBatch(), DENSE_ARR, self.arr_len, data,
+                             (self.nz, self.nl, self.nv, self.nv), z, l, v, y, capacity)

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <stdexcept>
+#include <vector>
 #include <string>
 
 #include "../fbstab_types.h"
@@ -109,33 +110,108 @@ inline SolverOut FromC(const fbstab_solver_out_t& c) {
   return o;
 }
 
-// PrintFinal (impl:485-541) for Display::FINAL and above; the per-iteration
-// levels are not produced by the device path.
-template <class OutStream>
-void PrintFinal(const SolverOut& s, const AlgorithmParameters& p, const OutStream& os) {
-  if (p.display_level < Display::FINAL) return;
-  char buff[100];
-  const char* msg = " Undefined\n";
-  switch (s.eflag) {
-    case ExitFlag::SUCCESS: msg = " Success\n"; break;
-    case ExitFlag::DIVERGENCE: msg = " Divergence\n"; break;
-    case ExitFlag::MAXITERATIONS: msg = " Iteration limit exceeded\n"; break;
-    case ExitFlag::PRIMAL_INFEASIBLE: msg = " Primal Infeasibility\n"; break;
-    case ExitFlag::DUAL_INFEASIBLE: msg = " Dual Infeasibility\n"; break;
-    case ExitFlag::PRIMAL_DUAL_INFEASIBLE: msg = " Primal-Dual Infeasibility\n"; break;
+// The display of the reference (fbstab_algorithm-impl.h:411-541).
+//
+// Display::FINAL (batch path): the summary block with the total residual, which
+// is what SolverOut carries.  Display::ITER / ITER_DETAILED: Solve() runs
+// fbstab_hip_*_solve_traced and PrintTrace() formats the records it returns,
+// line for line as the reference prints them, including the |rz| |rl| |rv|
+// columns of the summary block.
+inline const char* ExitMessage(ExitFlag e) {
+  switch (e) {
+    case ExitFlag::SUCCESS: return " Success\n";
+    case ExitFlag::DIVERGENCE: return " Divergence\n";
+    case ExitFlag::MAXITERATIONS: return " Iteration limit exceeded\n";
+    case ExitFlag::PRIMAL_INFEASIBLE: return " Primal Infeasibility\n";
+    case ExitFlag::DUAL_INFEASIBLE: return " Dual Infeasibility\n";
+    case ExitFlag::PRIMAL_DUAL_INFEASIBLE: return " Primal-Dual Infeasibility\n";
   }
+  return " Undefined\n";
+}
+
+// Head of the summary block (impl:497-531).
+template <class OutStream>
+void PrintSummaryHead(const SolverOut& s, const AlgorithmParameters& p, const OutStream& os) {
+  char buff[100];
   os.Print("\nOptimization completed!  Exit code:");
-  os.Print(msg);
+  os.Print(ExitMessage(s.eflag));
   snprintf(buff, 100, "Time elapsed: %f ms (-1.0 indicates timing disabled)\n", 1000.0 * s.solve_time);
   os.Print(buff);
   snprintf(buff, 100, "Proximal iterations: %d out of %d\n", s.prox_iters, p.max_prox_iters);
   os.Print(buff);
   snprintf(buff, 100, "Newton iterations: %d out of %d\n", s.newton_iters, p.max_newton_iters);
   os.Print(buff);
+}
+
+template <class OutStream>
+void PrintFinal(const SolverOut& s, const AlgorithmParameters& p, const OutStream& os) {
+  if (p.display_level < Display::FINAL) return;
+  char buff[100];
+  PrintSummaryHead(s, p, os);
   snprintf(buff, 100, "%10s  %10s\n", "|r|", "Tolerance");
   os.Print(buff);
   snprintf(buff, 100, "%10.4e  %10.4e\n\n", s.residual, p.abs_tol);
   os.Print(buff);
+}
+
+// Number of records one solve can produce: two per proximal iteration, one per
+// inner-loop pass (at most one more pass than Newton steps per subproblem), one
+// footer per subproblem, the summary.
+inline int TraceCapacity(const AlgorithmParameters& p) {
+  return 8 + 4 * (p.max_prox_iters + 1) + p.max_newton_iters + p.max_prox_iters * 2;
+}
+
+template <class OutStream>
+void PrintTrace(const fbstab_trace_record_t* rec, int n, const SolverOut& s,
+                const AlgorithmParameters& p, const OutStream& os) {
+  char buff[100];
+  const bool iter = p.display_level == Display::ITER;
+  const bool detailed = p.display_level == Display::ITER_DETAILED;
+  if (iter) {  // PrintIterHeader, impl:429-441
+    snprintf(buff, 100, "%12s  %12s  %12s  %12s  %12s  %12s  %12s\n", "prox iter", "newton iters", "|rz|",
+             "|rl|", "|rv|", "Inner res", "Inner tol");
+    os.Print(buff);
+  }
+  for (int k = 0; k < n; k++) {
+    const fbstab_trace_record_t& r = rec[k];
+    const int i0 = static_cast<int>(r.i0), i1 = static_cast<int>(r.i1);
+    switch (static_cast<int>(r.kind)) {
+      case FBSTAB_TRACE_ITER_LINE:  // impl:411-426
+        if (!iter) break;
+        snprintf(buff, 100, "%12d  %12d  %12.4e  %12.4e  %12.4e  %12.4e  %12.4e\n", i0, i1, r.v[0], r.v[1],
+                 r.v[2], r.v[3], r.v[4]);
+        os.Print(buff);
+        break;
+      case FBSTAB_TRACE_DETAILED_HEADER:  // impl:443-458
+        if (!detailed) break;
+        snprintf(buff, 100, "Begin Prox Iter: %d, Total Newton Iters: %d, Residual: %6.4e\n", i0, i1, r.v[0]);
+        os.Print(buff);
+        snprintf(buff, 100, "%10s  %10s  %10s  %10s  %10s\n", "Iter", "Step Size", "|rz|", "|rl|", "|rv|");
+        os.Print(buff);
+        break;
+      case FBSTAB_TRACE_DETAILED_LINE:  // impl:460-471
+        if (!detailed) break;
+        snprintf(buff, 100, "%10d  %10e  %10e  %10e  %10e\n", i0, r.v[0], r.v[1], r.v[2], r.v[3]);
+        os.Print(buff);
+        break;
+      case FBSTAB_TRACE_DETAILED_FOOTER:  // impl:473-488
+        if (!detailed) break;
+        snprintf(buff, 100, "Exiting inner loop. Inner residual: %6.4e, Inner tolerance: %6.4e\n", r.v[0],
+                 r.v[1]);
+        os.Print(buff);
+        break;
+      case FBSTAB_TRACE_FINAL:  // impl:490-541
+        PrintSummaryHead(s, p, os);
+        snprintf(buff, 100, "%10s  %10s  %10s  %10s\n", "|rz|", "|rl|", "|rv|", "Tolerance");
+        os.Print(buff);
+        snprintf(buff, 100, "%10.4e  %10.4e  %10.4e  %10.4e\n", r.v[0], r.v[1], r.v[2], r.v[3]);
+        os.Print(buff);
+        os.Print("\n");
+        break;
+      default:
+        break;
+    }
+  }
 }
 
 }  // namespace detail

@@ -107,6 +107,18 @@ class FBstabDense {
     v.base[0] = x->z.data(); v.base[1] = x->l.data(); v.base[2] = x->v.data(); v.base[3] = x->y.data();
     v.stride[0] = nz_; v.stride[1] = nl_; v.stride[2] = nv_; v.stride[3] = nv_;
     fbstab_solver_out_t out;
+    if (opts_.display_level >= Display::ITER) {
+      // per-iteration display (impl:411-488): the traced solve returns its lines as records
+      std::vector<fbstab_trace_record_t> rec(detail::TraceCapacity(opts_));
+      int n = 0;
+      if (fbstab_hip_dense_solve_traced(h_, &b, &v, &out, rec.data(), static_cast<int>(rec.size()), &n) !=
+          FBSTAB_HIP_OK)
+        throw std::runtime_error(std::string("In FBstabDense::Solve: ") + fbstab_hip_last_error());
+      SolverOut st = detail::FromC(out);
+      if (n > static_cast<int>(rec.size())) n = static_cast<int>(rec.size());
+      detail::PrintTrace(rec.data(), n, st, opts_, os);
+      return st;
+    }
     if (fbstab_hip_dense_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_HOST_POINTERS, nullptr) != FBSTAB_HIP_OK)
       throw std::runtime_error(std::string("In FBstabDense::Solve: ") + fbstab_hip_last_error());
     SolverOut s = detail::FromC(out);

@@ -14,10 +14,15 @@
  *   fbstab_hip_mpc_solve_batch          FBstabMpc::Solve(qp, &x), fbstab_mpc.h:181-195
  *                                       (batch == 1 with host pointers is exactly one
  *                                       reference Solve call)
+ *   fbstab_hip_mpc_solve_traced         the same Solve with Display::ITER / ITER_DETAILED:
+ *                                       the numbers of PrintIterLine, PrintDetailedHeader/
+ *                                       Line/Footer and PrintFinal
+ *                                       (fbstab_algorithm-impl.h:411-541) as records
  *   fbstab_hip_dense_create / _destroy  FBstabDense::FBstabDense(nz,nl,nv),
  *                                       fbstab/fbstab_dense.h:122, fbstab_dense.cc:18-42
  *   fbstab_hip_dense_set_options        FBstabDense::UpdateOptions, fbstab_dense.h:158
  *   fbstab_hip_dense_solve_batch        FBstabDense::Solve(qp, &x), fbstab_dense.h:136-149
+ *   fbstab_hip_dense_solve_traced       as fbstab_hip_mpc_solve_traced
  *
  * Data layout is the reference's: every MPC sequence is a MatrixSequence image
  * data[k*nr*nc + j*nr + i] (tools/matrix_sequence.h:81-83), dense matrices are
@@ -118,6 +123,20 @@ int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t handle, fbstab_options_t* opt
 int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t handle, int batch,
                                const fbstab_mpc_batch_t* data, const fbstab_var_batch_t* x,
                                fbstab_solver_out_t* out, int flags, void* stream);
+/* ONE QP given by host pointers, solved synchronously, with the per-iteration
+ * display of the reference returned as data: every line the reference's
+ * Display::ITER and ITER_DETAILED levels would print during this solve
+ * (fbstab_algorithm-impl.h:155-172, :250-257, :381) becomes one
+ * fbstab_trace_record_t, in the reference's print order; the caller formats
+ * the kinds its display level shows (the C++ facade does, PrintTrace in
+ * include/fbstab/fbstab_algorithm.h).  At most `capacity` records are stored;
+ * *count receives the number produced.  Runs on the flat-vector kernel (one
+ * QP per wavefront) whatever kernel the handle uses for batches, so iteration
+ * counts can differ from a solve_batch call within the tolerance the parity
+ * tests state. */
+int fbstab_hip_mpc_solve_traced(fbstab_mpc_handle_t handle, const fbstab_mpc_batch_t* data,
+                                const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                fbstab_trace_record_t* trace, int capacity, int* count);
 /* Device time of the solver kernel in the most recent solve_batch call on this
  * handle, measured with HIP events on the stream it ran on (ms; < 0 if none). */
 double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t handle);
@@ -146,6 +165,9 @@ int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t handle, int batch,
                                  const fbstab_dense_batch_t* data,
                                  const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
                                  int flags, void* stream);
+int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t handle, const fbstab_dense_batch_t* data,
+                                  const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                  fbstab_trace_record_t* trace, int capacity, int* count);
 double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t handle);
 int fbstab_hip_dense_query(fbstab_dense_handle_t handle, long long* scratch_bytes,
                            int* lds_bytes, int* workgroups, int* threads);

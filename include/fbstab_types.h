@@ -35,6 +35,35 @@ enum fbstab_display {
   FBSTAB_DISPLAY_ITER_DETAILED = 3
 };
 
+/* One line of the reference's per-iteration display, as data.  The reference
+ * formats these inside the solver loop (PrintIterLine, PrintDetailedHeader,
+ * PrintDetailedLine, PrintDetailedFooter, PrintFinal;
+ * fbstab_algorithm-impl.h:411-541); here the solver records the numbers in the
+ * order the reference would print them and the caller formats the ones its
+ * display level shows (include/fbstab/fbstab_algorithm.h: detail::PrintTrace).
+ *
+ *   kind              i0           i1            v[0..4]
+ *   ITER_LINE         prox_iters   newton_iters  |rz| |rl| |rv| of the outer residual,
+ *                                                inner residual norm, inner tolerance
+ *   DETAILED_HEADER   prox_iters   newton_iters  outer residual norm
+ *   DETAILED_LINE     inner iter   -             step size, |rz| |rl| |rv| of the inner residual
+ *   DETAILED_FOOTER   -            -             inner residual norm, inner tolerance
+ *   FINAL             exit flag    -             |rz| |rl| |rv| of the outer residual, tolerance
+ */
+enum fbstab_trace_kind {
+  FBSTAB_TRACE_ITER_LINE = 1,
+  FBSTAB_TRACE_DETAILED_HEADER = 2,
+  FBSTAB_TRACE_DETAILED_LINE = 3,
+  FBSTAB_TRACE_DETAILED_FOOTER = 4,
+  FBSTAB_TRACE_FINAL = 5
+};
+typedef struct fbstab_trace_record_t {
+  double kind; /* enum fbstab_trace_kind (all fields double: one device store format) */
+  double i0;
+  double i1;
+  double v[5];
+} fbstab_trace_record_t;
+
 /* SolverOut, fbstab/fbstab_algorithm.h:30-37.  Same member order, hence the
  * same 40-byte layout as the reference struct on LP64. */
 typedef struct fbstab_solver_out_t {

@@ -43,6 +43,12 @@ class Algorithm {
     fbstab_options_validate(&opts_);
   }
 
+  // Where the reference prints a display line (PrintIterLine, PrintDetailed*,
+  // PrintFinal; fbstab_algorithm-impl.h:411-541) this restatement appends one
+  // record of 8 doubles [kind, i0, i1, v0..v4] to *sink, whatever the display
+  // level (fbstab_trace_record_t in include/fbstab_types.h names the fields).
+  void SetTraceSink(std::vector<double>* sink) { trace_ = sink; }
+
   // fbstab_algorithm-impl.h:113-224.  z0,l0,v0 in/out; y0 out.
   template <class ProblemData>
   fbstab_solver_out_t Solve(const ProblemData& qp, Vec* z0, Vec* l0, Vec* v0,
@@ -81,10 +87,13 @@ class Algorithm {
       rk_->PenalizedNaturalResidual(*xk_);
       Ek = rk_->Norm();
       if (Ek <= combo_tol_ || dx_->Norm() <= opts_.stall_tol) {
+        EmitIterLine(inner_tol);  // impl:165
         fbstab_solver_out_t out = Output(FBSTAB_SUCCESS, E0);
         Write(*xk_, z0, l0, v0, y0);
         return out;
       }
+      Emit(FBSTAB_TRACE_DETAILED_HEADER, prox_iters_, newton_iters_, rk_->Norm());  // impl:171
+      EmitIterLine(inner_tol);                                                     // impl:172
       inner_tol = saturate(inner_tol * opts_.delta, opts_.inner_tol_min, Ek);
       xi_->Copy(*xk_);
       const double Eo = SolveProximalSubproblem(xi_, xk_, inner_tol, sigma, Ek);
@@ -129,9 +138,13 @@ class Algorithm {
       const double Ei = ri_->Norm();
       rk_->PenalizedNaturalResidual(*x);
       Eo = rk_->Norm();
+      // impl:250-257
+      Emit(FBSTAB_TRACE_DETAILED_LINE, i, 0, t, ri_->z_norm(), ri_->l_norm(), ri_->v_norm());
       if ((Ei <= tol && Eo < current_outer_residual) ||
-          (Ei <= opts_.inner_tol_min))
+          (Ei <= opts_.inner_tol_min)) {
+        Emit(FBSTAB_TRACE_DETAILED_FOOTER, 0, 0, ri_->Norm(), tol);
         break;
+      }
       if (newton_iters_ >= opts_.max_newton_iters) break;
       if (!linear_solver_->Initialize(*x, *xbar, sigma))
         throw std::runtime_error(
@@ -183,6 +196,8 @@ class Algorithm {
   }
   // fbstab_algorithm-impl.h:362-383 (timing filled by the caller)
   fbstab_solver_out_t Output(int eflag, double E0) const {
+    // PrintFinal (impl:381, :493-541)
+    Emit(FBSTAB_TRACE_FINAL, eflag, 0, rk_->z_norm(), rk_->l_norm(), rk_->v_norm(), combo_tol_);
     fbstab_solver_out_t o;
     o.eflag = eflag;
     o.pad_ = 0;
@@ -193,6 +208,17 @@ class Algorithm {
     o.initial_residual = E0;
     return o;
   }
+  void Emit(int kind, int i0, int i1, double v0 = 0, double v1 = 0, double v2 = 0, double v3 = 0,
+            double v4 = 0) const {
+    if (!trace_) return;
+    const double r[8] = {double(kind), double(i0), double(i1), v0, v1, v2, v3, v4};
+    trace_->insert(trace_->end(), r, r + 8);
+  }
+  // PrintIterLine (impl:411-426): ri is whatever the inner loop last left there
+  void EmitIterLine(double inner_tol) const {
+    Emit(FBSTAB_TRACE_ITER_LINE, prox_iters_, newton_iters_, rk_->z_norm(), rk_->l_norm(),
+         rk_->v_norm(), ri_->Norm(), inner_tol);
+  }
   static void Write(const FullVariable& x, Vec* z, Vec* l, Vec* v, Vec* y) {
     *z = x.z();
     *l = x.l();
@@ -200,6 +226,7 @@ class Algorithm {
     *y = x.y();
   }
 
+  std::vector<double>* trace_ = nullptr;
   double combo_tol_ = 0.0;
   int newton_iters_ = 0;
   int prox_iters_ = 0;

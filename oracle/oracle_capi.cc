@@ -16,6 +16,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "oracle_algorithm.h"
 
@@ -59,6 +60,22 @@ fbstab::AlgorithmParameters ToRef(const fbstab_options_t& o) {
   p.display_level = static_cast<fbstab::Display>(o.display_level);
   return p;
 }
+// An output stream of the reference's own kind (tools/output_stream.h:15-37)
+// that collects what the reference prints instead of sending it to stdout.
+class CaptureOutput : public fbstab::OutputStream<CaptureOutput> {
+ public:
+  explicit CaptureOutput(std::string* sink) : sink_(sink) {}
+
+ protected:
+  void PrintImplementation(const char* message) const {
+    if (sink_) sink_->append(message); else printf("%s", message);
+  }
+  friend class fbstab::OutputStream<CaptureOutput>;
+
+ private:
+  std::string* sink_;
+};
+
 fbstab_solver_out_t FromRef(const fbstab::SolverOut& s) {
   fbstab_solver_out_t o;
   o.eflag = static_cast<int>(s.eflag);
@@ -104,6 +121,11 @@ struct Workspace {
 #endif
   }
 
+  // Display capture for the *_solve_display entry points: the reference build
+  // collects the text the reference prints, the restated build the records.
+  std::string* text_sink = nullptr;
+  std::vector<double>* trace_sink = nullptr;
+
   template <class DataT>
   fbstab_solver_out_t Solve(const DataT& data, double* zp, double* lp,
                             double* vp, double* yp) {
@@ -112,9 +134,10 @@ struct Workspace {
     std::copy(vp, vp + v.size(), v.begin());
     const auto t0 = std::chrono::high_resolution_clock::now();
 #ifdef FBO_USE_REFERENCE_ALGORITHM
-    fbstab::StandardOutput os;
+    CaptureOutput os(text_sink);
     fbstab_solver_out_t out = FromRef(alg.Solve(data, &z, &l, &v, &y, os));
 #else
+    alg.SetTraceSink(trace_sink);
     fbstab_solver_out_t out = alg.Solve(data, &z, &l, &v, &y);
 #endif
     const auto t1 = std::chrono::high_resolution_clock::now();
@@ -275,6 +298,81 @@ int fbo_mpc_solve_batch(int batch, int N, int nx, int nu, int nc,
   }
   g_last_error = err;
   return failures;
+}
+
+
+}  // extern "C"
+
+// One QP with its display captured.  The reference-algorithm build returns
+// the text the reference's own Print* functions produce at opts->display_level
+// (fbstab_algorithm-impl.h:411-541) in `text` (NUL-terminated, truncated to
+// text_cap) and no records; the restated build returns the records
+// (fbstab_trace_record_t, 8 doubles each, at most trace_cap of them) and an
+// empty text.  *trace_count is the number of records produced.
+template <class Ws, class DataT>
+static int solve_display(Ws* ws, const DataT& data, double* z, double* l, double* v, double* y,
+                         const fbstab_options_t* opts, fbstab_solver_out_t* out, char* text,
+                         int text_cap, double* trace, int trace_cap, int* trace_count) {
+  std::string txt;
+  std::vector<double> rec;
+  try {
+    ws->SetOptions(opts);
+    ws->text_sink = &txt;
+    ws->trace_sink = &rec;
+    *out = ws->Solve(data, z, l, v, y);
+  } catch (const std::exception& e) {
+    FailOut(out);
+    g_last_error = e.what();
+    return 1;
+  }
+  if (text && text_cap > 0) {
+    const size_t n = std::min(txt.size(), (size_t)text_cap - 1);
+    std::memcpy(text, txt.data(), n);
+    text[n] = 0;
+  }
+  const int nrec = (int)(rec.size() / 8);
+  if (trace_count) *trace_count = nrec;
+  if (trace) std::copy(rec.begin(), rec.begin() + 8 * (size_t)std::min(nrec, trace_cap), trace);
+  return 0;
+}
+
+extern "C" {
+
+int fbo_dense_solve_display(int nz, int nl, int nv, const double* H, const double* f,
+                            const double* G, const double* h, const double* A, const double* b,
+                            double* z, double* l, double* v, double* y,
+                            const fbstab_options_t* opts, fbstab_solver_out_t* out, char* text,
+                            int text_cap, double* trace, int trace_cap, int* trace_count) {
+  try {
+    DenseWs ws(nz, nl, nv, nz, nl, nv);
+    fbo::DenseData data(H, f, G, h, A, b, nz, nl, nv);
+    return solve_display(&ws, data, z, l, v, y, opts, out, text, text_cap, trace, trace_cap,
+                         trace_count);
+  } catch (const std::exception& e) {
+    FailOut(out);
+    g_last_error = e.what();
+    return 1;
+  }
+}
+
+int fbo_mpc_solve_display(int N, int nx, int nu, int nc, const double* Q, const double* R,
+                          const double* S, const double* q, const double* r, const double* A,
+                          const double* B, const double* c, const double* E, const double* L,
+                          const double* d, const double* x0, double* z, double* l, double* v,
+                          double* y, const fbstab_options_t* opts, fbstab_solver_out_t* out,
+                          char* text, int text_cap, double* trace, int trace_cap,
+                          int* trace_count) {
+  try {
+    const int nz = (N + 1) * (nx + nu), nl = (N + 1) * nx, nv = (N + 1) * nc;
+    MpcWs ws(nz, nl, nv, N, nx, nu, nc);
+    fbo::MpcData data(Q, R, S, q, r, A, B, c, E, L, d, x0, N, nx, nu, nc);
+    return solve_display(&ws, data, z, l, v, y, opts, out, text, text_cap, trace, trace_cap,
+                         trace_count);
+  } catch (const std::exception& e) {
+    FailOut(out);
+    g_last_error = e.what();
+    return 1;
+  }
 }
 
 }  // extern "C"

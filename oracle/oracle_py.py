@@ -155,6 +155,41 @@ class Oracle:
             raise RuntimeError(self.last_error())
         return z, l, v, y, _out_to_numpy(out)
 
+    def solve_display(self, prob, x0guess=None, opts: Optional[Options] = None,
+                      text_cap: int = 1 << 20, trace_cap: int = 1 << 14):
+        """Solve QP 0 of ``prob`` with its display captured.  Returns
+        ``(z, l, v, y, out, text, records)``: the reference-loop library fills
+        ``text`` with what the reference prints at ``opts.display_level``
+        (fbstab_algorithm-impl.h:411-541), the restated library fills
+        ``records`` (``(n, 8)`` array of fbstab_trace_record_t)."""
+        opts = opts or default_options()
+        z, l, v, y = (np.zeros(n) for n in (prob.nz, prob.nl, prob.nv, prob.nv))
+        if x0guess is not None:
+            z[:], l[:], v[:] = (np.asarray(g, dtype=np.float64).reshape(-1) for g in x0guess)
+        A = {k: np.ascontiguousarray(prob.arrays[k][0], dtype=np.float64) for k in prob.arrays}
+        out = SolverOut()
+        text = C.create_string_buffer(text_cap)
+        rec = np.zeros((trace_cap, 8))
+        nrec = C.c_int(0)
+        tail = (_p(z), _p(l), _p(v), _p(y), C.byref(opts), C.byref(out), text, text_cap,
+                _p(rec), trace_cap, C.byref(nrec))
+        if hasattr(prob, "N"):
+            N, nx, nu, nc = prob.sizes()
+            rc = self.lib.fbo_mpc_solve_display(
+                N, nx, nu, nc, _p(A["Q"]), _p(A["R"]), _p(A["S"]), _p(A["q"]), _p(A["r"]),
+                _p(A["A"]), _p(A["B"]), _p(A["c"]), _p(A["E"]), _p(A["L"]), _p(A["d"]),
+                _p(A["x0"]), *tail)
+        else:
+            G = A["G"] if prob.nl else np.zeros(1)
+            h = A["h"] if prob.nl else np.zeros(1)
+            rc = self.lib.fbo_dense_solve_display(
+                prob.nz, prob.nl, prob.nv, _p(A["H"]), _p(A["f"]), _p(G), _p(h), _p(A["A"]),
+                _p(A["b"]), *tail)
+        if rc:
+            raise RuntimeError(self.last_error())
+        o = _out_to_numpy((SolverOut * 1)(out))
+        return z, l, v, y, o, text.value.decode(), rec[:min(nrec.value, trace_cap)].copy()
+
     # -- component probes -----------------------------------------------------
     def mpc_data_op(self, prob, which: str, x, a=1.0, b=0.0, y=None):
         idx = ["gemvH", "gemvA", "gemvG", "gemvAT", "gemvGT", "axpyf", "axpyh",

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <memory>
 #include <stdexcept>
+#include <string>
 
 #include "fbstab/fbstab_dense.h"
 #include "fbstab/fbstab_mpc.h"
@@ -246,7 +247,63 @@ static void ErrorBehaviour() {
   EXPECT_TRUE(raw.beta == 0.7 && raw.max_newton_iters == 500);  // header initialisers differ
 }
 
-int main() {
+// A stream of the user's own (tools/output_stream.h:15-37) collecting the display.
+class StringOutput : public OutputStream<StringOutput> {
+ public:
+  explicit StringOutput(std::string* s) : s_(s) {}
+
+ protected:
+  void PrintImplementation(const char* message) const { s_->append(message); }
+  friend class OutputStream<StringOutput>;
+
+ private:
+  std::string* s_;
+};
+
+// `facade_tests display`: FeasibleQP and DoubleIntegrator(2) at Display::ITER and
+// ITER_DETAILED (default options), text between markers; tests/test_facade.py
+// compares it with what the reference prints (tests/golden/reference_display.json).
+static int DisplayMode() {
+  const Display levels[2] = {Display::ITER, Display::ITER_DETAILED};
+  for (int k = 0; k < 2; k++) {
+    {
+      FBstabDense::Variable x0(2, 0, 2);
+      FBstabDense::ProblemData data(2, 0, 2);
+      data.H = {3, 1, 1, 1};
+      data.f = {10, 5};
+      data.A = {-1, 0, 0, 1};
+      data.b = {0, 0};
+      FBstabDense solver(2, 0, 2);
+      FBstabDense::Options o = FBstabDense::DefaultOptions();
+      o.display_level = levels[k];
+      solver.UpdateOptions(o);
+      std::string text;
+      StringOutput os(&text);
+      SolverOut out = solver.Solve(data, &x0, os);
+      printf("===BEGIN dense FeasibleQP %d===\n%s===END===\n", static_cast<int>(levels[k]), text.c_str());
+      EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+      EXPECT_NEAR(x0.z(1), -5.0, 1e-5);
+    }
+    {
+      Ocp ocp;
+      ocp.DoubleIntegrator(2);
+      FBstabMpc::Variable x(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+      FBstabMpc solver(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+      FBstabMpc::Options o = FBstabMpc::DefaultOptions();
+      o.display_level = levels[k];
+      solver.UpdateOptions(o);
+      std::string text;
+      StringOutput os(&text);
+      SolverOut out = solver.Solve(ocp.data, &x, os);
+      printf("===BEGIN mpc DoubleIntegrator %d===\n%s===END===\n", static_cast<int>(levels[k]), text.c_str());
+      EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+    }
+  }
+  return g_fail ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "display") return DisplayMode();
   FeasibleQP();
   FeasibleQPwithEQ();
   DegenerateQP();

@@ -83,3 +83,66 @@ def natural_residual_norm(H, f, G, h, A, b, z, l, v):
     rl = h - G @ z
     rv = np.minimum(b - A @ z, v)
     return np.sqrt(rz @ rz + rl @ rl + rv @ rv)
+
+
+# -- the reference's per-iteration display (fbstab_algorithm-impl.h:411-541) ----
+EXIT_MESSAGES = {0: " Success\n", 1: " Divergence\n", 2: " Iteration limit exceeded\n",
+                 3: " Primal Infeasibility\n", 4: " Dual Infeasibility\n",
+                 5: " Primal-Dual Infeasibility\n"}
+
+
+def format_display(records, level, out, opts):
+    """Text of display level ``level`` (2 = ITER, 3 = ITER_DETAILED) from trace
+    records ``(n, 8)`` = kind, i0, i1, v0..v4 (fbstab_trace_record_t) and the
+    SolverOut record ``out``; the wall time is written as ``<t>``."""
+    s = ""
+    if level == 2:
+        s += "%12s  %12s  %12s  %12s  %12s  %12s  %12s\n" % (
+            "prox iter", "newton iters", "|rz|", "|rl|", "|rv|", "Inner res", "Inner tol")
+    for r in records:
+        kind, i0, i1, v = int(r[0]), int(r[1]), int(r[2]), r[3:]
+        if kind == 1 and level == 2:
+            s += "%12d  %12d  %12.4e  %12.4e  %12.4e  %12.4e  %12.4e\n" % (i0, i1, *v[:5])
+        elif kind == 2 and level == 3:
+            s += "Begin Prox Iter: %d, Total Newton Iters: %d, Residual: %6.4e\n" % (i0, i1, v[0])
+            s += "%10s  %10s  %10s  %10s  %10s\n" % ("Iter", "Step Size", "|rz|", "|rl|", "|rv|")
+        elif kind == 3 and level == 3:
+            s += "%10d  %10e  %10e  %10e  %10e\n" % (i0, *v[:4])
+        elif kind == 4 and level == 3:
+            s += "Exiting inner loop. Inner residual: %6.4e, Inner tolerance: %6.4e\n" % (v[0], v[1])
+        elif kind == 5:
+            s += "\nOptimization completed!  Exit code:" + EXIT_MESSAGES[int(out["eflag"])]
+            s += "Time elapsed: <t> ms (-1.0 indicates timing disabled)\n"
+            s += "Proximal iterations: %d out of %d\n" % (out["prox_iters"], opts.max_prox_iters)
+            s += "Newton iterations: %d out of %d\n" % (out["newton_iters"], opts.max_newton_iters)
+            s += "%10s  %10s  %10s  %10s\n" % ("|rz|", "|rl|", "|rv|", "Tolerance")
+            s += "%10.4e  %10.4e  %10.4e  %10.4e\n\n" % tuple(v[:4])
+    return s
+
+
+def normalise_time(text):
+    import re
+    return re.sub(r"Time elapsed: \S+ ms", "Time elapsed: <t> ms", text)
+
+
+def display_texts_agree(a, b, rtol=5e-4, atol=1e-7):
+    """Token-wise comparison of two display texts: words must be equal, numbers
+    agree to ``atol + rtol*|b|`` (the display prints 5 significant digits; atol
+    is 1e-7 of the largest residual of the solve), and numbers below 1e4*atol -
+    residuals left behind by a converged Newton iteration, which squares the
+    rounding differences of the step before - within a factor of two."""
+    import re
+    ta, tb = re.split(r"[\s,]+", a.strip()), re.split(r"[\s,]+", b.strip())
+    if len(ta) != len(tb):
+        return False, "token count %d vs %d" % (len(ta), len(tb))
+    for x, y in zip(ta, tb):
+        try:
+            fx_, fy = float(x), float(y)
+        except ValueError:
+            if x != y:
+                return False, "%r vs %r" % (x, y)
+            continue
+        err = abs(fx_ - fy)
+        if err > atol + rtol * abs(fy) and not (abs(fy) < 1e4 * atol and err <= 0.5 * max(abs(fx_), abs(fy))):
+            return False, "%r vs %r" % (x, y)
+    return True, ""

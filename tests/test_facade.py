@@ -30,3 +30,26 @@ def test_facade_reference_style_tests():
     _build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL FACADE TESTS PASSED" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_iter_display_is_the_reference_display():
+    """Display::ITER / ITER_DETAILED through the facade and a user OutputStream:
+    the text equals what the reference prints for the same problems
+    (tests/golden/reference_display.json, produced by the reference's own print
+    functions), numbers to 5e-4 relative / 1e-7 absolute."""
+    import json
+    import re
+    from tests import helpers as H
+    _build()
+    r = subprocess.run([EXE, "display"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    blocks = re.findall(r"===BEGIN (\w+) (\w+) (\d)===\n(.*?)===END===", r.stdout, flags=re.S)
+    assert len(blocks) == 4
+    with open(os.path.join(ROOT, "tests", "golden", "reference_display.json")) as f:
+        golden = json.load(f)["cases"]
+    for kind, name, level, text in blocks:
+        g = [c for c in golden if (c["kind"], c["name"], c["level"]) == (kind, name, int(level))
+             and c["index"] == 0][0]
+        ok, why = H.display_texts_agree(H.normalise_time(text), g["text"])
+        assert ok, (kind, name, level, why, text)

@@ -32,34 +32,43 @@ data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.array
 mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
 y = mk(p.nv)
 out_dev = torch.zeros((T, 40), dtype=torch.uint8, device=dev)
-kernel_ms = []
 
 
 retired = torch.zeros(T, dtype=torch.bool, device=dev)
+stream = torch.cuda.Stream(dev)  # a real stream: 0 would select the handle's own
+events = []
 
 
 def solve(x0, z, l, v):
-    if RETIRE and bool(retired.any()):
-        x0[retired] = 0.0
-        z[retired] = 0.0
-        l[retired] = 0.0
-        v[retired] = 0.0
-    data["x0"] = x0.contiguous()
-    s.Solve(data, z, l, v, y, out=out_dev, keep_matrices=KEEP)
-    kernel_ms.append(s.last_kernel_ms())
-    o = hip_api.out_to_numpy(out_dev)
+    # nothing here waits for the device: the retire mask, the plant update in
+    # closed_loop() and the next launch are all queued behind the solve
     if RETIRE:
-        retired.logical_or_(torch.from_numpy(o["eflag"] != 0).to(dev))
-    return z, l, v, y, o
+        m = retired.unsqueeze(1)
+        for a in (x0, z, l, v):
+            a.masked_fill_(m, 0.0)
+    data["x0"] = x0.contiguous()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    s.Solve(data, z, l, v, y, out=out_dev, keep_matrices=KEEP, stream=stream.cuda_stream, async_=True)
+    e1.record(stream)
+    events.append((e0, e1))
+    if RETIRE:
+        retired.logical_or_(out_dev.view(torch.int32)[:, 0] != 0)
+    return z, l, v, y, out_dev.clone()
 
 
 x0 = data["x0"].clone()
+Ad, Bd = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+z0, l0, v0 = mk(p.nz), mk(p.nl), mk(p.nv)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-log = rh.closed_loop(solve, x0, mk(p.nz), mk(p.nl), mk(p.nv), torch.from_numpy(A).to(dev),
-                     torch.from_numpy(B).to(dev), nx, nu, S)
+with torch.cuda.stream(stream):  # plant update, masks and solves all queue on this stream
+    log = rh.closed_loop(solve, x0, z0, l0, v0, Ad, Bd, nx, nu, S)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+kernel_ms = [a.elapsed_time(b) for a, b in events]
+for r in log:
+    r["out"] = hip_api.out_to_numpy(r["out"])
 it = np.array([r["out"]["newton_iters"].mean() for r in log])
 ok = all((r["out"]["eflag"] == 0).all() for r in log)
 for k in (0, 1, 2, 5, 10, S - 1):
