@@ -11,12 +11,17 @@
 //   * FullFeasibility::CheckFeasibility       full_feasibility.cc:25-88
 //
 // K and every iterate vector live in LDS for the whole solve; H, G, A are read
-// from HBM/L2 where they are used.  The LDL' here is right-looking (rank-1
+// from HBM/L2 where they are used.  When K = (nz+nl)^2 doubles does not fit
+// beside the vectors (nz + nl > ~140) the KGLOBAL instance keeps K in a
+// per-workgroup global scratch instead (L2-resident at these sizes), the vectors
+// stay in LDS, and the generic multi-wavefront factorisation runs unchanged.  The LDL' here is right-looking (rank-1
 // trailing updates spread over the workgroup) where Eigen's is left-looking;
 // pivot order is the same rule, summation order differs (rounding only).
 #pragma once
 
 #include <float.h>
+
+#include <type_traits>
 
 #include "fb_common.h"
 #include "fb_mpc.h"  // FB_LDS, lds_ptr
@@ -37,14 +42,28 @@ struct DenseLayout {
   // walks by different lanes then hit different banks).  a_lds == 0: read A
   // from global memory instead.
   int o_a, lda, a_lds;
+  // k_global != 0: K lives in global scratch (k_doubles per workgroup), not at o_k
+  int k_global;
+  long k_doubles;
 
 #if !defined(FB_HOSTSIM)
   __host__ __device__
 #endif
   void init(int nz_, int nl_, int nv_, int nthreads) {
+    carve(nz_, nl_, nv_, nthreads, 0);
+    if ((long)lds_doubles * 8 > 160 * 1024 || k_doubles > (1L << 30)) carve(nz_, nl_, nv_, nthreads, 1);
+  }
+
+#if !defined(FB_HOSTSIM)
+  __host__ __device__
+#endif
+  void carve(int nz_, int nl_, int nv_, int nthreads, int kg) {
     nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
-    int s = 0;
-    o_k = s; s += nk * nk;
+    k_doubles = (long)nk * nk;
+    k_global = kg;
+    long s = 0;
+    o_k = 0;
+    if (!k_global) s += k_doubles;
     o_rhs = s; s += nk;
     o_z = s; s += nz;  o_l = s; s += nl;  o_v = s; s += nv;  o_y = s; s += nv;
     o_zb = s; s += nz; o_lb = s; s += nl; o_vb = s; s += nv; o_yb = s; s += nv;
@@ -53,17 +72,20 @@ struct DenseLayout {
     o_gam = s; s += nv; o_rvm = s; s += nv;
     o_perm = s; s += (nk + 1) / 2 + 1;  // nk ints
     o_red = s; s += kMaxReduce * ((nthreads + 63) / 64);
-    s = (s + 1) & ~1;
+    s = (s + 1) & ~1L;
     lda = nv | 1;
     o_a = s;
-    a_lds = (long)(s + (long)lda * nz) * 8 <= 80 * 1024 ? 1 : 0;  // two workgroups per CU must still fit
+    // two workgroups per CU must still fit
+    a_lds = !k_global && (s + (long)lda * nz) * 8 <= 80 * 1024 ? 1 : 0;
     if (a_lds) s += lda * nz;
-    lds_doubles = (s + 1) & ~1;
+    s = (s + 1) & ~1L;
+    lds_doubles = s > (1L << 28) ? (1 << 28) : (int)s;  // (callers reject what exceeds the LDS)
   }
 };
 
-template <class C>
+template <class C, bool KGLOBAL = false>
 struct DenseProblem {
+  typedef typename std::conditional<KGLOBAL, double*, lds_ptr>::type kptr;
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
   DenseLayout lay;
@@ -72,14 +94,17 @@ struct DenseProblem {
   lds_ptr lds;
   int nz, nl, nv;
   lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
-  lds_ptr gam, rvm, K, rhs, Al;
+  lds_ptr gam, rvm, rhs, Al;
+  kptr K;
   FB_LDS int* perm;
 
   FB_DEV void bind(const DenseLayout& L_, const DenseData& D_, double* uz_, double* ul_,
-                   double* uv_, double* uy_, lds_ptr lds_) {
+                   double* uv_, double* uy_, lds_ptr lds_, double* k_scratch = nullptr) {
     lay = L_; D = D_; uz = uz_; ul = ul_; uv = uv_; uy = uy_; lds = lds_;
     nz = lay.nz; nl = lay.nl; nv = lay.nv;
-    K = lds + lay.o_k; rhs = lds + lay.o_rhs;
+    if constexpr (KGLOBAL) K = k_scratch;
+    else K = lds + lay.o_k;
+    rhs = lds + lay.o_rhs;
     z = lds + lay.o_z; l = lds + lay.o_l; v = lds + lay.o_v; y = lds + lay.o_y;
     zb = lds + lay.o_zb; lb = lds + lay.o_lb; vb = lds + lay.o_vb; yb = lds + lay.o_yb;
     dz = lds + lay.o_dz; dl = lds + lay.o_dl; dv = lds + lay.o_dv; adz = lds + lay.o_adz;
@@ -219,7 +244,7 @@ struct DenseProblem {
   }
   FB_DEV bool ldlt(const C& c) const {
 #if !defined(FB_HOSTSIM)
-    if (C::nt > 64 && lay.nk <= 64) return ldlt_fused(c);
+    if (!KGLOBAL && C::nt > 64 && lay.nk <= 64) return ldlt_fused(c);
 #endif
     // (running the whole factorisation on one wavefront was measured too: 27.3 ms
     // against 23.3 on config 2 - the trailing update wants the four of them)

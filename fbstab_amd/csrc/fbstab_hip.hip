@@ -280,12 +280,25 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
 #endif
 }
 
-template <int NT, bool TRACE = false>
+// KGLOBAL: K in a per-workgroup global scratch (fb_dense.h); the argument is
+// empty for the LDS instance, like the trace buffer for the untraced ones.
+template <bool KGLOBAL>
+struct KScratchArg {
+  __device__ double* get() const { return nullptr; }
+};
+template <>
+struct KScratchArg<true> {
+  double* p;
+  __device__ double* get() const { return p; }
+};
+
+template <int NT, bool TRACE = false, bool KGLOBAL = false>
 __global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, DenseBatchArgs data,
                                                           VarBatchArgs x,
                                                           fbstab_solver_out_t* out,
                                                           fbstab_options_t opts, int* counter,
-                                                          int batch, TraceArg<TRACE> trace) {
+                                                          int batch, TraceArg<TRACE> trace,
+                                                          KScratchArg<KGLOBAL> kscratch) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   FB_WAVE_TIMER(28);  // total wave cycles (diagnostic builds)
   lds_ptr lds = (lds_ptr)smem;
@@ -303,10 +316,12 @@ __global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, Dense
     D.h = data.base[FBSTAB_DENSE_h] + q * data.stride[FBSTAB_DENSE_h];
     D.A = data.base[FBSTAB_DENSE_A] + q * data.stride[FBSTAB_DENSE_A];
     D.b = data.base[FBSTAB_DENSE_b] + q * data.stride[FBSTAB_DENSE_b];
-    DenseProblem<C> p;
+    DenseProblem<C, KGLOBAL> p;
+    double* ks = nullptr;
+    if constexpr (KGLOBAL) ks = kscratch.get() + (long)blockIdx.x * lay.k_doubles;
     p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
-           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds);
-    Solver<DenseProblem<C>, C, TRACE> solver(p, ctx, opts, trace.get());
+           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ks);
+    Solver<DenseProblem<C, KGLOBAL>, C, TRACE> solver(p, ctx, opts, trace.get());
     solver.solve(out + q);
     ctx.sync();
   }
@@ -865,17 +880,16 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
   if (s->lds_bytes > kLdsLimitBytes) {
     delete s;
-    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "KKT matrix and iterates do not fit the 160 KiB LDS budget");
+    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "the iterate vectors do not fit the 160 KiB LDS budget");
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  auto kern = fbstab_dense_kernel<kDenseThreads>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  const void* kern = s->lay.k_global
+                         ? reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads, false, true>)
+                         : reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads>);
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0;
-  if (e == hipSuccess)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern),
-                                                     s->threads, s->lds_bytes);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, s->threads, s->lds_bytes);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -889,6 +903,14 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   s->workgroups = prop.multiProcessorCount * per_cu;
   if (s->workgroups > max_batch) s->workgroups = max_batch;
   s->scratch_bytes = 0;
+  if (s->lay.k_global) {  // K of every resident workgroup (fb_dense.h)
+    s->scratch_bytes = (long long)sizeof(double) * s->lay.k_doubles * s->workgroups;
+    e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
+    if (e != hipSuccess) {
+      s->release(); delete s;
+      return fail(FBSTAB_HIP_ERR_DEVICE, std::string("scratch allocation: ") + hipGetErrorString(e));
+    }
+  }
   s->arr_len = {(long long)nz * nz, (long long)nz, (long long)nl * nz, (long long)nl,
                 (long long)nv * nz, (long long)nv};
   s->var_len[0] = nz; s->var_len[1] = nl; s->var_len[2] = nv; s->var_len[3] = nv;
@@ -961,15 +983,26 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
   HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
   int grid = h->workgroups < batch ? h->workgroups : batch;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  if (d_trace) {
+  if (d_trace && h->lay.k_global) {
+    auto kern = fbstab_dense_kernel<kDenseThreads, true, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a, v, d_out, h->opts,
+                       h->counter, 1, TraceArg<true>{d_trace}, KScratchArg<true>{h->scratch});
+  } else if (d_trace) {
     auto kern = fbstab_dense_kernel<kDenseThreads, true>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
     hipLaunchKernelGGL(kern, dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a, v, d_out, h->opts,
-                       h->counter, 1, TraceArg<true>{d_trace});
+                       h->counter, 1, TraceArg<true>{d_trace}, KScratchArg<false>());
+  } else if (h->lay.k_global) {
+    hipLaunchKernelGGL((fbstab_dense_kernel<kDenseThreads, false, true>), dim3(grid), dim3(h->threads),
+                       h->lds_bytes, s, h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>(),
+                       KScratchArg<true>{h->scratch});
   } else {
     hipLaunchKernelGGL(fbstab_dense_kernel<kDenseThreads>, dim3(grid), dim3(h->threads), h->lds_bytes, s,
-                       h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>());
+                       h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>(),
+                       KScratchArg<false>());
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));

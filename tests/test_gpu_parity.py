@@ -357,6 +357,25 @@ def test_dense_odd_shapes(hip, oracle, shape):
     assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(110, 20, 150), (150, 20, 220), (200, 0, 260)])
+def test_dense_kkt_matrix_larger_than_lds(hip, oracle, shape):
+    """nz + nl beyond ~140: K = (nz+nl)^2 doubles no longer fits the 160 KiB LDS
+    beside the vectors and lives in a per-workgroup global scratch (fb_dense.h,
+    KGLOBAL instance); (110, 20, 150) is the largest kind that still keeps K in LDS.
+    The reference has no size limit (Eigen heap matrices, fbstab_dense.cc:18-42)."""
+    nz, nl, nv = shape
+    p = fx.synthetic_dense_batch(6, nz, nl, nv, first_id=9000 + nz)
+    o = default_options()
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=6)
+    q = s.query()
+    assert (q["scratch_bytes"] > 0) == ((nz + nl) > 140), q
+    assert q["lds_bytes"] <= 160 * 1024
+    gpu = _solve_dense_host(hip, p, o)
+    cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+    assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
+
+
 def test_mpc_device_pointers_match_host_pointers(hip):
     import torch
     p = fx.synthetic_mpc_batch(64, first_id=1000)
