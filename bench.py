@@ -9,7 +9,7 @@ One "step" = one fbstab_hip_mpc_solve_batch call over the rank's whole shard
 (cold start, zero initial guess), problem data already resident in HBM.  For
 N > 1 the batch is sharded by global instance id (weak scaling, 8192 QPs per
 GPU) and each step ends with one RCCL gather of the solutions to rank 0.
-Consecutive steps are issued on --pipeline (default 2) alternating HIP streams,
+Consecutive steps are issued on --pipeline (default 3) alternating HIP streams,
 each with its own solver handle and output buffers, the way a stream of
 batches is served: iteration counts differ 10x between QPs, so the tail of
 one batch (a few slow QPs) overlaps the bulk of the next.  --pipeline 1
@@ -83,10 +83,10 @@ def pmc_traffic(batch: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="QPs per GPU")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="steps in flight (alternating streams/handles); 1 = serial")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="QPs for the CPU baseline (0 disables; default sized for ~15 s)")

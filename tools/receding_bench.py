@@ -23,6 +23,7 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 RETIRE = "retire" in sys.argv[3:]
 KEEP = "keep" in sys.argv[3:]  # FBSTAB_HIP_KEEP_MATRICES: the matrices do not change between steps
+STAMPS = "stamps" in sys.argv[3:]  # -DFB_CLOCKSTAMP build: where the wavefronts' cycles go from step 20 on
 p = fx.synthetic_mpc_batch(T)
 N, nx, nu, nc = p.sizes()
 A, B = fx.quadrotor_model()
@@ -40,6 +41,10 @@ events = []
 
 
 def solve(x0, z, l, v):
+    if STAMPS and len(events) == 20:
+        import ctypes
+        torch.cuda.synchronize()
+        hip_api.load_library().fbstab_hip_debug_stamps((ctypes.c_ulonglong * 32)(), 1)
     # nothing here waits for the device: the retire mask, the plant update in
     # closed_loop() and the next launch are all queued behind the solve
     if RETIRE:
@@ -80,3 +85,13 @@ print(f"trajectories={T} steps={S}: {T * S / dt:.0f} QP/s wall ({dt / S * 1e3:.2
       f"kernel ms first/median/last {kernel_ms[0]:.2f}/{np.median(kernel_ms):.2f}/{kernel_ms[-1]:.2f}, "
       f"mean Newton iterations first/last step {it[0]:.2f}/{it[-1]:.2f}, all converged {ok}, "
       f"retired {int(retired.sum())}")
+
+if STAMPS:
+    import ctypes
+    st = (ctypes.c_ulonglong * 32)()
+    hip_api.load_library().fbstab_hip_debug_stamps(st, 1)
+    tot = float(st[28]) or 1.0
+    print(f"steps 20..{S - 1}: sum of wave lifetimes {st[29] * 1e-5:.1f} ms")
+    for k, nm, cnt in ((19, "load_guess", 0), (22, "open_prox", st[25]), (20, "newton_step", st[27]),
+                       (23, "norms_at_multi", st[24]), (21, "close_subproblem", st[26])):
+        print(f"   wave cycles in {nm:18s} {100.0 * st[k] / tot:5.1f} %" + (f"  ({cnt} calls)" if cnt else ""))
