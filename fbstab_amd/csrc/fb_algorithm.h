@@ -25,6 +25,11 @@
 
 #include "fb_common.h"
 
+// A wavefront with this many busy rows or fewer offers them to others (build knob).
+#ifndef FB_MIG_MAX_BUSY
+#define FB_MIG_MAX_BUSY 2
+#endif
+
 // Step lengths evaluated per line-search pass (build knob).
 #ifndef FB_LS_KT
 #define FB_LS_KT 4
@@ -435,6 +440,7 @@ struct Solver : TraceState<TRACE> {
     return Eo_top;
   }
 
+#if !defined(FB_HOSTSIM)  // (device intrinsics; the host simulation runs solve())
   // The whole solve as ONE flat loop over "Newton iterations of this row", for
   // policies that host several QPs per wavefront (fb_mpc_r16.h).  Each trip of the
   // outer loop first lets every row run the bookkeeping between two Newton
@@ -445,10 +451,32 @@ struct Solver : TraceState<TRACE> {
   // for each other at the end of a subproblem or of a QP (nested loops reconverge
   // at their exits), and a row loses no Newton slot to its bookkeeping.
   // Same statements, same order per QP as solve()/subproblem_fused().
-  // `next(p)` binds the policy to the next QP and returns its index or -1.
-  template <class Next>
-  FB_DEV void solve_stream(Next&& next, fbstab_solver_out_t* out_base) const {
+  // `qu.fetch(p)` binds the policy to the next QP and returns its index or -1.
+  //
+  // Once the queue is empty the rows of a wavefront finish at different times and
+  // the wavefront lives until its last row does (17 % of all row slots idle at
+  // batch 8192).  With P::kMigrate a wavefront that is down to one or two busy
+  // rows therefore invites others to take those solves (qu.invite) and keeps
+  // solving.  A wavefront whose four rows have all run out of work does not leave
+  // at once: its rows accept open invitations (qu.claim).  The owner notices at
+  // its next stop in front of a Newton step, parks the loop's scalars in the QP's
+  // slot (P::park - everything else of a solve lives there already) and lets go
+  // (qu.hand_over); the new row picks the solve up (qu.take_over -> P::resume) and
+  // takes the very Newton step the old one was about to take.  Solves of several
+  // thin wavefronts gather in one full one and the thin ones leave their SIMD to
+  // the next launch.  A solve moves at most once.  Only wavefronts without work
+  // ever wait (for one Newton step of an owner, who cannot leave: it ends the
+  // solve or hands it over), and the loop the busy rows run is the plain one: rows
+  // leave it when they are done.  (An earlier version kept idle rows polling inside
+  // that loop; lanes that take a loop edge early are not held until the others
+  // arrive, the idle rows ran ahead and the busy rows of their own wavefront
+  // starved - wavefronts waiting on each other's solves then deadlock.)  The
+  // arithmetic of a QP does not depend on which rows ran it.
+  template <class Queue>
+  FB_DEV void solve_stream(Queue& qu, fbstab_solver_out_t* out_base) const {
     enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5 };
+    constexpr int NST = 20;  // scalars of a parked solve
+    [[maybe_unused]] bool moved = false;  // this row's solve came from another wavefront
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -456,10 +484,15 @@ struct Solver : TraceState<TRACE> {
     double Ei = 0.0, Eo = 0.0, Eo_top = 0.0, Ei0 = 0.0;
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
+    for (;;) {  // (kMigrate: once per set of solves this wavefront hosts)
     for (;;) {
       while (phase != kNewton && phase != kDone) {
         if (phase == kFetch) {
-          const int q = next(p);
+          if constexpr (P::kMigrate) {
+            qu.retire(p);  // (the solve that has just ended)
+            moved = false;
+          }
+          const int q = qu.fetch(p);
           if (q < 0) {
             phase = kDone;
             continue;
@@ -565,25 +598,59 @@ struct Solver : TraceState<TRACE> {
         }
       }
       if (phase == kDone) break;
+      if constexpr (P::kMigrate) {
+        // rows that have left the loop are inactive: `busy` counts the others
+        const int busy = C::rows_where(phase == kNewton);
+        bool gone = false;
+        if (qu.invited()) {
+          if (qu.claimed(p)) {
+            const double st[NST] = {combo_tol, Ek, E0, rk_last, inner_tol, dx_norm, Ei, Eo, Eo_top, Ei0,
+                                    merit[0], merit[1], merit[2], merit[3], merit[4],
+                                    (double)newton, (double)prox, (double)k, (double)inner_i, 0.0};
+            p.park(c, st);
+            qu.hand_over(p);
+            phase = kDone;
+            gone = true;
+          }
+        } else if (busy <= FB_MIG_MAX_BUSY && !moved) {
+          qu.invite(p, busy);
+        }
+        if (gone) break;
+      }
       // ---- one Newton step and its line search (impl:262-298), all rows together
+      {
+      // The loop's scalars are not needed until the line search is over: they wait
+      // in LDS meanwhile (the sweeps have no registers to spare; left to the
+      // compiler they are spilled to scratch memory inside the passes).
+      {
+        auto sv = qu.save_area();
+        sv[0] = combo_tol; sv[1] = Ek; sv[2] = E0; sv[3] = rk_last; sv[4] = inner_tol; sv[5] = dx_norm;
+        sv[6] = Eo_top; sv[7] = Ei0; sv[8] = merit[0]; sv[9] = merit[1]; sv[10] = merit[2]; sv[11] = merit[3];
+        sv[12] = Eo;
+        sv[13] = __hiloint2double(newton, prox);
+        sv[14] = __hiloint2double(k, inner_i);
+        sv[15] = __longlong_as_double((long long)(out - out_base));
+        sv[16] = Ei;
+      }
       double ti2, to2;
-      if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2)) {
+      const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2);
+      if (!stepped) {
+        auto sv = qu.save_area();
+        out = out_base + __double_as_longlong(sv[15]);
         p.flush(c);
         p.write_x(c);
-        finish(out, FBSTAB_DIVERGENCE, rk_last, newton, prox, E0);
+        finish(out, FBSTAB_DIVERGENCE, sv[3], __double2hiint(sv[13]), __double2loint(sv[13]), sv[2]);
         phase = kFetch;
-        continue;
-      }
-      newton++;
-      const double cm = 0.5 * Ei * Ei;
-      merit[4] = merit[3];
-      merit[3] = merit[2];
-      merit[2] = merit[1];
-      merit[1] = merit[0];
-      merit[0] = cm;
-      double m0 = cm;
-      if (o.nonmonotone_linesearch) {
-        for (int m = 1; m < 5; m++) m0 = merit[m] > m0 ? merit[m] : m0;
+      } else {
+      // merit FIFO (impl:276-278): the four older entries are in the save area
+      double cm, m0;
+      {
+        auto sv = qu.save_area();
+        cm = 0.5 * sv[16] * sv[16];
+        m0 = cm;
+        if (o.nonmonotone_linesearch) {
+          for (int m = 8; m < 12; m++) m0 = sv[m] > m0 ? sv[m] : m0;
+        }
       }
       double t = 1.0;
       double Et = sqrt(ti2), Eot = sqrt(to2);
@@ -634,10 +701,54 @@ struct Solver : TraceState<TRACE> {
       p.pend_t = t;
       Ei = Et;
       Eo = Eot;
-      inner_i++;
+      {
+        auto sv = qu.save_area();
+        combo_tol = sv[0]; Ek = sv[1]; E0 = sv[2]; rk_last = sv[3]; inner_tol = sv[4]; dx_norm = sv[5];
+        Eo_top = sv[6]; Ei0 = sv[7];
+        merit[4] = sv[11]; merit[3] = sv[10]; merit[2] = sv[9]; merit[1] = sv[8]; merit[0] = cm;
+        newton = __double2hiint(sv[13]) + 1;
+        prox = __double2loint(sv[13]);
+        k = __double2hiint(sv[14]);
+        inner_i = __double2loint(sv[14]) + 1;
+        out = out_base + __double_as_longlong(sv[15]);
+      }
       phase = kInnerTop;
+      }  // step taken
+      }
+    }
+    if constexpr (!P::kMigrate) {
+      break;
+    } else {
+      // ---- all four rows are out of work: take over solves other wavefronts offer
+      qu.claim();
+      for (int spin = 0; C::rows_where(qu.waiting()) != 0; spin++) {
+        if (qu.waiting()) {
+          double st[NST];
+          int q = 0;
+          if (qu.take_over(p, st, &q) == 1) {
+            out = out_base + q;
+            combo_tol = st[0]; Ek = st[1]; E0 = st[2]; rk_last = st[3]; inner_tol = st[4];
+            dx_norm = st[5]; Ei = st[6]; Eo = st[7]; Eo_top = st[8]; Ei0 = st[9];
+            for (int m = 0; m < 5; m++) merit[m] = st[10 + m];
+            newton = (int)st[15]; prox = (int)st[16]; k = (int)st[17]; inner_i = (int)st[18];
+            moved = true;
+            phase = kNewton;
+          }
+        }
+        // an owner hands over within one Newton step (< 1 ms); a wavefront that has
+        // waited a thousand times longer reports (ctl[4]) and leaves rather than hang
+        if (spin > 400000) {
+          qu.give_up();
+          break;
+        }
+        __builtin_amdgcn_s_sleep(127);
+      }
+      if (C::rows_where(phase == kNewton) == 0) break;
+    }
     }
   }
+
+#endif  // !FB_HOSTSIM
 
   // FBstabAlgorithm::Solve (impl:113-224).
   FB_DEV void solve(fbstab_solver_out_t* out) const {

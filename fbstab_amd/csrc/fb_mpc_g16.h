@@ -88,6 +88,11 @@ struct Ctx16 {
 #pragma unroll
     for (int k = 0; k < K; k++) v[k] = row_reduce<OpMax16>(v[k]);
   }
+  // Number of the wavefront's four rows for which the (row-uniform) predicate
+  // holds; wavefront-uniform.
+  static FB_DEV int rows_where(bool pred) {
+    return __builtin_popcountll(__ballot(pred) & 0x0001000100010001ull);
+  }
 };
 
 // Pins the emitted instruction order at this point.  The 64-bit DPP move has a

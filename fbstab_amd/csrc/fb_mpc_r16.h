@@ -104,7 +104,9 @@ struct MpcR16 {
   static constexpr int pABc = pABr + 16;               // column r of [A B], NX slots
   static constexpr int kPackSlots = (pABc + NX + 1) & ~1;
   static constexpr int kPack = 16 * kPackSlots;
-  static constexpr long hdr_doubles(int N) { return ((N + 1) / 2 + 16) & ~15L; }  // poff[N+1] ints
+  // poff[N+1] ints and the flag word, then kParkDoubles for a parked solve (below)
+  static constexpr int kParkDoubles = 32;
+  static constexpr long hdr_doubles(int N) { return (((N + 1) / 2 + 16) & ~15L) + kParkDoubles; }
   static constexpr long ws_doubles(int N) { return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1); }
 
   static constexpr int off(int slot) { return (slot >> 1) * 32 + (slot & 1); }
@@ -176,6 +178,44 @@ struct MpcR16 {
     pend_t = 0.0;
   }
   FB_DEV int num_primal_dual() const { return (N + 1) * (2 * prob_nx() + prob_nu() + prob_nc()); }
+
+  // ---- handing a solve in progress to another row (Solver::solve_stream) -----------
+  // Everything a solve owns lives in its slot (records, matrix copies, poff) except
+  // the loop's scalars: park() writes those (row-uniform) into the slot header,
+  // resume() binds a row to a parked slot and reads them back.  The step that was
+  // accepted but not applied yet travels as a scalar too.
+  // Off by default (-DFB_R16_MIGRATE turns it on): as measured in round 1 it packs
+  // the rows better (0.82 -> 0.86-0.91 busy rows per wavefront step) but the kernel
+  // instance with it compiled in loses more in its line-search pass (register
+  // spills inside the stage loop) than the packing gains; see DESIGN.md section 5.
+#if defined(FB_R16_MIGRATE)
+  static constexpr bool kMigrate = !KEEP;
+#else
+  static constexpr bool kMigrate = false;
+#endif
+  // the hand-over word of a slot (R16Queue in fbstab_hip.hip)
+  static FB_DEV double* park_flag(double* ws_row, int N_) { return ws_row + hdr_doubles(N_) - 1; }
+  template <int NS>
+  FB_DEV void park(const C& c, const double (&st)[NS]) const {
+    static_assert(NS + 2 <= kParkDoubles, "park area");
+    double* h = reinterpret_cast<double*>(poff) + hdr_doubles(N) - kParkDoubles;
+    sfor<0, NS>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if (c.tid == (i & 15)) h[i] = st[i];
+    });
+    if (c.tid == 0) h[NS] = pend_t;
+  }
+  template <int NS>
+  FB_DEV void resume(int lane16, double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d,
+                     const VarBatchPtrs* x, long q_, int N_, double (&st)[NS]) {
+    bind(ws_row, lds_row, d, x, q_, N_, lane16);
+    const double* h = ws_row + hdr_doubles(N_) - kParkDoubles;
+    sfor<0, NS>([&](auto I) { st[decltype(I)::value] = h[decltype(I)::value]; });
+    pend_t = h[NS];
+#if !defined(FB_R16_NO_BOUNDS_PATH)
+    bounds = poff[N_ + 1] != 0;
+#endif
+  }
 
   // ---- record access -------------------------------------------------------------
   static FB_DEV double ld(const double* R, int slot) { return R[off(slot)]; }
@@ -534,7 +574,11 @@ struct MpcR16 {
     });
   }
   template <int K>
+#if defined(FB_R16_NOINLINE_NORMS) && !defined(FB_HOSTSIM)
+  __device__ __attribute__((noinline)) void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
+#else
   FB_DEV void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
+#endif
                              double (&Ei)[K], double (&Eo)[K]) {
     FB_WAVE_COUNT(24);
     FB_WAVE_TIMER(23);

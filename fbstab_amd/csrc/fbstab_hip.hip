@@ -196,19 +196,11 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
     if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
     Solver<MpcProblemG16<NX, NU, NC>, Ctx16> solver(p, ctx, opts);
-#ifdef FB_G16_FLAT
-    // One flat loop over Newton steps (rows never wait at subproblem exits).
-    // Measured slower on the BASELINE workload (77.7k vs 99.4k QP/s): the
-    // proximal-level passes are then run by one row at a time instead of by
-    // the four rows together.  Kept for later rounds.
-    solver.solve_stream(next, out);
-#else
     for (;;) {
       const int q = next(p);
       if (q < 0) break;
       solver.solve(out + q);
     }
-#endif
   }
 }
 
@@ -223,6 +215,247 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
 #endif
 // Record-based 16-lane kernel (fb_mpc_r16.h): four QPs per wavefront, rows pull
 // QP indices from the shared counter.  scratch: rows * ws_doubles(N).
+// Work distribution of the record kernel: the shared queue of QP indices and the
+// board on which solves in progress change wavefronts (Solver::solve_stream
+// explains why).  One instance per 16-lane row; every function is called by
+// the whole row and returns row-uniform values.  Nothing in here waits for
+// another wavefront.
+//
+// Device memory (zeroed by the host before each launch):
+//   ctl[0] next QP index     ctl[1] board entries reserved
+//   ctl[3] every board entry below this index is closed
+//   board[i]: 0 reserved, not written yet
+//             OPEN    = busy << 61 | (workgroup + 1) << 48 | (slot + 1) << 24 | (q + 1): an
+//                       invitation - the row keeps solving while it stands; busy = busy
+//                       rows of its wavefront when it was posted
+//             CLAIMED = OPEN | 1 << 63: a row of another wavefront will continue this
+//                       solve as soon as its owner has parked it
+//             DEAD    = ~0: withdrawn (the solve ended first)
+// and in the slot header of every QP the hand-over word (P::park_flag): 0 running,
+// 1 parked and ready, 2 finished before the claim was noticed.
+// Invitations are accepted by the rows of wavefronts that have run out of work
+// (Solver::solve_stream), and a solve moves at most once.  Coherence: the two rows
+// may sit in different XCDs, whose L2s are not coherent; the owner writes its L2
+// back (agent-scope release fence) before it sets the hand-over word, the new
+// owner invalidates (acquire fence) after it has read it, and the words
+// themselves are agent-scope atomics.
+constexpr int kQueueCtlInts = 8;
+constexpr int kBoardEntries = 16384;
+constexpr size_t kQueueBytes = kQueueCtlInts * sizeof(int) + kBoardEntries * sizeof(unsigned long long);
+constexpr unsigned long long kBoardClaimed = 1ull << 63, kBoardDead = ~0ull;
+
+template <class P, bool KEEP>
+struct R16Queue {
+  // Only launch-uniform values live in here (SGPRs).  What a row remembers between
+  // trips sits in four spare words of its LDS region - the sweeps have no
+  // registers to spare for it (a handful of VGPRs held across the Newton step
+  // turned 2 spilled registers into 44):
+  //   [0] cursor: board entries below it are closed for good
+  //   [1] index of this row's standing invitation, -1 none
+  //   [2] slot of the solve this row has claimed and waits for, -1 none   [3] its QP index
+  const MpcBatchPtrs* data;
+  const VarBatchPtrs* x;
+  int* ctl;
+  unsigned long long* board;
+  double* scratch;
+  int batch, N;
+  bool reuse;
+  bool taken = false;  // (KEEP) this row has had its one QP
+
+  static __device__ __forceinline__ int tid() { return threadIdx.x & 15; }
+  static __device__ __forceinline__ int row() { return threadIdx.x >> 4; }
+  static __device__ __forceinline__ int home() { return blockIdx.x * 4 + row(); }
+  static __device__ __forceinline__ int wg() { return blockIdx.x; }
+  static __device__ __forceinline__ lds_ptr lds() {
+    extern __shared__ __attribute__((aligned(16))) double smem_[];
+    return (lds_ptr)smem_ + row() * P::kLdsPerRow;
+  }
+  static __device__ __forceinline__ FB_LDS int* mem() { return (FB_LDS int*)(lds() + P::kLdsDoubles); }
+  // Twenty more spare doubles of the row's LDS region: the solver loop parks its
+  // scalars there while a Newton step and its line search run (Solver::solve_stream).
+  static __device__ __forceinline__ lds_ptr save_area() { return lds() + P::kLdsDoubles + 4; }
+  static __device__ __forceinline__ void init() {
+    FB_LDS int* m = mem();
+    m[0] = 0;
+    m[1] = -1;
+    m[2] = -1;
+    m[3] = -1;
+  }
+
+  // Reads and writes of the words other wavefronts change go through read-modify-
+  // write atomics, which are performed at the memory side.  An agent-scope atomic
+  // LOAD is not enough on this part: it may be served from this XCD's L2, which
+  // another XCD's writes do not update (measured: a polled word stayed stale
+  // for the rest of the kernel).
+  static __device__ __forceinline__ int load(int* p) { return atomicAdd(p, 0); }
+  static __device__ __forceinline__ unsigned long long load(unsigned long long* p) { return atomicAdd(p, 0ull); }
+  static __device__ __forceinline__ double load_flag(double* p) {
+    return __longlong_as_double((long long)atomicAdd(reinterpret_cast<unsigned long long*>(p), 0ull));
+  }
+  static __device__ __forceinline__ void store_flag(double* p, double v) {
+    atomicExch(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+  }
+  __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
+
+  // Binds the policy to the next QP of the queue, in this row's own slot.
+  __device__ __forceinline__ int fetch(P& pp) {
+    int q = 0;
+    if constexpr (KEEP) {
+      q = home();
+      if (taken) return -1;
+      taken = true;
+    } else {
+      if (tid() == 0) q = atomicAdd(&ctl[0], 1);
+      q = bci<0>(q);
+    }
+    if (q >= batch) return -1;
+    pp.bind(slot_ptr(home()), lds(), data, x, q, N, tid());
+    if constexpr (KEEP) pp.reuse = reuse;
+    if constexpr (P::kMigrate) {
+      if (tid() == 0)
+        store_flag(P::park_flag(slot_ptr(home()), N), 0.0);
+    }
+    return q;
+  }
+
+  // ---- the row that owns a solve ---------------------------------------------------
+  __device__ __forceinline__ bool invited() const { return mem()[1] >= 0; }
+  // Posts an invitation for the solve pp is bound to (no-op when the board is full).
+  __device__ __forceinline__ void invite(const P& pp, int busy) {
+    // (the reset of this slot's hand-over word by fetch / take_over must have landed
+    // before anybody can see the invitation)
+    __threadfence();
+    int i = -1;
+    if (tid() == 0 && pp.q + 1 < (1 << 24)) {
+      i = atomicAdd(&ctl[1], 1);
+      if (i < kBoardEntries) {
+        const long slot = (reinterpret_cast<const double*>(pp.poff) - scratch) / P::ws_doubles(N);
+        const unsigned long long v = ((unsigned long long)busy << 61) | ((unsigned long long)(wg() + 1) << 48) | ((unsigned long long)(slot + 1) << 24) |
+                                     (unsigned long long)(pp.q + 1);
+        // (the hand-over word of this slot was reset by an atomic before: it is out already)
+        atomicExch(&board[i], v);
+      } else {
+        i = -1;
+      }
+    }
+    mem()[1] = bci<0>(i);
+  }
+  // Has somebody accepted the standing invitation?
+  __device__ __forceinline__ bool claimed(const P& pp) const {
+    int c = 0;
+    if (tid() == 0) {
+      const unsigned long long e = load(&board[mem()[1]]);
+      c = (e & kBoardClaimed) ? 1 : 0;
+    }
+    return bci<0>(c) != 0;
+  }
+  // The solve is parked in its slot (P::park): let the claiming row have it.
+  __device__ __forceinline__ void hand_over(const P& pp) {
+    __threadfence();
+    if (tid() == 0) store_flag(P::park_flag(reinterpret_cast<double*>(pp.poff), N), 1.0);
+    mem()[1] = -1;
+  }
+  // The solve has ended on this row: withdraw the invitation, or tell the row
+  // that accepted it in the meantime.
+  __device__ __forceinline__ void retire(const P& pp) {
+    const int invite_idx = mem()[1];
+    if (invite_idx < 0) return;
+    if (tid() == 0) {
+      unsigned long long v = load(&board[invite_idx]);
+      if (!(v & kBoardClaimed)) v = atomicCAS(&board[invite_idx], v, kBoardDead);
+      if (v & kBoardClaimed) store_flag(P::park_flag(reinterpret_cast<double*>(pp.poff), N), 2.0);
+    }
+    mem()[1] = -1;
+  }
+
+  // ---- an idle row ------------------------------------------------------------------
+  __device__ __forceinline__ bool waiting() const { return mem()[2] >= 0; }
+  // Accepts one open invitation, if there is one (called by the rows of a wavefront
+  // that has run out of work).
+  __device__ __forceinline__ void claim() {
+    int n = 0, head = 0;
+    int cursor = mem()[0];
+    if (tid() == 0) {
+      n = load(&ctl[1]);
+      if (cursor == 0) head = load(&ctl[3]);  // (a row that has not looked yet starts at the shared hint)
+    }
+    n = bci<0>(n);
+    head = bci<0>(head);
+    if (n > kBoardEntries) n = kBoardEntries;
+    const bool from_hint = cursor == 0;
+    if (cursor < head) cursor = head;
+    else head = cursor;
+    // The row's cursor passes closed entries for good; an entry that is reserved but
+    // not written yet holds it back.  The shared hint ctl[3] lets rows that have
+    // not looked yet skip the closed prefix.
+    bool all_closed = from_hint;  // every entry in [hint, sc) is closed
+    for (int sc = cursor; sc < n;) {
+      const int idx = sc + tid();  // sixteen entries at a time, one per lane
+      unsigned long long v = 0ull;
+      if (idx < n) v = load(&board[idx]);
+      const bool closed = idx >= n || (v & kBoardClaimed) != 0ull;  // CLAIMED or DEAD
+      const bool mine = !closed && v != 0ull;  // OPEN
+      const int first = 16 - (int)row_reduce<OpMax16>(mine ? (double)(16 - tid()) : 0.0);
+      if (first < 16) {
+        int won = 0;
+        if (tid() == first) won = atomicCAS(&board[idx], v, v | kBoardClaimed) == v ? 1 : 0;
+        won = __shfl(won, first, 16);
+        if (won) {
+          const int lo = __shfl((int)(v & 0xffffffffull), first, 16);
+          const int hi = __shfl((int)(v >> 32), first, 16);
+          const unsigned long long e = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+          mem()[2] = (int)((e >> 24) & 0xffffffull) - 1;
+          mem()[3] = (int)(e & 0xffffffull) - 1;
+          mem()[0] = sc;  // (this window is looked at again next time)
+          return;
+        }
+        continue;  // another row was quicker: look at the window again
+      }
+      const int first_unwritten =
+          16 - (int)row_reduce<OpMax16>((idx < n && v == 0ull) ? (double)(16 - tid()) : 0.0);
+      if (first_unwritten < 16) {
+        cursor = sc + first_unwritten;
+        break;
+      }
+      const int nclosed = (int)row_reduce<OpSum16>(closed ? 1.0 : 0.0);
+      all_closed = all_closed && nclosed == 16 && sc == head;
+      sc += 16;
+      cursor = sc < n ? sc : n;
+      if (all_closed) {
+        head = cursor;
+        if (tid() == 0) atomicMax(&ctl[3], cursor);
+      }
+    }
+    mem()[0] = cursor;
+  }
+  // (never expected) the wavefront waited in vain: ctl[4] tells the host
+  __device__ __forceinline__ void give_up() {
+    if (tid() == 0 && waiting()) {
+      atomicAdd(&ctl[4], 1);
+    }
+  }
+  // Is the claimed solve ready?  1: pp is bound to its slot and st holds the parked
+  // scalars, *q its index; 2: it ended on its old row; 0: not yet.
+  template <int NS>
+  __device__ __forceinline__ int take_over(P& pp, double (&st)[NS], int* q) {
+    double* ws = slot_ptr(mem()[2]);
+    const int wait_q = mem()[3];
+    int f = 0;
+    if (tid() == 0)
+      f = (int)load_flag(P::park_flag(ws, N));
+    f = bci<0>(f);
+    if (f == 0) return 0;
+    if (f == 1) {
+      __threadfence();
+      pp.resume(tid(), ws, lds(), data, x, wait_q, N, st);
+      if (tid() == 0) store_flag(P::park_flag(ws, N), 0.0);
+      *q = wait_q;
+    }
+    mem()[2] = -1;
+    return f;
+  }
+};
+
 // KEEP (FBSTAB_HIP_KEEP_MATRICES): QP q is solved in slot q, so that the slot's
 // matrix copies survive from call to call; `reuse` says they are valid already.
 template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false>
@@ -234,41 +467,32 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
 #if defined(FB_ANY_STAMP)
   const long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
 #endif
-  const int lane = threadIdx.x, row = lane >> 4;
+  const int lane = threadIdx.x;
   Ctx16 ctx;
   ctx.tid = lane & 15;
   P p;
-  double* const ws = scratch + ((long)blockIdx.x * 4 + row) * P::ws_doubles(N);
-  lds_ptr const lds = (lds_ptr)smem + row * P::kLdsPerRow;
-  // Binds the policy to the next QP of the shared queue; -1 when it is empty.
-  bool taken = false;  // (KEEP) this row has had its one QP
-  auto next = [&](P& pp) -> int {
-    int q = 0;
-    if constexpr (KEEP) {
-      q = blockIdx.x * 4 + row;
-      if (taken) return -1;
-      taken = true;
-    } else {
-      if (ctx.tid == 0) q = atomicAdd(counter, 1);
-      q = bci<0>(q);
-    }
-    if (q >= batch) return -1;
-    pp.bind(ws, lds, &data, &x, q, N, ctx.tid);
-    if constexpr (KEEP) pp.reuse = reuse != 0;
-    return q;
-  };
+  R16Queue<P, KEEP> qu;
+  qu.data = &data;
+  qu.x = &x;
+  qu.ctl = counter;
+  qu.board = reinterpret_cast<unsigned long long*>(counter + kQueueCtlInts);
+  qu.scratch = scratch;
+  qu.batch = batch;
+  qu.N = N;
+  qu.reuse = reuse != 0;
+  qu.init();
   if constexpr (DBG) {
-    if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
+    if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
     Solver<P, Ctx16> solver(p, ctx, opts);
 #ifdef FB_R16_NESTED
     for (;;) {
-      const int q = next(p);
+      const int q = qu.fetch(p);
       if (q < 0) break;
       solver.solve(out + q);
     }
 #else
-    solver.solve_stream(next, out);
+    solver.solve_stream(qu, out);
 #endif
   }
 #if defined(FB_ANY_STAMP)
@@ -390,7 +614,7 @@ struct SolverBase {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipMalloc(&counter, sizeof(int)));
+    HIP_TRY(hipMalloc(&counter, kQueueBytes));  // queue counter (+ the record kernel's board)
     return FBSTAB_HIP_OK;
   }
 
@@ -725,7 +949,7 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     }
     d_out = h->d_out;
   }
-  HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(h->counter, 0, h->r16 ? kQueueBytes : sizeof(int), s));
   int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
@@ -818,7 +1042,7 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
   double* d_io = nullptr;
   HIP_TRY(hipMalloc(&d_io, n_io * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(d_io, io, sizeof(double) * (L.nz + L.nl + L.nv), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(h->counter, 0, h->r16 ? kQueueBytes : sizeof(int), s));
   if (h->r16) {
     launch_r16<true>(h, 1, s, a, v, h->d_out, 1, d_io);
   } else if (h->g16) {

@@ -53,3 +53,8 @@ if st[20]:
 if st[29]:
     print(f"mean shader clock over the wavefronts' lifetimes: {st[28] / (st[29] * 0.01):.0f} MHz "
           f"(sum of wave lifetimes {st[29] * 1e-5:.1f} ms)")
+
+if st[4] or st[3]:
+    tot = float(st[28])
+    print(f"migration: invitations {st[4]}, solves taken over {st[3]}, sleep trips {st[2]}; wave cycles: idle-row block "
+          f"{100.0 * st[0] / tot:.1f} %, owner block {100.0 * st[1] / tot:.1f} %, sleeping {100.0 * st[5] / tot:.1f} %")
