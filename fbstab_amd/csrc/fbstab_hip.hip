@@ -243,6 +243,13 @@ constexpr int kQueueCtlInts = 8;
 constexpr int kBoardEntries = 16384;
 constexpr size_t kQueueBytes = kQueueCtlInts * sizeof(int) + kBoardEntries * sizeof(unsigned long long);
 constexpr unsigned long long kBoardClaimed = 1ull << 63, kBoardDead = ~0ull;
+// The board operations are rare: as real calls they stay out of the register
+// allocation of the solver loop (build knob FB_R16_MIG_INLINE for comparison).
+#if defined(FB_R16_MIG_INLINE)
+#define FB_COLD __device__ __forceinline__
+#else
+#define FB_COLD __device__ __attribute__((noinline))
+#endif
 
 template <class P, bool KEEP>
 struct R16Queue {
@@ -321,7 +328,7 @@ struct R16Queue {
   // ---- the row that owns a solve ---------------------------------------------------
   __device__ __forceinline__ bool invited() const { return mem()[1] >= 0; }
   // Posts an invitation for the solve pp is bound to (no-op when the board is full).
-  __device__ __forceinline__ void invite(const P& pp, int busy) {
+  FB_COLD void invite(const P& pp, int busy) {
     // (the reset of this slot's hand-over word by fetch / take_over must have landed
     // before anybody can see the invitation)
     __threadfence();
@@ -350,14 +357,14 @@ struct R16Queue {
     return bci<0>(c) != 0;
   }
   // The solve is parked in its slot (P::park): let the claiming row have it.
-  __device__ __forceinline__ void hand_over(const P& pp) {
+  FB_COLD void hand_over(const P& pp) {
     __threadfence();
     if (tid() == 0) store_flag(P::park_flag(reinterpret_cast<double*>(pp.poff), N), 1.0);
     mem()[1] = -1;
   }
   // The solve has ended on this row: withdraw the invitation, or tell the row
   // that accepted it in the meantime.
-  __device__ __forceinline__ void retire(const P& pp) {
+  FB_COLD void retire(const P& pp) {
     const int invite_idx = mem()[1];
     if (invite_idx < 0) return;
     if (tid() == 0) {
@@ -372,7 +379,7 @@ struct R16Queue {
   __device__ __forceinline__ bool waiting() const { return mem()[2] >= 0; }
   // Accepts one open invitation, if there is one (called by the rows of a wavefront
   // that has run out of work).
-  __device__ __forceinline__ void claim() {
+  FB_COLD void claim() {
     int n = 0, head = 0;
     int cursor = mem()[0];
     if (tid() == 0) {
@@ -429,7 +436,7 @@ struct R16Queue {
     mem()[0] = cursor;
   }
   // (never expected) the wavefront waited in vain: ctl[4] tells the host
-  __device__ __forceinline__ void give_up() {
+  FB_COLD void give_up() {
     if (tid() == 0 && waiting()) {
       atomicAdd(&ctl[4], 1);
     }
@@ -437,7 +444,7 @@ struct R16Queue {
   // Is the claimed solve ready?  1: pp is bound to its slot and st holds the parked
   // scalars, *q its index; 2: it ended on its old row; 0: not yet.
   template <int NS>
-  __device__ __forceinline__ int take_over(P& pp, double (&st)[NS], int* q) {
+  FB_COLD int take_over(P& pp, double (&st)[NS], int* q) {
     double* ws = slot_ptr(mem()[2]);
     const int wait_q = mem()[3];
     int f = 0;
