@@ -608,6 +608,49 @@ def test_full_size_properties(hip):
     assert np.array_equal(out["newton_iters"], out2["newton_iters"])
 
 
+@pytest.mark.parametrize("problem,N", [("ServoMotor", 25), ("SpacecraftRelativeMotion", 40), ("DoubleIntegrator", 20)])
+def test_closed_loop_with_the_generator_simulation_inputs(hip, oracle, problem, N):
+    """The reference's OcpGenerator hands out, next to the QP, the matrices to
+    simulate the plant with (GetSimulationInputs, ocp_generator.h:31-38): closed
+    loop x+ = A x + B u0* from its x0 and from seven perturbed copies, eight MPC
+    steps, warm-started unshifted, device path against the oracle run in the same
+    loop: equal exit flags, inputs applied equal to 1e-6 of the input scale."""
+    from fbstab_amd import receding_horizon as rh
+    gen = fx.OcpGenerator()
+    getattr(gen, problem)(N)
+    one = gen.GetFBstabInput()
+    sim = gen.GetSimulationInputs()
+    T, S = 8, 8
+    Nn, nx, nu, nc = one.sizes()
+    p = fx.MpcProblem(Nn, nx, nu, nc)
+    p.arrays = {k: np.repeat(v, T, axis=0) for k, v in one.arrays.items()}
+    scale = 1.0 + 0.02 * np.arange(T)[:, None]
+    p.arrays["x0"] = np.ascontiguousarray(p.arrays["x0"] * scale)
+    o = default_options()
+
+    def solver(backend):
+        def solve(x0, z, l, v):
+            q = fx.MpcProblem(Nn, nx, nu, nc)
+            q.arrays = dict(p.arrays)
+            q.arrays["x0"] = np.ascontiguousarray(x0)
+            if backend == "gpu":
+                r = _solve_mpc_host(hip, q, o, guess=(z, l, v))
+            else:
+                r = oracle.solve_mpc(q, (z, l, v), opts=o)
+            return r[0], r[1], r[2], r[3], r[4]
+        return solve
+
+    zeros = lambda: (np.zeros((T, p.nz)), np.zeros((T, p.nl)), np.zeros((T, p.nv)))
+    A, B = np.asarray(sim["A"], dtype=np.float64), np.asarray(sim["B"], dtype=np.float64)
+    g = rh.closed_loop(solver("gpu"), p.arrays["x0"].copy(), *zeros(), A, B, nx, nu, S)
+    c = rh.closed_loop(solver("cpu"), p.arrays["x0"].copy(), *zeros(), A, B, nx, nu, S)
+    for k in range(S):
+        assert np.array_equal(g[k]["out"]["eflag"], c[k]["out"]["eflag"]), (problem, k)
+        us = 1.0 + np.abs(c[k]["u0"]).max()
+        assert np.abs(g[k]["u0"] - c[k]["u0"]).max() <= 1e-6 * us, (problem, k)
+        assert np.abs(g[k]["x0"] - c[k]["x0"]).max() <= 1e-6 * (1.0 + np.abs(c[k]["x0"]).max()), (problem, k)
+
+
 def test_receding_horizon_sweep_matches_oracle(hip, oracle):
     """BASELINE config 5 in miniature: 24 closed-loop trajectories x 10 steps,
     warm-started (unshifted) from the previous solution, problem data resident
