@@ -25,6 +25,12 @@
 
 #include "fb_common.h"
 
+// Tail compaction: a wavefront with this many busy rows or fewer parks them for the
+// next launch (build knob; fbstab_hip.hip: R16Queue).
+#ifndef FB_COMPACT_MAX_BUSY
+#define FB_COMPACT_MAX_BUSY 2
+#endif
+
 // A wavefront with this many busy rows or fewer offers them to others (build knob).
 #ifndef FB_MIG_MAX_BUSY
 #define FB_MIG_MAX_BUSY 2
@@ -477,6 +483,7 @@ struct Solver : TraceState<TRACE> {
     enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5 };
     constexpr int NST = 20;  // scalars of a parked solve
     [[maybe_unused]] bool moved = false;  // this row's solve came from another wavefront
+    [[maybe_unused]] int seen_busy = 0;   // most busy rows this wavefront has had (tail compaction)
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -491,6 +498,22 @@ struct Solver : TraceState<TRACE> {
           if constexpr (P::kMigrate) {
             qu.retire(p);  // (the solve that has just ended)
             moved = false;
+          }
+          if constexpr (Queue::kResume) {
+            // this launch continues the solves the previous one parked (tail compaction)
+            double st[NST];
+            const int q = qu.fetch_parked(p, st);
+            if (q < 0) {
+              phase = kDone;
+              continue;
+            }
+            out = out_base + q;
+            combo_tol = st[0]; Ek = st[1]; E0 = st[2]; rk_last = st[3]; inner_tol = st[4];
+            dx_norm = st[5]; Ei = st[6]; Eo = st[7]; Eo_top = st[8]; Ei0 = st[9];
+            for (int m = 0; m < 5; m++) merit[m] = st[10 + m];
+            newton = (int)st[15]; prox = (int)st[16]; k = (int)st[17]; inner_i = (int)st[18];
+            phase = kNewton;
+            continue;
           }
           const int q = qu.fetch(p);
           if (q < 0) {
@@ -598,6 +621,22 @@ struct Solver : TraceState<TRACE> {
         }
       }
       if (phase == kDone) break;
+      if constexpr (Queue::kMayPark) {
+        // Tail compaction: rows that have left the loop are inactive, `busy` counts the
+        // others.  Fewer than at the start means the input has run dry; with
+        // kCompactMaxBusy or fewer left the wavefront parks them for the next launch.
+        const int busy = C::rows_where(phase == kNewton);
+        if (busy > seen_busy) seen_busy = busy;
+        if (busy <= FB_COMPACT_MAX_BUSY && busy < seen_busy) {
+          const double st[NST] = {combo_tol, Ek, E0, rk_last, inner_tol, dx_norm, Ei, Eo, Eo_top, Ei0,
+                                  merit[0], merit[1], merit[2], merit[3], merit[4],
+                                  (double)newton, (double)prox, (double)k, (double)inner_i, 0.0};
+          p.park(c, st);
+          qu.park_out(p);
+          phase = kDone;
+          break;
+        }
+      }
       if constexpr (P::kMigrate) {
         // rows that have left the loop are inactive: `busy` counts the others
         const int busy = C::rows_where(phase == kNewton);

@@ -196,11 +196,7 @@ struct MpcR16 {
   // the hand-over word of a slot (R16Queue in fbstab_hip.hip)
   static FB_DEV double* park_flag(double* ws_row, int N_) { return ws_row + hdr_doubles(N_) - 1; }
   template <int NS>
-#if !defined(FB_HOSTSIM)
-  __device__ __attribute__((noinline)) void park(const C& c, const double (&st)[NS]) const {
-#else
   FB_DEV void park(const C& c, const double (&st)[NS]) const {
-#endif
     static_assert(NS + 2 <= kParkDoubles, "park area");
     double* h = reinterpret_cast<double*>(poff) + hdr_doubles(N) - kParkDoubles;
     sfor<0, NS>([&](auto I) {

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
 // themselves are agent-scope atomics.
 constexpr int kQueueCtlInts = 8;
 constexpr int kBoardEntries = 16384;
-constexpr size_t kQueueBytes = kQueueCtlInts * sizeof(int) + kBoardEntries * sizeof(unsigned long long);
+constexpr size_t kBoardBytes = kQueueCtlInts * sizeof(int) + kBoardEntries * sizeof(unsigned long long);
 constexpr unsigned long long kBoardClaimed = 1ull << 63, kBoardDead = ~0ull;
 // The board operations are rare: as real calls they stay out of the register
 // allocation of the solver loop (build knob FB_R16_MIG_INLINE for comparison).
@@ -251,8 +251,37 @@ constexpr unsigned long long kBoardClaimed = 1ull << 63, kBoardDead = ~0ull;
 #define FB_COLD __device__ __attribute__((noinline))
 #endif
 
-template <class P, bool KEEP>
+// Tail compaction by relaunch (PHASE >= 0; the default for batches).  A batch runs
+// as three launches of this kernel on its stream.  In the first two, a wavefront
+// that is down to FB_COMPACT_MAX_BUSY (2) busy rows after the queue has run dry parks the
+// solves it still hosts (P::park - the rest of a solve lives in its slot already),
+// appends them to a list and leaves; the next launch starts from that list with
+// four parked solves per wavefront (P::resume) and continues each with the very
+// Newton step it was about to take.  Launches are ordered by the stream, so no
+// wavefront ever waits for another and nothing needs fences or atomics beyond the
+// two counters.  Why: once the queue is empty the rows of a wavefront finish at
+// different times while the wavefront holds its SIMD until the last one does -
+// 17 % of all row slots idle at batch 8192; a simulation over the measured iteration
+// counts gives 13 % less wavefront time for three launches.
+//   blk[0] next index into the input (QP queue or parked list)   blk[1] solves parked
+//   blk[8 + 2 i], blk[9 + 2 i]  slot and QP index of parked solve i
+constexpr int kCompactCap = 8192;  // >= 4 x resident wavefronts
+constexpr int kCompactBlkInts = 8 + 2 * kCompactCap;
+#if defined(FB_R16_MIGRATE) || defined(FB_R16_NO_COMPACT)
+constexpr bool kCompactBatches = false;
+#else
+constexpr bool kCompactBatches = true;
+#endif
+// the counter buffer of a handle: the board of the migration experiment or the three blocks
+constexpr size_t kQueueBytes = kBoardBytes > 3 * kCompactBlkInts * sizeof(int) ? kBoardBytes : 3 * kCompactBlkInts * sizeof(int);
+
+template <class P, bool KEEP, int PHASE = -1>
 struct R16Queue {
+  static constexpr bool kCompact = PHASE >= 0;
+  static constexpr bool kResume = PHASE >= 1;
+  static constexpr bool kMayPark = PHASE == 0 || PHASE == 1;
+  int* in_blk = nullptr;   // (kResume) the list the previous launch wrote
+  int* out_blk = nullptr;  // (kMayPark) the list this launch writes
   // Only launch-uniform values live in here (SGPRs).  What a row remembers between
   // trips sits in four spare words of its LDS region - the sweeps have no
   // registers to spare for it (a handful of VGPRs held across the Newton step
@@ -303,6 +332,26 @@ struct R16Queue {
     atomicExch(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
   }
   __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
+
+  // (kResume) binds the policy to the next parked solve; st receives its scalars.
+  template <int NS>
+  __device__ __forceinline__ int fetch_parked(P& pp, double (&st)[NS]) {
+    int i = 0;
+    if (tid() == 0) i = atomicAdd(&ctl[0], 1);
+    i = bci<0>(i);
+    if (i >= in_blk[1]) return -1;
+    const int slot = in_blk[8 + 2 * i], q = in_blk[9 + 2 * i];
+    pp.resume(tid(), slot_ptr(slot), lds(), data, x, q, N, st);
+    return q;
+  }
+  // (kMayPark) appends the solve pp has parked in its slot to this launch's list.
+  __device__ __forceinline__ void park_out(const P& pp) {
+    if (tid() == 0) {
+      const int i = atomicAdd(&out_blk[1], 1);
+      out_blk[8 + 2 * i] = (int)((reinterpret_cast<const double*>(pp.poff) - scratch) / P::ws_doubles(N));
+      out_blk[9 + 2 * i] = (int)pp.q;
+    }
+  }
 
   // Binds the policy to the next QP of the queue, in this row's own slot.
   __device__ __forceinline__ int fetch(P& pp) {
@@ -465,7 +514,7 @@ struct R16Queue {
 
 // KEEP (FBSTAB_HIP_KEEP_MATRICES): QP q is solved in slot q, so that the slot's
 // matrix copies survive from call to call; `reuse` says they are valid already.
-template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false>
+template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false, int PHASE = -1>
 __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
     int* counter, int batch, int N, int reuse, double* dbg) {
@@ -478,10 +527,17 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
   Ctx16 ctx;
   ctx.tid = lane & 15;
   P p;
-  R16Queue<P, KEEP> qu;
+  R16Queue<P, KEEP, PHASE> qu;
   qu.data = &data;
   qu.x = &x;
-  qu.ctl = counter;
+  if constexpr (PHASE >= 0) {
+    // one block of the counter buffer per launch of the batch
+    qu.ctl = counter + PHASE * kCompactBlkInts;
+    qu.out_blk = qu.ctl;
+    if constexpr (PHASE >= 1) qu.in_blk = counter + reuse * kCompactBlkInts;  // (`reuse`: block the list is in)
+  } else {
+    qu.ctl = counter;
+  }
   qu.board = reinterpret_cast<unsigned long long*>(counter + kQueueCtlInts);
   qu.scratch = scratch;
   qu.batch = batch;
@@ -731,6 +787,7 @@ struct fbstab_mpc_solver : SolverBase {
   bool g16 = false;       // 16-lane register kernel (four QPs per wavefront)
   bool r16 = false;       // record-based 16-lane kernel (fb_mpc_r16.h), the default for its shapes
   int kept_batch = -1;    // batch size of the last FBSTAB_HIP_KEEP_MATRICES call whose copies are still in the slots
+  int compact_phases = 1; // launches per batch of the record kernel (tail compaction, R16Queue)
   int lds_per_row = 0;
   int qps_per_wg = 1;
 };
@@ -774,6 +831,35 @@ void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArg
       else
         hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, false, true>), dim3(grid), dim3(64), h->lds_bytes,
                            s, d, x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, ru, dbg);
+      return;
+    }
+  }
+  if constexpr (!DBG && kCompactBatches) {
+    // tail compaction (R16Queue): up to three launches, each at most two parked solves
+    // per wavefront of the one before, four per wavefront of its own
+    if (h->compact_phases >= 2) {
+      const int g1 = (grid + 1) / 2, g2 = (g1 + 1) / 2;
+#define FB_LAUNCH_PHASE(EX, PH, G, IN)                                                                             \
+  hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, EX, false, PH>), dim3(G), dim3(64), h->lds_bytes, s, d, \
+                     x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, IN, dbg)
+      if (exact) {
+        FB_LAUNCH_PHASE(true, 0, grid, 0);
+        if (h->compact_phases >= 3) {
+          FB_LAUNCH_PHASE(true, 1, g1, 0);
+          FB_LAUNCH_PHASE(true, 2, g2, 1);
+        } else {
+          FB_LAUNCH_PHASE(true, 2, g1, 0);
+        }
+      } else {
+        FB_LAUNCH_PHASE(false, 0, grid, 0);
+        if (h->compact_phases >= 3) {
+          FB_LAUNCH_PHASE(false, 1, g1, 0);
+          FB_LAUNCH_PHASE(false, 2, g2, 1);
+        } else {
+          FB_LAUNCH_PHASE(false, 2, g1, 0);
+        }
+      }
+#undef FB_LAUNCH_PHASE
       return;
     }
   }
@@ -841,8 +927,12 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
   const bool exact = g16_shape(nx, nu, nc);
-  const void* kern = s->r16   ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true>)
-                                       : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false>))
+  const void* r16_first =
+      kCompactBatches ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, false, 0>)
+                               : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, false, 0>))
+                      : (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true>)
+                               : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false>));
+  const void* kern = s->r16   ? r16_first
                      : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, false>)
                               : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>);
   const void* kern_dbg = s->r16   ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true, true>)
@@ -854,6 +944,14 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
     const void* kk = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, true>)
                            : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, true>);
     e = hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+    if (kCompactBatches) {
+      const void* k1 = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, false, 1>)
+                             : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, false, 1>);
+      const void* k2 = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, false, 2>)
+                             : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, false, 2>);
+      if (e == hipSuccess) e = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+      if (e == hipSuccess) e = hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+    }
   }
   if (e == hipSuccess) e = hipFuncSetAttribute(kern_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0, cus = 0;
@@ -870,7 +968,12 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   if (per_cu > 8) per_cu = 8;
   const char* env = getenv("FBSTAB_HIP_WGS_PER_CU");
   if (env && atoi(env) > 0) per_cu = atoi(env);
+  {
+    const char* cp = getenv("FBSTAB_HIP_COMPACT_PHASES");
+    if (cp && atoi(cp) >= 1 && atoi(cp) <= 3) s->compact_phases = atoi(cp);
+  }
   s->workgroups = cus * per_cu;
+  if (s->r16 && 2 * s->workgroups > kCompactCap) s->workgroups = kCompactCap / 2;  // (list capacity, R16Queue)
   {
     const int need = (max_batch + s->qps_per_wg - 1) / s->qps_per_wg;
     if (s->workgroups > need) s->workgroups = need;
