@@ -402,6 +402,23 @@ def test_mpc_device_pointers_match_host_pointers(hip):
     assert np.array_equal(v.cpu().numpy(), host[2])
 
 
+@pytest.mark.parametrize("phases", [2, 3])
+def test_tail_compaction_changes_nothing_but_the_schedule(hip, monkeypatch, phases):
+    """FBSTAB_HIP_COMPACT_PHASES: the batch runs as 2 or 3 launches, wavefronts that
+    thin out park their solves for the next one (R16Queue in fbstab_hip.hip).  A
+    parked solve continues with the very Newton step it was about to take, so
+    every output is bitwise what the single launch gives."""
+    p = fx.synthetic_mpc_batch(700, first_id=2500)
+    o = default_options()
+    ref = _solve_mpc_host(hip, p, o)
+    monkeypatch.setenv("FBSTAB_HIP_COMPACT_PHASES", str(phases))
+    got = _solve_mpc_host(hip, p, o)
+    for a, b in zip(ref[:4], got[:4]):
+        assert np.array_equal(a, b)
+    for f in ("eflag", "newton_iters", "prox_iters", "residual"):
+        assert np.array_equal(ref[4][f], got[4][f]), f
+
+
 def test_two_batches_in_flight_equal_one_at_a_time(hip):
     """What bench.py does by default: two handles on two HIP streams, launches
     asynchronous on device pointers, consecutive batches overlapping on the GPU.
