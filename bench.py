@@ -9,7 +9,7 @@ One "step" = one fbstab_hip_mpc_solve_batch call over the rank's whole shard
 (cold start, zero initial guess), problem data already resident in HBM.  For
 N > 1 the batch is sharded by global instance id (weak scaling, 8192 QPs per
 GPU) and each step ends with one RCCL gather of the solutions to rank 0.
-Consecutive steps are issued on --pipeline (default 3) alternating HIP streams,
+Consecutive steps are issued on --pipeline (default 8, one per hardware queue) alternating HIP streams,
 each with its own solver handle and output buffers, the way a stream of
 batches is served: iteration counts differ 10x between QPs, so the tail of
 one batch (a few slow QPs) overlaps the bulk of the next.  --pipeline 1
@@ -86,8 +86,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="QPs per GPU")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=8,
                     help="steps in flight (alternating streams/handles); 1 = serial")
+    ap.add_argument("--first-id", type=int, default=None,
+                    help="developer option: first global instance id of this rank's shard "
+                         "(default: rank * batch, the shard bench runs under torch.distributed.run)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="QPs for the CPU baseline (0 disables; default sized for ~15 s)")
     args = ap.parse_args()
@@ -116,6 +119,8 @@ def main():
     P = max(1, args.pipeline)
     from fbstab_amd import sharding
     first_id, _ = sharding.shard_range(rank, world, B)
+    if args.first_id is not None:
+        first_id = args.first_id
     p = fx.synthetic_mpc_batch(B, first_id=first_id)  # shard by global instance id
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
     nvar = p.nz + p.nl + 2 * p.nv
@@ -200,10 +205,16 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(B),
                          "kernel": "fbstab_mpc_r16_kernel<12,4,20>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B},
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B,
+                         # `achieved` divides by the duration of one launch as rocprof sees it; with
+                         # P launches sharing the GPU that duration is ~P times the time the GPU
+                         # spends per batch, which ms_per_step measures:
+                         "launches_in_flight": P,
+                         "achieved_per_step": ALG_BYTES_PER_QP * B * world / (elapsed / args.steps) / 1e9},
             "fp64": {"model_flop_per_newton_iter": FLOP_PER_NEWTON,
                      "mean_newton_iters": mean_newton,
-                     "achieved_tflops": FLOP_PER_NEWTON * mean_newton * B / (k_ms * 1e-3) / 1e12,
+                     # (rate of the whole GPU: flops of one batch over the time per step)
+                     "achieved_tflops": FLOP_PER_NEWTON * mean_newton * B * world / (elapsed / args.steps) / 1e12 / world,
                      "peak_tflops": FP64_PEAK_TFLOPS},
             "all_converged": ok,
             "launch": solver.query(),
