@@ -625,6 +625,29 @@ def test_full_size_properties(hip):
     assert np.array_equal(out["newton_iters"], out2["newton_iters"])
 
 
+def test_shard_of_rank_one_matches_the_oracle_including_its_iteration_limit_qps(hip, oracle):
+    """BASELINE config 4 shards the ids 0..65535 over eight GPUs.  The shard of rank 1
+    (ids 8192..16383) holds two instances that run to the 200-iteration limit
+    (11960 and 15020) on the reference path too: exit flags equal everywhere,
+    iteration counts equal on every instance that converges, and for the two that
+    do not, both report MAXITERATIONS after max_newton_iters steps."""
+    B, first = 8192, 8192
+    p = fx.synthetic_mpc_batch(B, first_id=first)
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    assert np.array_equal(gpu[4]["eflag"], cpu[4]["eflag"])
+    hard = np.where(cpu[4]["eflag"] != 0)[0]
+    assert sorted((hard + first).tolist()) == [11960, 15020]
+    assert (cpu[4]["eflag"][hard] == 2).all() and (gpu[4]["newton_iters"][hard] == 200).all()
+    easy = cpu[4]["eflag"] == 0
+    assert np.array_equal(gpu[4]["prox_iters"][easy], cpu[4]["prox_iters"][easy])
+    dn = np.abs(gpu[4]["newton_iters"][easy].astype(int) - cpu[4]["newton_iters"][easy].astype(int))
+    assert (dn == 0).mean() >= 0.99 and dn.max() <= 2  # the parity bar of DESIGN.md section 2
+    for a, b in zip(gpu[:3], cpu[:3]):
+        assert np.abs(a[easy] - b[easy]).max() <= 10 * o.abs_tol * (1 + np.abs(b[easy]).max())
+
+
 @pytest.mark.parametrize("problem,N", [("ServoMotor", 25), ("SpacecraftRelativeMotion", 40), ("DoubleIntegrator", 20)])
 def test_closed_loop_with_the_generator_simulation_inputs(hip, oracle, problem, N):
     """The reference's OcpGenerator hands out, next to the QP, the matrices to
