@@ -210,7 +210,10 @@ def main():
                          # P launches sharing the GPU that duration is ~P times the time the GPU
                          # spends per batch, which ms_per_step measures:
                          "launches_in_flight": P,
-                         "achieved_per_step": ALG_BYTES_PER_QP * B * world / (elapsed / args.steps) / 1e9},
+                         "achieved_per_step": ALG_BYTES_PER_QP * B * world / (elapsed / args.steps) / 1e9,
+                         # what the kernel actually moves (PMC bytes of one launch) per second of this
+                         # run, per GPU: the figure to hold against the HBM peak
+                         "traffic_per_step_GBps": (pmc_traffic(B) or 0.0) / (elapsed / args.steps) / 1e9 or None},
             "fp64": {"model_flop_per_newton_iter": FLOP_PER_NEWTON,
                      "mean_newton_iters": mean_newton,
                      # (rate of the whole GPU: flops of one batch over the time per step)
