@@ -1118,7 +1118,9 @@ struct MpcR16 {
         const double hsum = bc_dot<0, NX>(Pinv, th);
         if (rx) gv = r1 - hsum;
       }
-      stv<fPinv, NX>(R, Pinv);
+      // (lanes NX..15 hold no row of inv(Pi): their quarter of every slot is neither
+      // written nor read back - the pipelined solver is bound by these bytes)
+      if (rx) stv<fPinv, NX>(R, Pinv);
       FB_SB();
       FB_STAMP_LAP(2);
       // [A B] row r for W, requested now so that it arrives behind the chains
@@ -1221,7 +1223,10 @@ struct MpcR16 {
       double lbn = 0.0;
       auto load_g0 = [&]() { ldv<fX, NS>(R, XC); ldv<pABc, NX>(PK, Ac); tth = ld2(R, fT); };
       auto load_g1 = [&]() {};
-      auto load_g2 = [&]() { ldv<fPinv, NX>(R, Pinv); };
+      auto load_g2 = [&]() {
+        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
+        if (rx) ldv<fPinv, NX>(R, Pinv);
+      };
       auto load_g3 = [&]() {
         ldl<pC, NC>(Lp, Cc_);
         sfor<0, KS>([&](auto S_) {
