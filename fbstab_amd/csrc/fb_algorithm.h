@@ -25,17 +25,6 @@
 
 #include "fb_common.h"
 
-// Tail compaction: a wavefront with this many busy rows or fewer parks them for the
-// next launch (build knob; fbstab_hip.hip: R16Queue).
-#ifndef FB_COMPACT_MAX_BUSY
-#define FB_COMPACT_MAX_BUSY 2
-#endif
-
-// A wavefront with this many busy rows or fewer offers them to others (build knob).
-#ifndef FB_MIG_MAX_BUSY
-#define FB_MIG_MAX_BUSY 2
-#endif
-
 // Step lengths evaluated per line-search pass (build knob).
 #ifndef FB_LS_KT
 #define FB_LS_KT 4
@@ -459,31 +448,9 @@ struct Solver : TraceState<TRACE> {
   // Same statements, same order per QP as solve()/subproblem_fused().
   // `qu.fetch(p)` binds the policy to the next QP and returns its index or -1.
   //
-  // Once the queue is empty the rows of a wavefront finish at different times and
-  // the wavefront lives until its last row does (17 % of all row slots idle at
-  // batch 8192).  With P::kMigrate a wavefront that is down to one or two busy
-  // rows therefore invites others to take those solves (qu.invite) and keeps
-  // solving.  A wavefront whose four rows have all run out of work does not leave
-  // at once: its rows accept open invitations (qu.claim).  The owner notices at
-  // its next stop in front of a Newton step, parks the loop's scalars in the QP's
-  // slot (P::park - everything else of a solve lives there already) and lets go
-  // (qu.hand_over); the new row picks the solve up (qu.take_over -> P::resume) and
-  // takes the very Newton step the old one was about to take.  Solves of several
-  // thin wavefronts gather in one full one and the thin ones leave their SIMD to
-  // the next launch.  A solve moves at most once.  Only wavefronts without work
-  // ever wait (for one Newton step of an owner, who cannot leave: it ends the
-  // solve or hands it over), and the loop the busy rows run is the plain one: rows
-  // leave it when they are done.  (An earlier version kept idle rows polling inside
-  // that loop; lanes that take a loop edge early are not held until the others
-  // arrive, the idle rows ran ahead and the busy rows of their own wavefront
-  // starved - wavefronts waiting on each other's solves then deadlock.)  The
-  // arithmetic of a QP does not depend on which rows ran it.
   template <class Queue>
   FB_DEV void solve_stream(Queue& qu, fbstab_solver_out_t* out_base) const {
     enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5 };
-    constexpr int NST = 20;  // scalars of a parked solve
-    [[maybe_unused]] bool moved = false;  // this row's solve came from another wavefront
-    [[maybe_unused]] int seen_busy = 0;   // most busy rows this wavefront has had (tail compaction)
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -491,30 +458,9 @@ struct Solver : TraceState<TRACE> {
     double Ei = 0.0, Eo = 0.0, Eo_top = 0.0, Ei0 = 0.0;
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
-    for (;;) {  // (kMigrate: once per set of solves this wavefront hosts)
     for (;;) {
       while (phase != kNewton && phase != kDone) {
         if (phase == kFetch) {
-          if constexpr (P::kMigrate) {
-            qu.retire(p);  // (the solve that has just ended)
-            moved = false;
-          }
-          if constexpr (Queue::kResume) {
-            // this launch continues the solves the previous one parked (tail compaction)
-            double st[NST];
-            const int q = qu.fetch_parked(p, st);
-            if (q < 0) {
-              phase = kDone;
-              continue;
-            }
-            out = out_base + q;
-            combo_tol = st[0]; Ek = st[1]; E0 = st[2]; rk_last = st[3]; inner_tol = st[4];
-            dx_norm = st[5]; Ei = st[6]; Eo = st[7]; Eo_top = st[8]; Ei0 = st[9];
-            for (int m = 0; m < 5; m++) merit[m] = st[10 + m];
-            newton = (int)st[15]; prox = (int)st[16]; k = (int)st[17]; inner_i = (int)st[18];
-            phase = kNewton;
-            continue;
-          }
           const int q = qu.fetch(p);
           if (q < 0) {
             phase = kDone;
@@ -621,41 +567,6 @@ struct Solver : TraceState<TRACE> {
         }
       }
       if (phase == kDone) break;
-      if constexpr (Queue::kMayPark) {
-        // Tail compaction: rows that have left the loop are inactive, `busy` counts the
-        // others.  Fewer than at the start means the input has run dry; with
-        // kCompactMaxBusy or fewer left the wavefront parks them for the next launch.
-        const int busy = C::rows_where(phase == kNewton);
-        if (busy > seen_busy) seen_busy = busy;
-        if (busy <= FB_COMPACT_MAX_BUSY && busy < seen_busy) {
-          const double st[NST] = {combo_tol, Ek, E0, rk_last, inner_tol, dx_norm, Ei, Eo, Eo_top, Ei0,
-                                  merit[0], merit[1], merit[2], merit[3], merit[4],
-                                  (double)newton, (double)prox, (double)k, (double)inner_i, 0.0};
-          p.park(c, st);
-          qu.park_out(p);
-          phase = kDone;
-          break;
-        }
-      }
-      if constexpr (P::kMigrate) {
-        // rows that have left the loop are inactive: `busy` counts the others
-        const int busy = C::rows_where(phase == kNewton);
-        bool gone = false;
-        if (qu.invited()) {
-          if (qu.claimed(p)) {
-            const double st[NST] = {combo_tol, Ek, E0, rk_last, inner_tol, dx_norm, Ei, Eo, Eo_top, Ei0,
-                                    merit[0], merit[1], merit[2], merit[3], merit[4],
-                                    (double)newton, (double)prox, (double)k, (double)inner_i, 0.0};
-            p.park(c, st);
-            qu.hand_over(p);
-            phase = kDone;
-            gone = true;
-          }
-        } else if (busy <= FB_MIG_MAX_BUSY && !moved) {
-          qu.invite(p, busy);
-        }
-        if (gone) break;
-      }
       // ---- one Newton step and its line search (impl:262-298), all rows together
       {
       // The loop's scalars are not needed until the line search is over: they wait
@@ -754,36 +665,6 @@ struct Solver : TraceState<TRACE> {
       phase = kInnerTop;
       }  // step taken
       }
-    }
-    if constexpr (!P::kMigrate) {
-      break;
-    } else {
-      // ---- all four rows are out of work: take over solves other wavefronts offer
-      qu.claim();
-      for (int spin = 0; C::rows_where(qu.waiting()) != 0; spin++) {
-        if (qu.waiting()) {
-          double st[NST];
-          int q = 0;
-          if (qu.take_over(p, st, &q) == 1) {
-            out = out_base + q;
-            combo_tol = st[0]; Ek = st[1]; E0 = st[2]; rk_last = st[3]; inner_tol = st[4];
-            dx_norm = st[5]; Ei = st[6]; Eo = st[7]; Eo_top = st[8]; Ei0 = st[9];
-            for (int m = 0; m < 5; m++) merit[m] = st[10 + m];
-            newton = (int)st[15]; prox = (int)st[16]; k = (int)st[17]; inner_i = (int)st[18];
-            moved = true;
-            phase = kNewton;
-          }
-        }
-        // an owner hands over within one Newton step (< 1 ms); a wavefront that has
-        // waited a thousand times longer reports (ctl[4]) and leaves rather than hang
-        if (spin > 400000) {
-          qu.give_up();
-          break;
-        }
-        __builtin_amdgcn_s_sleep(127);
-      }
-      if (C::rows_where(phase == kNewton) == 0) break;
-    }
     }
   }
 

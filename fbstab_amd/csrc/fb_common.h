@@ -239,10 +239,31 @@ FB_DEV double sat(double x, double lo, double hi) {
   return t > lo ? t : lo;
 }
 
+// sqrt(x) for x >= 0 inside the Fischer-Burmeister function, where half of the
+// passes' instructions used to be the IEEE sqrt sequence (two residual steps,
+// range scaling and special-case selects around v_rsq_f64): hardware seed, one
+// coupled Goldschmidt step and ONE residual correction - within an ulp - and no
+// scaling (a^2 + b^2 has underflowed or overflowed long before the scaling would
+// matter).  sqrt(0) = 0 exactly: the NaN of 0 * inf is dropped by the final max.
+FB_DEV double fsqrt(double x) {
+#if defined(FB_HOSTSIM)
+  return sqrt(x);
+#else
+  const double r = __builtin_amdgcn_rsq(x);
+  double g = x * r, h = 0.5 * r;
+  const double d = fma(-h, g, 0.5);
+  g = fma(g, d, g);
+  h = fma(h, d, h);
+  const double e = fma(-g, g, x);
+  g = fma(e, h, g);
+  return __builtin_fmax(g, 0.0);
+#endif
+}
+
 // phi(a,b) = alpha (a + b - sqrt(a^2+b^2)) + (1-alpha) max(0,a) max(0,b)
 // (reference: full_residual.cc:115-118).
 FB_DEV double pfb(double a, double b, double alpha) {
-  const double fb = a + b - sqrt(a * a + b * b);
+  const double fb = a + b - fsqrt(a * a + b * b);
   return alpha * fb + (1.0 - alpha) * fmax0(a) * fmax0(b);
 }
 
@@ -256,7 +277,7 @@ FB_DEV double pnr(double y, double v, double alpha) {
 // Generalised gradient of phi (reference: riccati_linear_solver.cc:346-365 and
 // dense_cholesky_solver.cc:129-148, zero_tolerance_ = 1e-13).
 FB_DEV void pfb_gradient(double a, double b, double alpha, double* g0, double* g1) {
-  const double r = sqrt(a * a + b * b);
+  const double r = fsqrt(a * a + b * b);
   const double d = 0.70710678118654752440;  // 1/sqrt(2)
   if (r < 1e-13) {
     *g0 = alpha * (1.0 - d);
@@ -288,7 +309,7 @@ FB_DEV double rcp_fast(double x) {
 // phi(a,b) and its generalised gradient from ONE sqrt and ONE reciprocal
 // (pfb + pfb_gradient share r = sqrt(a^2+b^2)); same formulas as above.
 FB_DEV void pfb_all(double a, double b, double alpha, double* phi, double* g0, double* g1) {
-  const double r = sqrt(a * a + b * b);
+  const double r = fsqrt(a * a + b * b);
   const double pa = fmax0(a), pb = fmax0(b);
   *phi = alpha * (a + b - r) + (1.0 - alpha) * pa * pb;
   if (r < 1e-13) {

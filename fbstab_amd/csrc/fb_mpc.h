@@ -43,8 +43,7 @@ struct MpcLayout {
   int f_minv, f_sm, f_am, f_p, f_sginv, f_linv, f_tx, f_tu, f_th, f_stride;
   // iterate vectors in global scratch (offsets in doubles)
   long v_z, v_l, v_v, v_y, v_zb, v_lb, v_vb, v_yb, v_dz, v_dl, v_dv, v_adz, v_rz, v_rl,
-      v_wz, v_wl, v_gam, v_rvm, v_fac, v_pack, ws_doubles;
-  int pack_stride;  // doubles per stage of the lane-major data copy (fb_mpc_g16.h), 0 if unused
+      v_wz, v_wl, v_gam, v_rvm, v_fac, ws_doubles;
   // LDS carve (offsets in doubles)
   int t_q, t_r, t_s, t_a, t_b, t_e, t_l;                  // data tile
   int s_z, s_l, s_ln, s_v;                                // vector slices of the stage
@@ -72,11 +71,6 @@ struct MpcLayout {
     f_tu = o; o += nu;
     f_th = o; o += nx;
     f_stride = (o + 1) & ~1;
-    // the 16-lane register kernel (fb_mpc_g16.h) keeps a larger record
-    if (nx + nu <= 16) {
-      const int g16 = 512 + 16 * nx + 32;
-      if (g16 > f_stride) f_stride = g16;
-    }
     long g = 0;
     v_z = g; g += nz;  v_l = g; g += nl;  v_v = g; g += nv;  v_y = g; g += nv;
     v_zb = g; g += nz; v_lb = g; g += nl; v_vb = g; g += nv; v_yb = g; g += nv;
@@ -85,16 +79,6 @@ struct MpcLayout {
     v_gam = g; g += nv; v_rvm = g; g += nv;
     g = (g + 1) & ~1L;
     v_fac = g; g += (long)f_stride * (N + 1);
-    // lane-major copy of the stage matrices for the 16-lane register kernel:
-    // 16 doubles per slot, slots = rows of [Q S';S R], columns of [E L], rows and
-    // columns of [A B]
-    pack_stride = 0;
-    g = (g + 15) & ~15L;
-    v_pack = g;
-    if (nx + nu <= 16) {
-      pack_stride = 16 * ((16 + ((nc + 1) & ~1) + 16 + nx + 1) & ~1);
-      g += (long)pack_stride * (N + 1);
-    }
     ws_doubles = (g + 15) & ~15L;  // 128-byte multiple per workgroup slot
     int s = 0;
     t_q = s; s += nx * nx;  t_r = s; s += nu * nu;  t_s = s; s += nu * nx;

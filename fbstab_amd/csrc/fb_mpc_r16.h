@@ -4,11 +4,10 @@
 // per stage through a single base pointer.
 //
 // Mathematics: the block form of RiccatiLinearSolver documented at the top of
-// fb_mpc_g16.h (riccati_linear_solver.cc:77-344), the residual / feasibility /
+// fb_row16.h (riccati_linear_solver.cc:77-344), the residual / feasibility /
 // variable algebra of full_residual.cc:49-109, full_feasibility.cc:25-88,
 // full_variable.cc:47-83 and the implicit block products of mpc_data.cc:17-289.
-// What differs from MpcProblemG16 is where the data lives and who runs the
-// proximal-level passes:
+// Where the data lives and who runs the proximal-level passes:
 //
 //   * Stage record i of a QP = kSlots slots of 16 doubles, lane r of the row
 //     owning element r of every slot:
@@ -36,7 +35,7 @@
 //     [A B]'dl and the row triangle of inv(Lc) instead of reading W by columns.
 #pragma once
 
-#include "fb_mpc_g16.h"
+#include "fb_row16.h"
 
 namespace fbk {
 
@@ -64,13 +63,9 @@ struct MpcR16 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   static constexpr bool kFusedTrial = true;
   static constexpr bool kOwnVectorOps = true;
-#if defined(FB_R16_PREFETCH)
-  static constexpr bool kPrefetch = FB_R16_PREFETCH != 0;
-#elif defined(FB_R16_MIN_WAVES) && FB_R16_MIN_WAVES > 1
-  static constexpr bool kPrefetch = false;
-#else
+  // the loads of stage i+1 are issued during stage i (one wavefront per SIMD:
+  // nothing else covers their latency)
   static constexpr bool kPrefetch = true;
-#endif
   static constexpr int NS = NX + NU;
   static constexpr int KS = (NC + 15) / 16;  // constraint slots per lane
   static_assert(NS <= 16, "stage width must fit one DPP row");
@@ -104,9 +99,8 @@ struct MpcR16 {
   static constexpr int pABc = pABr + 16;               // column r of [A B], NX slots
   static constexpr int kPackSlots = (pABc + NX + 1) & ~1;
   static constexpr int kPack = 16 * kPackSlots;
-  // poff[N+1] ints and the flag word, then kParkDoubles for a parked solve (below)
-  static constexpr int kParkDoubles = 32;
-  static constexpr long hdr_doubles(int N) { return (((N + 1) / 2 + 16) & ~15L) + kParkDoubles; }
+  // poff[N+1] ints and the flag word
+  static constexpr long hdr_doubles(int N) { return ((N + 1) / 2 + 16) & ~15L; }
   static constexpr long ws_doubles(int N) { return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1); }
 
   static constexpr int off(int slot) { return (slot >> 1) * 32 + (slot & 1); }
@@ -121,13 +115,7 @@ struct MpcR16 {
   //                   buffer (forward sweep); odd strides.
   static constexpr int CS = NC | 1, TS = 17;
   static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
-#if defined(FB_R16_PACK_GLOBAL)
-  // (build knob for the two-waves-per-SIMD experiments: the copy stays in
-  // global memory / L2 and LDS holds the transposes only, 11.5 KB per wavefront)
-  static constexpr bool kPackInLds = false;
-#else
   static constexpr bool kPackInLds = true;
-#endif
   static constexpr int kPackLds = kPackInLds ? 16 * kPackLdsSlots : 0;
   // this lane's view of the matrix copy in use
   typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
@@ -137,7 +125,16 @@ struct MpcR16 {
   // ---- state -------------------------------------------------------------------
   double* rec;   // this row's records, lane offset included
   double* pack;  // this row's matrix copies, lane offset included
-  int* poff;     // per stage: offset (doubles) of the copy it reads
+  int* poff;     // per stage: offset (doubles) of the copy it reads (the slot's own table, kept
+                 // between calls for FBSTAB_HIP_KEEP_MATRICES)
+  // ... and its working copy in LDS: the passes read it every stage, and a global
+  // load there would make each stage wait for every memory operation in flight
+  // (loads return in order: the wait for the offset drains the prefetched records
+  // and the stores of the previous stage with it).
+  typedef FB_LDS int* lds_iptr;
+  lds_iptr lpo;
+  // ints of LDS per row for the table (N + 1 offsets and the flag word)
+  static constexpr int lpo_ints(int N) { return (N + 3) & ~1; }
   int lds_off;   // offset of the copy currently in LDS (-1: none)
   bool reuse = false;  // (KEEP instances) the slot's matrix copies are those of this QP already
   // Every constraint row of every stage has at most one nonzero (bounds on single
@@ -164,10 +161,11 @@ struct MpcR16 {
   // next forward sweep applies it stage by stage, everything else flushes first.
   double pend_t;
 
-  FB_DEV void bind(double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d, const VarBatchPtrs* x,
-                   long q_, int N_, int lane16) {
+  FB_DEV void bind(double* ws_row, lds_ptr lds_row, lds_iptr lpo_row, const MpcBatchPtrs* d,
+                   const VarBatchPtrs* x, long q_, int N_, int lane16) {
     lds_off = -1;
     poff = reinterpret_cast<int*>(ws_row);
+    lpo = lpo_row;
     pack = ws_row + hdr_doubles(N_) + 2 * lane16;
     rec = pack + (long)kPack * (N_ + 1);
     lds = lds_row;
@@ -178,44 +176,6 @@ struct MpcR16 {
     pend_t = 0.0;
   }
   FB_DEV int num_primal_dual() const { return (N + 1) * (2 * prob_nx() + prob_nu() + prob_nc()); }
-
-  // ---- handing a solve in progress to another row (Solver::solve_stream) -----------
-  // Everything a solve owns lives in its slot (records, matrix copies, poff) except
-  // the loop's scalars: park() writes those (row-uniform) into the slot header,
-  // resume() binds a row to a parked slot and reads them back.  The step that was
-  // accepted but not applied yet travels as a scalar too.
-  // Off by default (-DFB_R16_MIGRATE turns it on): as measured in round 1 it packs
-  // the rows better (0.82 -> 0.86-0.91 busy rows per wavefront step) but the kernel
-  // instance with it compiled in loses more in its line-search pass (register
-  // spills inside the stage loop) than the packing gains; see DESIGN.md section 5.
-#if defined(FB_R16_MIGRATE)
-  static constexpr bool kMigrate = !KEEP;
-#else
-  static constexpr bool kMigrate = false;
-#endif
-  // the hand-over word of a slot (R16Queue in fbstab_hip.hip)
-  static FB_DEV double* park_flag(double* ws_row, int N_) { return ws_row + hdr_doubles(N_) - 1; }
-  template <int NS>
-  FB_DEV void park(const C& c, const double (&st)[NS]) const {
-    static_assert(NS + 2 <= kParkDoubles, "park area");
-    double* h = reinterpret_cast<double*>(poff) + hdr_doubles(N) - kParkDoubles;
-    sfor<0, NS>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      if (c.tid == (i & 15)) h[i] = st[i];
-    });
-    if (c.tid == 0) h[NS] = pend_t;
-  }
-  template <int NS>
-  FB_DEV void resume(int lane16, double* ws_row, lds_ptr lds_row, const MpcBatchPtrs* d,
-                     const VarBatchPtrs* x, long q_, int N_, double (&st)[NS]) {
-    bind(ws_row, lds_row, d, x, q_, N_, lane16);
-    const double* h = ws_row + hdr_doubles(N_) - kParkDoubles;
-    sfor<0, NS>([&](auto I) { st[decltype(I)::value] = h[decltype(I)::value]; });
-    pend_t = h[NS];
-#if !defined(FB_R16_NO_BOUNDS_PATH)
-    bounds = poff[N_ + 1] != 0;
-#endif
-  }
 
   // ---- record access -------------------------------------------------------------
   static FB_DEV double ld(const double* R, int slot) { return R[off(slot)]; }
@@ -353,6 +313,7 @@ struct MpcR16 {
     pend_t = 0.0;
     double* const P0 = pack;
     int* const po = poff;
+    const lds_iptr lp = lpo;
     bool single = true;  // no constraint row with two nonzeros seen so far (row-uniform)
     int canon = 0;  // offset of the copy the previous stage uses (row-uniform)
     double lastKr[16], lastABr[16], lastCc[NC], lastABc[NX];  // that copy's values, this lane's share
@@ -367,7 +328,9 @@ struct MpcR16 {
       bool fresh = true;
       if constexpr (KEEP) fresh = !reuse;
       if (!fresh) {
-        ldv<pC, NC>(P0 + po[i], Cc);  // only C is needed here (y = b - A z)
+        const int kept = po[i];
+        lp[i] = kept;
+        ldv<pC, NC>(P0 + kept, Cc);  // only C is needed here (y = b - A z)
       } else {
         // matrices (the caller's arrays have the problem's own strides nx, nu, nc)
         double Kr[16], ABr[16], ABc[NX];
@@ -405,7 +368,6 @@ struct MpcR16 {
             ABc[j] = (rs_ && has_ab && j < nx_) ? src[j] : 0.0;
           });
         }
-#if !defined(FB_R16_NO_BOUNDS_PATH)
         {
           const int rowsh = 16 * ((threadIdx.x & 63) >> 4);
           sfor<0, NC>([&](auto Kk) {
@@ -413,7 +375,6 @@ struct MpcR16 {
             single = single && __popc((unsigned)(m >> rowsh) & 0xffffu) <= 1;
           });
         }
-#endif
         // A stage whose matrices equal (bitwise) those of the previous stage
         // shares its copy: nothing is written for it.
         bool differs = i == 0;
@@ -423,9 +384,6 @@ struct MpcR16 {
         });
         sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == lastCc[decltype(Kk)::value]); });
         sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == lastABc[decltype(J)::value]); });
-  #if defined(FB_R16_NO_SHARED_PACK)
-        differs = true;
-  #endif
         if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) {
           canon = i * kPack;
           stv<pK, 16>(PK, Kr);
@@ -439,7 +397,8 @@ struct MpcR16 {
           sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
           sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = ABc[decltype(J)::value]; });
         }
-        po[i] = canon;  // every lane: each later reads its own store
+        po[i] = canon;
+        lp[i] = canon;
       }
       lds_off = -1;
       // constants f, h, b (mpc_data.cc:240-289)
@@ -467,14 +426,13 @@ struct MpcR16 {
         st2(R, sDV + 2 * s, 0.0, 0.0);
       });
     }
-#if !defined(FB_R16_NO_BOUNDS_PATH)
     {
       bool fresh_all = true;
       if constexpr (KEEP) fresh_all = !reuse;
       if (fresh_all) po[N_ + 1] = single ? 1 : 0;  // (kept with the copies for FBSTAB_HIP_KEEP_MATRICES)
-      bounds = po[N_ + 1] != 0;
+      else single = po[N_ + 1] != 0;
+      bounds = single;
     }
-#endif
     c.sync();
   }
 
@@ -485,7 +443,7 @@ struct MpcR16 {
     const bool rx = r < NX;
     double* const R0 = rec;
     const double* const P0 = pack;
-    const int* const po = poff;
+    const lds_iptr po = lpo;
     pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
@@ -574,11 +532,7 @@ struct MpcR16 {
     });
   }
   template <int K>
-#if defined(FB_R16_NOINLINE_NORMS) && !defined(FB_HOSTSIM)
-  __device__ __attribute__((noinline)) void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
-#else
   FB_DEV void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
-#endif
                              double (&Ei)[K], double (&Eo)[K]) {
     FB_WAVE_COUNT(24);
     FB_WAVE_TIMER(23);
@@ -677,7 +631,7 @@ struct MpcR16 {
     pend_t = 0.0;
     double* const R0 = rec;
     const double* const P0 = pack;
-    const int* const po = poff;
+    const lds_iptr po = lpo;
     pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     lds_ptr Cl = lds + kPackLds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
@@ -804,7 +758,7 @@ struct MpcR16 {
     const bool rx = r < NX;
     double* const R0 = rec;
     const double* const P0 = pack;
-    const int* const po = poff;
+    const lds_iptr po = lpo;
     pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     double s_nat = 0.0, s_vo = 0.0, s_vi = 0.0;
     struct OIn {
@@ -1017,7 +971,7 @@ struct MpcR16 {
     const int r = c.tid;
     double* const R0 = rec;
     const double* const P0 = pack;
-    const int* const po = poff;
+    const lds_iptr po = lpo;
     pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
     lds_ptr Tr = lds + kPackLds;
     lds_ptr Cl = lds + kPackLds;
@@ -1123,16 +1077,18 @@ struct MpcR16 {
       if (rx) stv<fPinv, NX>(R, Pinv);
       FB_SB();
       FB_STAMP_LAP(2);
-      // [A B] row r for W, requested now so that it arrives behind the chains
-      double AB[NS];
-      ldl<pABr, NS>(Lp, AB);
-      // ---- Lc = chol(K), columns of inv(Lc)
+      // [A B] row r, the right-hand side of the W solve, requested now so that it
+      // arrives behind the first chain
+      double W[NS];
+      ldl<pABr, NS>(Lp, W);
+      // ---- Lc = chol(K); columns of inv(Lc) and W = [A B] inv(Lc)' (AM and -P of
+      // :149-175) from one pass over Lc
       ok = chol_rows<NS>(K, ro, sigma) && ok;
       if (!ok) { lds_off = loff; return false; }
       double XC[NS];
       FB_STAMP_LAP(3);
       FB_SB();
-      tri_inv_cols<NS>(K, XC, ro);
+      tri_inv_cols_solve<NS>(K, XC, W, ro);
       FB_STAMP_LAP(4);
       FB_SB();
       // rows of inv(Lc) through an LDS transpose
@@ -1151,24 +1107,20 @@ struct MpcR16 {
       const double tvec = bc_dot<0, NS>(XR, gv);
       st2(R, fT, tvec, th);
       FB_STAMP_LAP(5);
+      FB_SB();
+      // theta(i+1) partial = -W t.  (Outside the branch below on purpose: with W used
+      // only inside it, the optimiser sinks the W half of the fused solve into the
+      // branch and keeps all 120 broadcasts alive for it - 240 registers.)
+      thp = -bc_dot<0, NS>(W, tvec);
       if (i < N_) {
         FB_SB();
-        // ---- W = [A B] inv(Lc)'  (AM and -P of :149-175)
-        double W[NS];
-        sfor<0, NS>([&](auto Cc) { W[decltype(Cc)::value] = 0.0; });
-        sfor<0, NS>([&](auto Kk) {
-          constexpr int k = decltype(Kk)::value;
-          // X[cc][k] = lane cc's XR[k], nonzero for cc >= k
-          bc_pipeline<NS - k>([&](auto I) { return bc<k + decltype(I)::value>(XR[k]); },
-                              [&](auto I, double t) { W[k + decltype(I)::value] = fma(AB[k], t, W[k + decltype(I)::value]); });
-        });
         // next stage's inputs: in flight during the second chain below
         if (kPrefetch) load_fwd(R + kRec, cur);
         FB_SB();
-        FB_STAMP_LAP(6);
-        // theta(i+1) partial = -W t
-        thp = -bc_dot<0, NS>(W, tvec);
-        // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L)
+        // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L).
+        // (Measured and dropped: the two symmetric products with the other lanes'
+        // rows read as 16-byte LDS broadcasts instead of DPP moves - 96 + 42
+        // ds_read_b128 replace 270 v_mov_b64_dpp, and the kernel is 11-16 % slower.)
         double Pn[NX];
         sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = 0.0; });
         sfor<0, NS>([&](auto Kk) {

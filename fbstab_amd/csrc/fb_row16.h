@@ -1,0 +1,300 @@
+// DPP building blocks for solvers that keep one QP per 16-lane row of a wavefront
+// (four QPs per 64-wide wavefront, lane r of a row owning row r of every stage
+// matrix): row broadcasts and reductions, the software-pipelined broadcast-FMA
+// product, Cholesky and triangular inverse of a row-held matrix.
+//
+// The stage recursion of RiccatiLinearSolver (riccati_linear_solver.cc:125-206)
+// is used by the record kernel (fb_mpc_r16.h) in its equivalent block form.  With
+//     K_i  = [Qbar + inv(Pi_i)  Sbar'; Sbar  Rbar]     (NS x NS, NS = nx+nu)
+//     Lc   = chol(K_i) = [M 0; SM SG]      (the reference's M, SM, SG are its blocks)
+//     W    = [A B] inv(Lc)' = [AM  -P]     (the reference's AM and P)
+//     Pi_{i+1} = sigma I + W W'            (= sigma I + P P' + AM AM', :177-183)
+// the vector recursions (:212-327) become, with g_i = [-h_i; ru_i]:
+//     t_i = inv(Lc) g_i = [-tx; tu],  theta_{i+1} = r2_{i+1} - W t_i,
+//     h_{i+1} = inv(Pi_{i+1}) theta_{i+1} - rx_{i+1},
+//     [dx_i; du_i] = inv(Lc)' (t_i - W' dl_{i+1}),   dl_i = -inv(Pi_i)(theta_i + dx_i).
+// One 16-step Cholesky per stage therefore replaces the reference's chol(M),
+// two right-solves and chol(SG); L(i+1) = chol(Pi_{i+1}) is the second chain.
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+#include "fb_common.h"
+
+namespace fbk {
+
+#if !defined(FB_HOSTSIM)
+
+// ---- compile-time loops ------------------------------------------------------
+template <int B, class F, int... I>
+FB_DEV void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, class F>
+FB_DEV void sfor(F&& f) {
+  if constexpr (E > B) sfor_impl<B>(f, std::make_integer_sequence<int, E - B>{});
+}
+
+// ---- DPP helpers on one 16-lane row -------------------------------------------
+template <int CTRL>
+FB_DEV double dpp_mov(double x) {
+  // 64-bit DPP move: for row_newbcast gfx950 has a single v_mov_b64_dpp; other
+  // controls are split into two 32-bit moves by the compiler.  old = 0 with
+  // bound_ctrl, so the destination is not tied to a copy of the source.
+  return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true);
+}
+// value of lane J of this lane's 16-lane row
+template <int J>
+FB_DEV double bc(double x) { return dpp_mov<0x150 + J>(x); }
+template <int J>
+FB_DEV int bci(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xf, 0xf, true); }
+
+struct OpSum16 { static FB_DEV double apply(double a, double b) { return a + b; } };
+struct OpMax16 { static FB_DEV double apply(double a, double b) { return a > b ? a : b; } };
+
+// All-lanes reduction over the row; rotate-by-half-period keeps every lane's
+// result bitwise identical (each step pairs lanes that hold equal values).
+template <class Op>
+FB_DEV double row_reduce(double x) {
+  x = Op::apply(x, dpp_mov<0x128>(x));  // row_ror:8
+  x = Op::apply(x, dpp_mov<0x124>(x));  // row_ror:4
+  x = Op::apply(x, dpp_mov<0x122>(x));  // row_ror:2
+  x = Op::apply(x, dpp_mov<0x121>(x));  // row_ror:1
+  return x;
+}
+
+// Thread context of one 16-lane row (a "virtual workgroup" of 16 threads).
+struct Ctx16 {
+  int tid;  // lane within the row
+  static constexpr int nt = 16;
+  FB_DEV void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+  template <int K>
+  FB_DEV void sum(double (&v)[K]) const {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = row_reduce<OpSum16>(v[k]);
+  }
+  template <int K>
+  FB_DEV void max(double (&v)[K]) const {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = row_reduce<OpMax16>(v[k]);
+  }
+  // Number of the wavefront's four rows for which the (row-uniform) predicate
+  // holds; wavefront-uniform.
+  static FB_DEV int rows_where(bool pred) {
+    return __builtin_popcountll(__ballot(pred) & 0x0001000100010001ull);
+  }
+};
+
+// Pins the emitted instruction order at this point.  The 64-bit DPP move has a
+// result latency of ~17 cycles while a wave can issue one FP64/DPP instruction
+// every ~6.5 (tools/probes/bcast_probe.hip): a broadcast must be issued a few
+// instructions ahead of the FMA that consumes it, or the pair costs 2.4x its
+// issue slots.  The compiler's scheduler places them back to back, so the hot
+// products below spell the order out and fence it.
+#define FB_SB() __builtin_amdgcn_sched_barrier(0)
+
+#ifndef FB_BC_AHEAD
+#define FB_BC_AHEAD 4
+#endif
+constexpr int kBcAhead = FB_BC_AHEAD;  // broadcasts in flight ahead of their consumers
+
+// Runs consume(I, mov(I)) for I in [0, CNT) with the mov of I + kBcAhead issued
+// before the consumer of I.
+template <int CNT, class Mov, class Use>
+FB_DEV void bc_pipeline(Mov&& mov, Use&& use) {
+  if constexpr (CNT > 0) {
+    double t[CNT];
+    constexpr int P = CNT < kBcAhead ? CNT : kBcAhead;
+    sfor<0, P>([&](auto I) {
+      t[decltype(I)::value] = mov(I);
+      FB_SB();
+    });
+    sfor<0, CNT>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (i + P < CNT) {
+        t[i + P] = mov(std::integral_constant<int, i + P>{});
+        FB_SB();
+      }
+      use(I, t[i]);
+      FB_SB();
+    });
+  }
+}
+
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed (~2^-24 relative) and one
+// third-order step r(1 + e/2 + 3e^2/8), e = 1 - d r^2 (error ~e^3): four
+// dependent levels instead of the six of two Newton steps.  Split into stages
+// so that a caller can put independent work between the dependent levels.
+struct RsqrtChain {
+  double d, r, e, p, re, q;
+  template <int S>
+  FB_DEV void stage() {
+    if constexpr (S == 0) r = __builtin_amdgcn_rsq(d);
+    if constexpr (S == 1) e = -d * r;
+    if constexpr (S == 2) e = fma(e, r, 1.0);
+    if constexpr (S == 3) { p = fma(0.375, e, 0.5); re = r * e; }
+    if constexpr (S == 4) q = fma(re, p, r);
+  }
+  static constexpr int kStages = 5;
+};
+FB_DEV double rsqrt_full(double d) {
+  RsqrtChain c;
+  c.d = d;
+  sfor<0, RsqrtChain::kStages>([&](auto S) { c.template stage<decltype(S)::value>(); });
+  return c.q;
+}
+
+// In-place Cholesky of an N x N SPD matrix held one row per lane (a[c] = A[r][c],
+// lower triangle meaningful).  On return a[k] = L[r][k] for k < r and the
+// diagonal slot a[r] holds 1/L[r][r] (only the reciprocal is ever needed).
+// Returns false (row-uniform) on a non-positive pivot.
+//
+// Pivot j + 1's dependent chain (broadcast, rsqrt levels, scaling) is issued one
+// level at a time between the rank-1 update instructions of pivot j, which do
+// not depend on it: the chain's latency is covered instead of exposed.
+template <int N>
+FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
+  bool ok = true;
+  RsqrtChain ch;
+  double lj, nlj;
+  // chain levels of pivot J: 0 = pivot broadcast, 1..5 = rsqrt, 6 = scale column J
+  constexpr int kLevels = RsqrtChain::kStages + 2;
+  auto level = [&](auto J, auto S) {
+    constexpr int j = decltype(J)::value;
+    constexpr int lv = decltype(S)::value;
+    if constexpr (lv == 0) {
+      // the caller's "+ diag_add * I" is applied here, at pivot time: no per-lane
+      // (r == j) selects, which the compiler would otherwise hoist and keep live
+      ch.d = bc<j>(a[j]) + diag_add;
+      ok = ok && (ch.d > 0.0);
+    } else if constexpr (lv <= RsqrtChain::kStages) {
+      ch.template stage<lv - 1>();
+    } else {
+      lj = a[j] * ch.q;  // L[r][j] for r > j
+      nlj = -lj;
+      a[j] = (r == j) ? ch.q : lj;
+    }
+    FB_SB();
+  };
+  sfor<0, kLevels>([&](auto S) { level(std::integral_constant<int, 0>{}, S); });
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int cnt = N - j - 1;
+    const double ljj = lj, nljj = nlj;  // this pivot's column (lj is rewritten by level 6)
+    // column j + 1 first: the next pivot's chain hangs on it
+    bc_pipeline<cnt>(
+        [&](auto I) { return bc<j + 1 + decltype(I)::value>(ljj); },
+        [&](auto I, double t) {
+          constexpr int i = decltype(I)::value;
+          a[j + 1 + i] = fma(nljj, t, a[j + 1 + i]);
+          if constexpr (i < kLevels) {
+            FB_SB();
+            level(std::integral_constant<int, j + 1>{}, I);
+          }
+        });
+    if constexpr (j + 1 < N) {
+      sfor<(cnt < kLevels ? cnt : kLevels), kLevels>(
+          [&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
+    }
+  });
+  return ok;
+}
+
+// Column r of inv(L) for the row-held factor of chol_rows (a[k] = L[r][k],
+// a[r] = 1/L[r][r]).  Column-oriented: once x[k] is known it is folded into every
+// later row's sum, so only one FMA and one multiply per row sit on the chain.
+template <int N>
+FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
+  sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
+  double dg = bc<0>(a[0]);  // 1 / L[k][k], fetched one column ahead
+  sfor<0, N>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    if constexpr (k == 0) x[0] *= dg;
+    const double nx = -x[k];
+    if constexpr (k + 1 < N) dg = bc<k + 1>(a[k + 1]);
+    FB_SB();
+    bc_pipeline<N - k - 1>(
+        [&](auto I) { return bc<k + 1 + decltype(I)::value>(a[k]); },
+        [&](auto I, double t) {
+          constexpr int i = decltype(I)::value;
+          x[k + 1 + i] = fma(t, nx, x[k + 1 + i]);
+          if constexpr (i == 0) {
+            FB_SB();
+            x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
+          }
+        });
+  });
+}
+
+// tri_inv_cols fused with the right-solve W Lc' = B for a second row-held matrix:
+// on entry w[c] = B[r][c], on return w[c] = (B inv(Lc)')[r][c] (forward
+// substitution along the row, W[r][m] = (B[r][m] - sum_{k<m} W[r][k] L[m][k]) / L[m][m]).
+// Both recurrences consume the same broadcasts L[m][k], so the product
+// B inv(Lc)' costs one more FMA per broadcast instead of a broadcast-FMA pair of
+// its own per element.
+template <int N>
+FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)[N], int r) {
+  sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
+  double dg = bc<0>(a[0]);  // 1 / L[k][k], fetched one column ahead
+  sfor<0, N>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    if constexpr (k == 0) {
+      x[0] *= dg;
+      w[0] *= dg;
+    }
+    const double nx = -x[k], nw = -w[k];
+    if constexpr (k + 1 < N) dg = bc<k + 1>(a[k + 1]);
+    FB_SB();
+    bc_pipeline<N - k - 1>(
+        [&](auto I) { return bc<k + 1 + decltype(I)::value>(a[k]); },
+        [&](auto I, double t) {
+          constexpr int i = decltype(I)::value;
+          x[k + 1 + i] = fma(t, nx, x[k + 1 + i]);
+          w[k + 1 + i] = fma(t, nw, w[k + 1 + i]);
+          if constexpr (i == 0) {
+            FB_SB();
+            x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
+            w[k + 1] *= dg;
+          }
+        });
+  });
+}
+
+// acc = sum_c m[c] * (lane c's v), c in [B, E): four partial sums so that the
+// FMAs do not form one dependent chain.
+template <int B, int E, int N>
+FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
+  double p[4] = {init, 0.0, 0.0, 0.0};
+  bc_pipeline<E - B>([&](auto I) { return bc<B + decltype(I)::value>(v); },
+                     [&](auto I, double t) {
+                       constexpr int i = decltype(I)::value;
+                       p[i & 3] = fma(m[B + i], t, p[i & 3]);
+                     });
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// out[c] = lane c's v, c in [0, N)
+template <int N>
+FB_DEV void bc_all(double v, double (&out)[N]) {
+  sfor<0, N>([&](auto Cc) { out[decltype(Cc)::value] = bc<decltype(Cc)::value>(v); });
+  FB_SB();
+}
+// sum_c m[c] * b[c], c in [0, N), four partial sums
+template <int N, int NM, int NB>
+FB_DEV double dot4(const double (&m)[NM], const double (&b)[NB], double init = 0.0) {
+  double p[4] = {init, 0.0, 0.0, 0.0};
+  sfor<0, N>([&](auto Cc) {
+    constexpr int c = decltype(Cc)::value;
+    p[c & 3] = fma(m[c], b[c], p[c & 3]);
+  });
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+#endif  // !FB_HOSTSIM
+
+}  // namespace fbk

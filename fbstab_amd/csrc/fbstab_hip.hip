@@ -18,7 +18,6 @@
 #include "fb_algorithm.h"
 #include "fb_dense.h"
 #include "fb_mpc.h"
-#include "fb_mpc_g16.h"
 #include "fb_mpc_r16.h"
 
 #if defined(FB_STAMP) || defined(FB_CLOCKSTAMP)
@@ -164,135 +163,20 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
 }
 
 
-#ifndef FB_G16_MIN_WAVES
-#define FB_G16_MIN_WAVES 1
-#endif
-// Four QPs per wavefront, one per 16-lane DPP row (fb_mpc_g16.h).  Rows run
-// the solver loop independently (SIMT divergence between rows) and pull QP
-// indices from the shared counter.
-template <int NX, int NU, int NC, bool DBG>
-__global__ __launch_bounds__(64, FB_G16_MIN_WAVES) void fbstab_mpc_g16_kernel(
-    MpcLayout lay, MpcBatchArgs data, VarBatchArgs x, fbstab_solver_out_t* out,
-    fbstab_options_t opts, double* scratch, int* counter, int batch, int lds_per_row, double* dbg) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x, row = lane >> 4;
-  lds_ptr lds = (lds_ptr)smem + row * lds_per_row;
-  Ctx16 ctx;
-  ctx.tid = lane & 15;
-  double* ws = scratch + ((long)blockIdx.x * 4 + row) * lay.ws_doubles;
-  MpcProblemG16<NX, NU, NC> p;
-  // Binds the policy to the next QP of the shared queue; -1 when it is empty.
-  auto next = [&](MpcProblemG16<NX, NU, NC>& pp) -> int {
-    int q = 0;
-    if (ctx.tid == 0) q = atomicAdd(counter, 1);
-    q = bci<0>(q);
-    if (q >= batch) return -1;
-    pp.bind(lay, mpc_data_of(data, q), x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
-            x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
-    pp.pend_t = 0.0;
-    return q;
-  };
-  if constexpr (DBG) {
-    if (next(p) >= 0) newton_probe(p, ctx, opts, dbg);
-  } else {
-    Solver<MpcProblemG16<NX, NU, NC>, Ctx16> solver(p, ctx, opts);
-    for (;;) {
-      const int q = next(p);
-      if (q < 0) break;
-      solver.solve(out + q);
-    }
-  }
-}
-
-// Build knobs (measured on the BASELINE workload):
-//   FB_R16_MIN_WAVES  1: 512 registers per wave, loads prefetched a stage ahead
-//                     2: two waves per SIMD, loads at the point of use
-//   FB_R16_NESTED     the four rows of a wavefront run solve() in step instead of
-//                     the per-row state machine of solve_stream (rows never wait
-//                     for each other; +11 % QP/s with two batches in flight)
-#ifndef FB_R16_MIN_WAVES
-#define FB_R16_MIN_WAVES 1
-#endif
 // Record-based 16-lane kernel (fb_mpc_r16.h): four QPs per wavefront, rows pull
 // QP indices from the shared counter.  scratch: rows * ws_doubles(N).
-// Work distribution of the record kernel: the shared queue of QP indices and the
-// board on which solves in progress change wavefronts (Solver::solve_stream
-// explains why).  One instance per 16-lane row; every function is called by
-// the whole row and returns row-uniform values.  Nothing in here waits for
-// another wavefront.
-//
-// Device memory (zeroed by the host before each launch):
-//   ctl[0] next QP index     ctl[1] board entries reserved
-//   ctl[3] every board entry below this index is closed
-//   board[i]: 0 reserved, not written yet
-//             OPEN    = busy << 61 | (workgroup + 1) << 48 | (slot + 1) << 24 | (q + 1): an
-//                       invitation - the row keeps solving while it stands; busy = busy
-//                       rows of its wavefront when it was posted
-//             CLAIMED = OPEN | 1 << 63: a row of another wavefront will continue this
-//                       solve as soon as its owner has parked it
-//             DEAD    = ~0: withdrawn (the solve ended first)
-// and in the slot header of every QP the hand-over word (P::park_flag): 0 running,
-// 1 parked and ready, 2 finished before the claim was noticed.
-// Invitations are accepted by the rows of wavefronts that have run out of work
-// (Solver::solve_stream), and a solve moves at most once.  Coherence: the two rows
-// may sit in different XCDs, whose L2s are not coherent; the owner writes its L2
-// back (agent-scope release fence) before it sets the hand-over word, the new
-// owner invalidates (acquire fence) after it has read it, and the words
-// themselves are agent-scope atomics.
-constexpr int kQueueCtlInts = 8;
-constexpr int kBoardEntries = 16384;
-constexpr size_t kBoardBytes = kQueueCtlInts * sizeof(int) + kBoardEntries * sizeof(unsigned long long);
-constexpr unsigned long long kBoardClaimed = 1ull << 63, kBoardDead = ~0ull;
-// The board operations are rare: as real calls they stay out of the register
-// allocation of the solver loop (build knob FB_R16_MIG_INLINE for comparison).
-#if defined(FB_R16_MIG_INLINE)
-#define FB_COLD __device__ __forceinline__
-#else
-#define FB_COLD __device__ __attribute__((noinline))
-#endif
+// One queue object per 16-lane row; every function is called by the whole row and
+// returns row-uniform values.  Nothing in here waits for another wavefront.
+constexpr size_t kQueueBytes = 8 * sizeof(int);
 
-// Tail compaction by relaunch (PHASE >= 0; the default for batches).  A batch runs
-// as three launches of this kernel on its stream.  In the first two, a wavefront
-// that is down to FB_COMPACT_MAX_BUSY (2) busy rows after the queue has run dry parks the
-// solves it still hosts (P::park - the rest of a solve lives in its slot already),
-// appends them to a list and leaves; the next launch starts from that list with
-// four parked solves per wavefront (P::resume) and continues each with the very
-// Newton step it was about to take.  Launches are ordered by the stream, so no
-// wavefront ever waits for another and nothing needs fences or atomics beyond the
-// two counters.  Why: once the queue is empty the rows of a wavefront finish at
-// different times while the wavefront holds its SIMD until the last one does -
-// 17 % of all row slots idle at batch 8192; a simulation over the measured iteration
-// counts gives 13 % less wavefront time for three launches.
-//   blk[0] next index into the input (QP queue or parked list)   blk[1] solves parked
-//   blk[8 + 2 i], blk[9 + 2 i]  slot and QP index of parked solve i
-constexpr int kCompactCap = 8192;  // >= 4 x resident wavefronts
-constexpr int kCompactBlkInts = 8 + 2 * kCompactCap;
-#if defined(FB_R16_MIGRATE) || defined(FB_R16_NO_COMPACT)
-constexpr bool kCompactBatches = false;
-#else
-constexpr bool kCompactBatches = true;
-#endif
-// the counter buffer of a handle: the board of the migration experiment or the three blocks
-constexpr size_t kQueueBytes = kBoardBytes > 3 * kCompactBlkInts * sizeof(int) ? kBoardBytes : 3 * kCompactBlkInts * sizeof(int);
-
-template <class P, bool KEEP, int PHASE = -1>
+template <class P, bool KEEP>
 struct R16Queue {
-  static constexpr bool kCompact = PHASE >= 0;
-  static constexpr bool kResume = PHASE >= 1;
-  static constexpr bool kMayPark = PHASE == 0 || PHASE == 1;
-  int* in_blk = nullptr;   // (kResume) the list the previous launch wrote
-  int* out_blk = nullptr;  // (kMayPark) the list this launch writes
-  // Only launch-uniform values live in here (SGPRs).  What a row remembers between
-  // trips sits in four spare words of its LDS region - the sweeps have no
-  // registers to spare for it (a handful of VGPRs held across the Newton step
-  // turned 2 spilled registers into 44):
-  //   [0] cursor: board entries below it are closed for good
-  //   [1] index of this row's standing invitation, -1 none
-  //   [2] slot of the solve this row has claimed and waits for, -1 none   [3] its QP index
+  // Only launch-uniform values live in here (SGPRs): the sweeps have no registers
+  // to spare (a handful of VGPRs held across the Newton step turned 2 spilled
+  // registers into 44).
   const MpcBatchPtrs* data;
   const VarBatchPtrs* x;
-  int* ctl;
-  unsigned long long* board;
+  int* ctl;  // ctl[0]: next QP index
   double* scratch;
   int batch, N;
   bool reuse;
@@ -301,57 +185,19 @@ struct R16Queue {
   static __device__ __forceinline__ int tid() { return threadIdx.x & 15; }
   static __device__ __forceinline__ int row() { return threadIdx.x >> 4; }
   static __device__ __forceinline__ int home() { return blockIdx.x * 4 + row(); }
-  static __device__ __forceinline__ int wg() { return blockIdx.x; }
   static __device__ __forceinline__ lds_ptr lds() {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
     return (lds_ptr)smem_ + row() * P::kLdsPerRow;
   }
-  static __device__ __forceinline__ FB_LDS int* mem() { return (FB_LDS int*)(lds() + P::kLdsDoubles); }
-  // Twenty more spare doubles of the row's LDS region: the solver loop parks its
-  // scalars there while a Newton step and its line search run (Solver::solve_stream).
+  // Twenty spare doubles of the row's LDS region: the solver loop parks its scalars
+  // there while a Newton step and its line search run (Solver::solve_stream).
   static __device__ __forceinline__ lds_ptr save_area() { return lds() + P::kLdsDoubles + 4; }
-  static __device__ __forceinline__ void init() {
-    FB_LDS int* m = mem();
-    m[0] = 0;
-    m[1] = -1;
-    m[2] = -1;
-    m[3] = -1;
-  }
-
-  // Reads and writes of the words other wavefronts change go through read-modify-
-  // write atomics, which are performed at the memory side.  An agent-scope atomic
-  // LOAD is not enough on this part: it may be served from this XCD's L2, which
-  // another XCD's writes do not update (measured: a polled word stayed stale
-  // for the rest of the kernel).
-  static __device__ __forceinline__ int load(int* p) { return atomicAdd(p, 0); }
-  static __device__ __forceinline__ unsigned long long load(unsigned long long* p) { return atomicAdd(p, 0ull); }
-  static __device__ __forceinline__ double load_flag(double* p) {
-    return __longlong_as_double((long long)atomicAdd(reinterpret_cast<unsigned long long*>(p), 0ull));
-  }
-  static __device__ __forceinline__ void store_flag(double* p, double v) {
-    atomicExch(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+  // the row's table of matrix-copy offsets, behind the four row regions
+  __device__ __forceinline__ typename P::lds_iptr lpo() const {
+    extern __shared__ __attribute__((aligned(16))) double smem_[];
+    return (typename P::lds_iptr)((lds_ptr)smem_ + 4 * P::kLdsPerRow) + row() * P::lpo_ints(N);
   }
   __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
-
-  // (kResume) binds the policy to the next parked solve; st receives its scalars.
-  template <int NS>
-  __device__ __forceinline__ int fetch_parked(P& pp, double (&st)[NS]) {
-    int i = 0;
-    if (tid() == 0) i = atomicAdd(&ctl[0], 1);
-    i = bci<0>(i);
-    if (i >= in_blk[1]) return -1;
-    const int slot = in_blk[8 + 2 * i], q = in_blk[9 + 2 * i];
-    pp.resume(tid(), slot_ptr(slot), lds(), data, x, q, N, st);
-    return q;
-  }
-  // (kMayPark) appends the solve pp has parked in its slot to this launch's list.
-  __device__ __forceinline__ void park_out(const P& pp) {
-    if (tid() == 0) {
-      const int i = atomicAdd(&out_blk[1], 1);
-      out_blk[8 + 2 * i] = (int)((reinterpret_cast<const double*>(pp.poff) - scratch) / P::ws_doubles(N));
-      out_blk[9 + 2 * i] = (int)pp.q;
-    }
-  }
 
   // Binds the policy to the next QP of the queue, in this row's own slot.
   __device__ __forceinline__ int fetch(P& pp) {
@@ -365,157 +211,16 @@ struct R16Queue {
       q = bci<0>(q);
     }
     if (q >= batch) return -1;
-    pp.bind(slot_ptr(home()), lds(), data, x, q, N, tid());
+    pp.bind(slot_ptr(home()), lds(), lpo(), data, x, q, N, tid());
     if constexpr (KEEP) pp.reuse = reuse;
-    if constexpr (P::kMigrate) {
-      if (tid() == 0)
-        store_flag(P::park_flag(slot_ptr(home()), N), 0.0);
-    }
     return q;
-  }
-
-  // ---- the row that owns a solve ---------------------------------------------------
-  __device__ __forceinline__ bool invited() const { return mem()[1] >= 0; }
-  // Posts an invitation for the solve pp is bound to (no-op when the board is full).
-  FB_COLD void invite(const P& pp, int busy) {
-    // (the reset of this slot's hand-over word by fetch / take_over must have landed
-    // before anybody can see the invitation)
-    __threadfence();
-    int i = -1;
-    if (tid() == 0 && pp.q + 1 < (1 << 24)) {
-      i = atomicAdd(&ctl[1], 1);
-      if (i < kBoardEntries) {
-        const long slot = (reinterpret_cast<const double*>(pp.poff) - scratch) / P::ws_doubles(N);
-        const unsigned long long v = ((unsigned long long)busy << 61) | ((unsigned long long)(wg() + 1) << 48) | ((unsigned long long)(slot + 1) << 24) |
-                                     (unsigned long long)(pp.q + 1);
-        // (the hand-over word of this slot was reset by an atomic before: it is out already)
-        atomicExch(&board[i], v);
-      } else {
-        i = -1;
-      }
-    }
-    mem()[1] = bci<0>(i);
-  }
-  // Has somebody accepted the standing invitation?
-  __device__ __forceinline__ bool claimed(const P& pp) const {
-    int c = 0;
-    if (tid() == 0) {
-      const unsigned long long e = load(&board[mem()[1]]);
-      c = (e & kBoardClaimed) ? 1 : 0;
-    }
-    return bci<0>(c) != 0;
-  }
-  // The solve is parked in its slot (P::park): let the claiming row have it.
-  FB_COLD void hand_over(const P& pp) {
-    __threadfence();
-    if (tid() == 0) store_flag(P::park_flag(reinterpret_cast<double*>(pp.poff), N), 1.0);
-    mem()[1] = -1;
-  }
-  // The solve has ended on this row: withdraw the invitation, or tell the row
-  // that accepted it in the meantime.
-  FB_COLD void retire(const P& pp) {
-    const int invite_idx = mem()[1];
-    if (invite_idx < 0) return;
-    if (tid() == 0) {
-      unsigned long long v = load(&board[invite_idx]);
-      if (!(v & kBoardClaimed)) v = atomicCAS(&board[invite_idx], v, kBoardDead);
-      if (v & kBoardClaimed) store_flag(P::park_flag(reinterpret_cast<double*>(pp.poff), N), 2.0);
-    }
-    mem()[1] = -1;
-  }
-
-  // ---- an idle row ------------------------------------------------------------------
-  __device__ __forceinline__ bool waiting() const { return mem()[2] >= 0; }
-  // Accepts one open invitation, if there is one (called by the rows of a wavefront
-  // that has run out of work).
-  FB_COLD void claim() {
-    int n = 0, head = 0;
-    int cursor = mem()[0];
-    if (tid() == 0) {
-      n = load(&ctl[1]);
-      if (cursor == 0) head = load(&ctl[3]);  // (a row that has not looked yet starts at the shared hint)
-    }
-    n = bci<0>(n);
-    head = bci<0>(head);
-    if (n > kBoardEntries) n = kBoardEntries;
-    const bool from_hint = cursor == 0;
-    if (cursor < head) cursor = head;
-    else head = cursor;
-    // The row's cursor passes closed entries for good; an entry that is reserved but
-    // not written yet holds it back.  The shared hint ctl[3] lets rows that have
-    // not looked yet skip the closed prefix.
-    bool all_closed = from_hint;  // every entry in [hint, sc) is closed
-    for (int sc = cursor; sc < n;) {
-      const int idx = sc + tid();  // sixteen entries at a time, one per lane
-      unsigned long long v = 0ull;
-      if (idx < n) v = load(&board[idx]);
-      const bool closed = idx >= n || (v & kBoardClaimed) != 0ull;  // CLAIMED or DEAD
-      const bool mine = !closed && v != 0ull;  // OPEN
-      const int first = 16 - (int)row_reduce<OpMax16>(mine ? (double)(16 - tid()) : 0.0);
-      if (first < 16) {
-        int won = 0;
-        if (tid() == first) won = atomicCAS(&board[idx], v, v | kBoardClaimed) == v ? 1 : 0;
-        won = __shfl(won, first, 16);
-        if (won) {
-          const int lo = __shfl((int)(v & 0xffffffffull), first, 16);
-          const int hi = __shfl((int)(v >> 32), first, 16);
-          const unsigned long long e = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
-          mem()[2] = (int)((e >> 24) & 0xffffffull) - 1;
-          mem()[3] = (int)(e & 0xffffffull) - 1;
-          mem()[0] = sc;  // (this window is looked at again next time)
-          return;
-        }
-        continue;  // another row was quicker: look at the window again
-      }
-      const int first_unwritten =
-          16 - (int)row_reduce<OpMax16>((idx < n && v == 0ull) ? (double)(16 - tid()) : 0.0);
-      if (first_unwritten < 16) {
-        cursor = sc + first_unwritten;
-        break;
-      }
-      const int nclosed = (int)row_reduce<OpSum16>(closed ? 1.0 : 0.0);
-      all_closed = all_closed && nclosed == 16 && sc == head;
-      sc += 16;
-      cursor = sc < n ? sc : n;
-      if (all_closed) {
-        head = cursor;
-        if (tid() == 0) atomicMax(&ctl[3], cursor);
-      }
-    }
-    mem()[0] = cursor;
-  }
-  // (never expected) the wavefront waited in vain: ctl[4] tells the host
-  FB_COLD void give_up() {
-    if (tid() == 0 && waiting()) {
-      atomicAdd(&ctl[4], 1);
-    }
-  }
-  // Is the claimed solve ready?  1: pp is bound to its slot and st holds the parked
-  // scalars, *q its index; 2: it ended on its old row; 0: not yet.
-  template <int NS>
-  FB_COLD int take_over(P& pp, double (&st)[NS], int* q) {
-    double* ws = slot_ptr(mem()[2]);
-    const int wait_q = mem()[3];
-    int f = 0;
-    if (tid() == 0)
-      f = (int)load_flag(P::park_flag(ws, N));
-    f = bci<0>(f);
-    if (f == 0) return 0;
-    if (f == 1) {
-      __threadfence();
-      pp.resume(tid(), ws, lds(), data, x, wait_q, N, st);
-      if (tid() == 0) store_flag(P::park_flag(ws, N), 0.0);
-      *q = wait_q;
-    }
-    mem()[2] = -1;
-    return f;
   }
 };
 
 // KEEP (FBSTAB_HIP_KEEP_MATRICES): QP q is solved in slot q, so that the slot's
 // matrix copies survive from call to call; `reuse` says they are valid already.
-template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false, int PHASE = -1>
-__global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
+template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false>
+__global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
     int* counter, int batch, int N, int reuse, double* dbg) {
   typedef MpcR16<NX, NU, NC, EXACT, KEEP> P;
@@ -527,36 +232,19 @@ __global__ __launch_bounds__(64, FB_R16_MIN_WAVES) void fbstab_mpc_r16_kernel(
   Ctx16 ctx;
   ctx.tid = lane & 15;
   P p;
-  R16Queue<P, KEEP, PHASE> qu;
+  R16Queue<P, KEEP> qu;
   qu.data = &data;
   qu.x = &x;
-  if constexpr (PHASE >= 0) {
-    // one block of the counter buffer per launch of the batch
-    qu.ctl = counter + PHASE * kCompactBlkInts;
-    qu.out_blk = qu.ctl;
-    if constexpr (PHASE >= 1) qu.in_blk = counter + reuse * kCompactBlkInts;  // (`reuse`: block the list is in)
-  } else {
-    qu.ctl = counter;
-  }
-  qu.board = reinterpret_cast<unsigned long long*>(counter + kQueueCtlInts);
+  qu.ctl = counter;
   qu.scratch = scratch;
   qu.batch = batch;
   qu.N = N;
   qu.reuse = reuse != 0;
-  qu.init();
   if constexpr (DBG) {
     if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
     Solver<P, Ctx16> solver(p, ctx, opts);
-#ifdef FB_R16_NESTED
-    for (;;) {
-      const int q = qu.fetch(p);
-      if (q < 0) break;
-      solver.solve(out + q);
-    }
-#else
     solver.solve_stream(qu, out);
-#endif
   }
 #if defined(FB_ANY_STAMP)
   // shader clock actually delivered to this wavefront: s_memtime vs the 100 MHz counter
@@ -674,10 +362,13 @@ struct SolverBase {
       return fail(FBSTAB_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
     if (dev < 0 || dev >= ndev) return fail(FBSTAB_HIP_ERR_ARGUMENT, "bad device index");
     HIP_TRY(hipSetDevice(dev));
-    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // A blocking stream: ordered against the device's null stream in both
+    // directions, so a caller that prepared its device arrays on the null stream
+    // (and passes stream = NULL) needs no extra synchronisation.
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamDefault));
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipMalloc(&counter, kQueueBytes));  // queue counter (+ the record kernel's board)
+    HIP_TRY(hipMalloc(&counter, kQueueBytes));  // queue counter
     return FBSTAB_HIP_OK;
   }
 
@@ -782,38 +473,70 @@ int check_common(const void* handle, int batch, const void* data, const fbstab_v
 
 }  // namespace
 
+// One compiled instance of the record kernel family: its entry points (batch,
+// FBSTAB_HIP_KEEP_MATRICES, Newton-step probe) and its footprint.
+struct RecordInstance {
+  const char* name;
+  int nx, nu, nc;        // largest problem it runs (smaller ones zero-padded)
+  int qps_per_wg;
+  int (*lds_bytes)(int N);
+  long long (*ws_doubles)(int N);
+  const void *solve, *solve_keep, *probe;  // kernels of the padded instance
+  const void *solve_exact, *solve_keep_exact, *probe_exact;  // problem == instance shape
+};
+
 struct fbstab_mpc_solver : SolverBase {
   fbk::MpcLayout lay;
-  bool g16 = false;       // 16-lane register kernel (four QPs per wavefront)
-  bool r16 = false;       // record-based 16-lane kernel (fb_mpc_r16.h), the default for its shapes
+  const RecordInstance* rec = nullptr;  // record kernel (fb_mpc_r16.h) serving this shape, or the flat-vector kernel
+  bool exact = false;     // the problem has exactly the instance's shape
   int kept_batch = -1;    // batch size of the last FBSTAB_HIP_KEEP_MATRICES call whose copies are still in the slots
-  int compact_phases = 1; // launches per batch of the record kernel (tail compaction, R16Queue)
-  int lds_per_row = 0;
   int qps_per_wg = 1;
 };
 
 namespace {
-// The specialised shapes compiled into the library: the flat-layout register
-// kernel needs the exact shape, the record kernel runs anything that fits its
-// (12, 4, 20) instance zero-padded.
-bool g16_shape(int nx, int nu, int nc) { return nx == 12 && nu == 4 && nc == 20; }
-bool r16_fits(int nx, int nu, int nc) { return nx <= 12 && nu <= 4 && nc <= 20; }
-
-template <class... A>
-void launch_mpc(fbstab_mpc_solver* h, int grid, hipStream_t s, A... args) {
-  if (h->r16) {
-    // unreachable: the record kernel takes a different argument list (launch_r16)
-  } else if (h->g16) {
-    hipLaunchKernelGGL((fbstab_mpc_g16_kernel<12, 4, 20, false>), dim3(grid), dim3(64), h->lds_bytes, s,
-                       args..., h->lds_per_row, (double*)nullptr);
-  } else {
-    hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, false>), dim3(grid), dim3(h->threads), h->lds_bytes, s,
-                       args..., (double*)nullptr);
-  }
+template <int NX, int NU, int NC>
+long long r16_ws_doubles(int N) { return fbk::MpcR16<NX, NU, NC>::ws_doubles(N); }
+template <int NX, int NU, int NC>
+int r16_lds_bytes(int N) {
+  typedef fbk::MpcR16<NX, NU, NC> R;
+  return 4 * R::kLdsPerRow * (int)sizeof(double) + 4 * R::lpo_ints(N) * (int)sizeof(int);
 }
-template <bool DBG>
-void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArgs& a, const VarBatchArgs& v,
-                fbstab_solver_out_t* out, int batch, double* dbg, bool keep = false, bool reuse = false) {
+template <int NX, int NU, int NC>
+RecordInstance r16_instance(const char* name) {
+  RecordInstance r;
+  r.name = name;
+  r.nx = NX; r.nu = NU; r.nc = NC;
+  r.qps_per_wg = 4;
+  r.lds_bytes = r16_lds_bytes<NX, NU, NC>;
+  r.ws_doubles = r16_ws_doubles<NX, NU, NC>;
+  r.solve = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, false, false>);
+  r.solve_keep = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, false, true>);
+  r.probe = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, true, false, false>);
+  r.solve_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, true, false>);
+  r.solve_keep_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, true, true>);
+  r.probe_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, true, true, false>);
+  return r;
+}
+// The record-kernel instances compiled into the library, smallest first: a shape
+// runs on the first one it fits (zero-padded unless it is that instance's own).
+const RecordInstance* record_instances(int* count) {
+  static const RecordInstance table[] = {
+      r16_instance<12, 4, 20>("fbstab_mpc_r16_kernel<12,4,20>"),
+  };
+  *count = (int)(sizeof(table) / sizeof(table[0]));
+  return table;
+}
+const RecordInstance* record_instance_for(int nx, int nu, int nc) {
+  int n = 0;
+  const RecordInstance* t = record_instances(&n);
+  for (int i = 0; i < n; i++)
+    if (nx <= t[i].nx && nu <= t[i].nu && nc <= t[i].nc) return &t[i];
+  return nullptr;
+}
+
+// Launches one kernel of a record instance (same argument list for all of them).
+int launch_record(fbstab_mpc_solver* h, const void* kern, int grid, hipStream_t s, const MpcBatchArgs& a,
+                  const VarBatchArgs& v, fbstab_solver_out_t* out, int batch, double* dbg, bool reuse) {
   MpcBatchPtrs d;
   VarBatchPtrs x;
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { d.base[i] = a.base[i]; d.stride[i] = a.stride[i]; }
@@ -821,54 +544,10 @@ void launch_r16(fbstab_mpc_solver* h, int grid, hipStream_t s, const MpcBatchArg
   d.nx = h->lay.nx;
   d.nu = h->lay.nu;
   d.nc = h->lay.nc;
-  const bool exact = g16_shape(h->lay.nx, h->lay.nu, h->lay.nc);
-  const int ru = reuse ? 1 : 0;
-  if constexpr (!DBG) {
-    if (keep) {
-      if (exact)
-        hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, true, true>), dim3(grid), dim3(64), h->lds_bytes,
-                           s, d, x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, ru, dbg);
-      else
-        hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, false, true>), dim3(grid), dim3(64), h->lds_bytes,
-                           s, d, x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, ru, dbg);
-      return;
-    }
-  }
-  if constexpr (!DBG && kCompactBatches) {
-    // tail compaction (R16Queue): up to three launches, each at most two parked solves
-    // per wavefront of the one before, four per wavefront of its own
-    if (h->compact_phases >= 2) {
-      const int g1 = (grid + 1) / 2, g2 = (g1 + 1) / 2;
-#define FB_LAUNCH_PHASE(EX, PH, G, IN)                                                                             \
-  hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, false, EX, false, PH>), dim3(G), dim3(64), h->lds_bytes, s, d, \
-                     x, out, h->opts, h->scratch, h->counter, batch, h->lay.N, IN, dbg)
-      if (exact) {
-        FB_LAUNCH_PHASE(true, 0, grid, 0);
-        if (h->compact_phases >= 3) {
-          FB_LAUNCH_PHASE(true, 1, g1, 0);
-          FB_LAUNCH_PHASE(true, 2, g2, 1);
-        } else {
-          FB_LAUNCH_PHASE(true, 2, g1, 0);
-        }
-      } else {
-        FB_LAUNCH_PHASE(false, 0, grid, 0);
-        if (h->compact_phases >= 3) {
-          FB_LAUNCH_PHASE(false, 1, g1, 0);
-          FB_LAUNCH_PHASE(false, 2, g2, 1);
-        } else {
-          FB_LAUNCH_PHASE(false, 2, g1, 0);
-        }
-      }
-#undef FB_LAUNCH_PHASE
-      return;
-    }
-  }
-  if (exact)
-    hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG, true>), dim3(grid), dim3(64), h->lds_bytes, s, d, x, out,
-                       h->opts, h->scratch, h->counter, batch, h->lay.N, 0, dbg);
-  else
-    hipLaunchKernelGGL((fbstab_mpc_r16_kernel<12, 4, 20, DBG, false>), dim3(grid), dim3(64), h->lds_bytes, s, d, x,
-                       out, h->opts, h->scratch, h->counter, batch, h->lay.N, 0, dbg);
+  int N = h->lay.N, ru = reuse ? 1 : 0;
+  void* args[] = {&d, &x, &out, &h->opts, &h->scratch, &h->counter, &batch, &N, &ru, &dbg};
+  HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(64), args, (size_t)h->lds_bytes, s));
+  return FBSTAB_HIP_OK;
 }
 }  // namespace
 struct fbstab_dense_solver : SolverBase {
@@ -899,26 +578,19 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   s->threads = kMpcThreads;
   s->lay.init(N, nx, nu, nc, s->threads);
   s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
+  // FBSTAB_HIP_GENERIC=1 forces the flat-vector kernel (comparisons, tests)
   const char* force_generic = getenv("FBSTAB_HIP_GENERIC");
-  s->g16 = g16_shape(nx, nu, nc) && !(force_generic && atoi(force_generic) > 0);
-  // FBSTAB_HIP_MPC_KERNEL=g16 selects the previous register kernel (comparisons)
-  const char* which = getenv("FBSTAB_HIP_MPC_KERNEL");
-  s->r16 = r16_fits(nx, nu, nc) && !(force_generic && atoi(force_generic) > 0) &&
-           !(which && strcmp(which, "g16") == 0);
-  typedef fbk::MpcR16<12, 4, 20> R16;
-  if (s->r16) {
-    s->g16 = false;
-    s->lds_per_row = R16::kLdsPerRow;
-    s->qps_per_wg = 4;
-    s->lds_bytes = 4 * R16::kLdsPerRow * (int)sizeof(double);
+  if (!(force_generic && atoi(force_generic) > 0)) s->rec = record_instance_for(nx, nu, nc);
+  if (s->rec) {
+    s->exact = nx == s->rec->nx && nu == s->rec->nu && nc == s->rec->nc;
+    s->qps_per_wg = s->rec->qps_per_wg;
+    s->lds_bytes = s->rec->lds_bytes(N);
   }
-  if (s->g16) {
-    int d = s->lay.w_sb;  // tile + stage slices of the generic passes
-    if (d < fbk::MpcProblemG16<12, 4, 20>::kLdsDoubles) d = fbk::MpcProblemG16<12, 4, 20>::kLdsDoubles;
-    // region stride == 16 doubles mod 32 (bank placement, see fb_mpc_g16.h)
-    s->lds_per_row = ((d + 31) & ~31) + 16;
-    s->qps_per_wg = 4;
-    s->lds_bytes = 4 * s->lds_per_row * (int)sizeof(double);
+  {
+    // developer knob: extra (unused) LDS per workgroup, to lower the number of
+    // resident wavefronts in occupancy experiments
+    const char* pad = getenv("FBSTAB_HIP_LDS_PAD_BYTES");
+    if (pad && atoi(pad) > 0) s->lds_bytes += atoi(pad) & ~15;
   }
   if (nx > s->threads || s->lds_bytes > kLdsLimitBytes) {
     delete s;
@@ -926,37 +598,23 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  const bool exact = g16_shape(nx, nu, nc);
-  const void* r16_first =
-      kCompactBatches ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, false, 0>)
-                               : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, false, 0>))
-                      : (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true>)
-                               : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false>));
-  const void* kern = s->r16   ? r16_first
-                     : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, false>)
-                              : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>);
-  const void* kern_dbg = s->r16   ? (exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true, true>)
-                                           : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, true, false>))
-                         : s->g16 ? reinterpret_cast<const void*>(fbstab_mpc_g16_kernel<12, 4, 20, true>)
-                                  : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>);
-  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-  if (e == hipSuccess && s->r16) {
-    const void* kk = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, true>)
-                           : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, true>);
-    e = hipFuncSetAttribute(kk, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-    if (kCompactBatches) {
-      const void* k1 = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, false, 1>)
-                             : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, false, 1>);
-      const void* k2 = exact ? reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, true, false, 2>)
-                             : reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<12, 4, 20, false, false, false, 2>);
-      if (e == hipSuccess) e = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-      if (e == hipSuccess) e = hipFuncSetAttribute(k2, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-    }
+  // every kernel this handle can launch gets the LDS attribute; the occupancy
+  // query runs on the one batches are launched with
+  std::vector<const void*> kerns;
+  if (s->rec) {
+    const RecordInstance& r = *s->rec;
+    if (s->exact) kerns = {r.solve_exact, r.solve_keep_exact, r.probe_exact};
+    else kerns = {r.solve, r.solve_keep, r.probe};
+  } else {
+    kerns = {reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>),
+             reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>)};
   }
-  if (e == hipSuccess) e = hipFuncSetAttribute(kern_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  hipError_t e = hipSuccess;
+  for (const void* k : kerns)
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0, cus = 0;
   if (e == hipSuccess)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, s->threads, s->lds_bytes);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kerns[0], s->threads, s->lds_bytes);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
   if (e != hipSuccess) {
@@ -968,17 +626,12 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   if (per_cu > 8) per_cu = 8;
   const char* env = getenv("FBSTAB_HIP_WGS_PER_CU");
   if (env && atoi(env) > 0) per_cu = atoi(env);
-  {
-    const char* cp = getenv("FBSTAB_HIP_COMPACT_PHASES");
-    if (cp && atoi(cp) >= 1 && atoi(cp) <= 3) s->compact_phases = atoi(cp);
-  }
   s->workgroups = cus * per_cu;
-  if (s->r16 && 2 * s->workgroups > kCompactCap) s->workgroups = kCompactCap / 2;  // (list capacity, R16Queue)
   {
     const int need = (max_batch + s->qps_per_wg - 1) / s->qps_per_wg;
     if (s->workgroups > need) s->workgroups = need;
   }
-  const long long ws_doubles = s->r16 ? (long long)R16::ws_doubles(N) : (long long)s->lay.ws_doubles;
+  const long long ws_doubles = s->rec ? s->rec->ws_doubles(N) : (long long)s->lay.ws_doubles;
   s->scratch_bytes = ws_doubles * sizeof(double) * s->workgroups * s->qps_per_wg;
   e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
   if (e != hipSuccess) {
@@ -1041,6 +694,8 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     rc = h->ensure_staging();
     if (rc != FBSTAB_HIP_OK) return rc;
     for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) {
+      if (data->stride[i] != 0 && data->stride[i] < h->arr_len[i] && batch > 1)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "problem data stride smaller than the array length");
       rc = h->upload(data->base[i], data->stride[i], h->arr_len[i], batch, h->d_arr[i], &a.stride[i], s);
       if (rc != FBSTAB_HIP_OK) return rc;
       a.base[i] = h->d_arr[i];
@@ -1059,7 +714,7 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     }
     d_out = h->d_out;
   }
-  HIP_TRY(hipMemsetAsync(h->counter, 0, h->r16 ? kQueueBytes : sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(h->counter, 0, kQueueBytes, s));
   int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
@@ -1074,14 +729,19 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     HIP_TRY(hipMalloc(&tmp_ws.p, sizeof(double) * (size_t)h->lay.ws_doubles));
     hipLaunchKernelGGL(kern, dim3(1), dim3(kMpcThreads), lds, s, h->lay, a, v, d_out, h->opts,
                        static_cast<double*>(tmp_ws.p), h->counter, 1, d_trace);
-  } else if (h->r16) {
+  } else if (h->rec) {
     // FBSTAB_HIP_KEEP_MATRICES: one QP per slot, slot = QP index
     const bool keep = (flags & FBSTAB_HIP_KEEP_MATRICES) && dev_ptrs && batch <= h->workgroups * h->qps_per_wg;
     const bool reuse = keep && h->kept_batch == batch;
-    launch_r16<false>(h, keep ? (batch + 3) / 4 : grid, s, a, v, d_out, batch, nullptr, keep, reuse);
+    const RecordInstance& r = *h->rec;
+    const void* kern = keep ? (h->exact ? r.solve_keep_exact : r.solve_keep) : (h->exact ? r.solve_exact : r.solve);
+    rc = launch_record(h, kern, keep ? (batch + h->qps_per_wg - 1) / h->qps_per_wg : grid, s, a, v, d_out, batch,
+                       nullptr, reuse);
+    if (rc != FBSTAB_HIP_OK) return rc;
     h->kept_batch = keep ? batch : -1;
   } else {
-    launch_mpc(h, grid, s, h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch);
+    hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, false>), dim3(grid), dim3(h->threads), h->lds_bytes, s,
+                       h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch, (double*)nullptr);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
@@ -1149,15 +809,15 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
   }
   const fbk::MpcLayout& L = h->lay;
   const size_t n_io = (size_t)(3 * L.nz + 3 * L.nl + 2 * L.nv + 1);
-  double* d_io = nullptr;
-  HIP_TRY(hipMalloc(&d_io, n_io * sizeof(double)));
+  DevBuf d_io_buf;
+  HIP_TRY(hipMalloc(&d_io_buf.p, n_io * sizeof(double)));
+  double* d_io = static_cast<double*>(d_io_buf.p);
   HIP_TRY(hipMemcpyAsync(d_io, io, sizeof(double) * (L.nz + L.nl + L.nv), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(h->counter, 0, h->r16 ? kQueueBytes : sizeof(int), s));
-  if (h->r16) {
-    launch_r16<true>(h, 1, s, a, v, h->d_out, 1, d_io);
-  } else if (h->g16) {
-    hipLaunchKernelGGL((fbstab_mpc_g16_kernel<12, 4, 20, true>), dim3(1), dim3(64), h->lds_bytes, s, h->lay, a, v,
-                       h->d_out, h->opts, h->scratch, h->counter, 1, h->lds_per_row, d_io);
+  HIP_TRY(hipMemsetAsync(h->counter, 0, kQueueBytes, s));
+  h->kept_batch = -1;  // the probe runs in slot 0 and overwrites its matrix copies
+  if (h->rec) {
+    rc = launch_record(h, h->exact ? h->rec->probe_exact : h->rec->probe, 1, s, a, v, h->d_out, 1, d_io, false);
+    if (rc != FBSTAB_HIP_OK) return rc;
   } else {
     hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, true>), dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a,
                        v, h->d_out, h->opts, h->scratch, h->counter, 1, d_io);
@@ -1165,7 +825,6 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(io, d_io, sizeof(double) * n_io, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  HIP_TRY(hipFree(d_io));
   return FBSTAB_HIP_OK;
 }
 
@@ -1196,6 +855,12 @@ int fbstab_hip_mpc_query(fbstab_mpc_handle_t h, long long* scratch_bytes, int* l
   if (workgroups) *workgroups = h->workgroups;
   if (threads) *threads = h->threads;
   return FBSTAB_HIP_OK;
+}
+
+// Name of the kernel batches of this handle run on (diagnostics, tests).
+const char* fbstab_hip_mpc_kernel_name(fbstab_mpc_handle_t h) {
+  if (!h) return "";
+  return h->rec ? h->rec->name : "fbstab_mpc_kernel<64>";
 }
 
 // ---------------------------------------------------------------------------
@@ -1296,6 +961,8 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
     rc = h->ensure_staging();
     if (rc != FBSTAB_HIP_OK) return rc;
     for (int i = 0; i < FBSTAB_DENSE_NARR; i++) {
+      if (data->stride[i] != 0 && data->stride[i] < h->arr_len[i] && batch > 1)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "problem data stride smaller than the array length");
       rc = h->upload(data->base[i], data->stride[i], h->arr_len[i], batch, h->d_arr[i], &a.stride[i], s);
       if (rc != FBSTAB_HIP_OK) return rc;
       a.base[i] = h->d_arr[i];

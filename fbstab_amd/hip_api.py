@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         getattr(lib, f"fbstab_hip_{kind}_solve_traced").argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fbstab_hip_mpc_kernel_name.restype = C.c_char_p
+    lib.fbstab_hip_mpc_kernel_name.argtypes = [C.c_void_p]
     lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
     lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
     _lib = lib
@@ -125,7 +127,8 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_mpc_create", "fbstab_hip_mpc_destroy", "fbstab_hip_mpc_set_options",
     "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch",
     "fbstab_hip_mpc_solve_traced",
-    "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
+    "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_kernel_name",
+    "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
     "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_traced",
     "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
@@ -230,6 +233,10 @@ class _SolverBase:
             if out is None:
                 out = torch.zeros((B, 40), dtype=torch.uint8, device=z.device)
             out_ptr = out.data_ptr()
+            if not stream:
+                # the arrays were produced on torch's current stream: run there (0 is
+                # the null stream, which the handle's own blocking stream is ordered with)
+                stream = torch.cuda.current_stream(z.device).cuda_stream
             flags = DEVICE_POINTERS | (ASYNC if async_ else 0) | (KEEP_MATRICES if keep_matrices else 0)
         else:
             if out is None:
@@ -296,6 +303,9 @@ class FBstabMpcBatch(_SolverBase):
         self.seq_len = [(N + 1) * nx * nx, (N + 1) * nu * nu, (N + 1) * nu * nx,
                         (N + 1) * nx, (N + 1) * nu, N * nx * nx, N * nx * nu, N * nx,
                         (N + 1) * nc * nx, (N + 1) * nc * nu, (N + 1) * nc, nx]
+
+    def kernel_name(self) -> str:
+        return self._lib.fbstab_hip_mpc_kernel_name(self._h).decode()
 
     def Solve(self, data: Dict[str, object], z, l, v, y, out=None, stream: int = 0,
               async_: bool = False, keep_matrices: bool = False):

@@ -119,7 +119,10 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
 int fbstab_hip_mpc_destroy(fbstab_mpc_handle_t handle);
 int fbstab_hip_mpc_set_options(fbstab_mpc_handle_t handle, const fbstab_options_t* options);
 int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t handle, fbstab_options_t* options);
-/* stream: a hipStream_t, or NULL for the handle's own stream. */
+/* stream: a hipStream_t, or NULL for the handle's own stream, which is a blocking
+ * stream (ordered against the device's null stream both ways).  With
+ * FBSTAB_HIP_DEVICE_POINTERS the caller's arrays must be ready on the stream the
+ * call runs on: work queued on another non-blocking stream needs an event. */
 int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t handle, int batch,
                                const fbstab_mpc_batch_t* data, const fbstab_var_batch_t* x,
                                fbstab_solver_out_t* out, int flags, void* stream);
@@ -144,6 +147,11 @@ double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t handle);
  * number of resident workgroups it launches (for DESIGN.md / diagnostics). */
 int fbstab_hip_mpc_query(fbstab_mpc_handle_t handle, long long* scratch_bytes,
                          int* lds_bytes, int* workgroups, int* threads);
+
+/* Name of the kernel instance this handle's batches run on, e.g.
+ * "fbstab_mpc_r16_kernel<12,4,20>" (record kernel, four QPs per wavefront) or
+ * "fbstab_mpc_kernel<64>" (any shape, one QP per wavefront). */
+const char* fbstab_hip_mpc_kernel_name(fbstab_mpc_handle_t handle);
 
 /* Diagnostics used by the parity tests: runs ONE Newton step of the device path
  * (LinearSolver::Initialize + Solve of the reference, abstract_components.h:291-338)

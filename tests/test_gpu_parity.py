@@ -75,10 +75,10 @@ def _assert_parity(gpu, cpu, abs_tol, exact_frac=0.99):
     np.testing.assert_allclose(og["initial_residual"], oc["initial_residual"], rtol=1e-10)
     # residuals agree where they are well above the rounding floor of a
     # cancellation-dominated quantity (terms are O(1..100), eps*100 ~ 1e-14,
-    # amplified by the Newton step's conditioning)
+    # amplified by the Newton step's conditioning, cond(K) up to 1e11: a few 1e-8)
     big = ok & (oc["residual"] > 1e-7)
     if big.any():
-        np.testing.assert_allclose(og["residual"][big], oc["residual"][big], rtol=1e-2)
+        np.testing.assert_allclose(og["residual"][big], oc["residual"][big], rtol=2e-2, atol=3e-8)
 
 
 # -- reference end-to-end tests through the C-ABI ------------------------------
@@ -132,16 +132,12 @@ def test_mpc_reference_tests(hip, oracle, kats, idx):
 
 # -- one Newton step (LinearSolver::Initialize + Solve) -------------------------
 def _select_kernel(monkeypatch, kernel):
-    """r16: record-based 16-lane kernel (default for its shapes); g16: the earlier
-    16-lane register kernel; generic: one QP per wavefront through LDS."""
+    """r16: record-based 16-lane kernel (default for its shapes); generic: one QP
+    per wavefront through LDS (any shape)."""
     monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kernel == "generic" else "0")
-    if kernel == "g16":
-        monkeypatch.setenv("FBSTAB_HIP_MPC_KERNEL", "g16")
-    else:
-        monkeypatch.delenv("FBSTAB_HIP_MPC_KERNEL", raising=False)
 
 
-@pytest.mark.parametrize("kernel", ["r16", "g16", "generic"])
+@pytest.mark.parametrize("kernel", ["r16", "generic"])
 def test_newton_step_matches_oracle(hip, oracle, monkeypatch, kernel):
     """Newton step of the device path vs the oracle's RiccatiLinearSolver at a
     random point of the BASELINE shape (cond(K) ~ 1e11 at sigma=1e-8), for the
@@ -174,9 +170,9 @@ def test_newton_step_matches_oracle(hip, oracle, monkeypatch, kernel):
     s.close()
 
 
-@pytest.mark.parametrize("kernel", ["r16", "g16", "generic"])
+@pytest.mark.parametrize("kernel", ["r16", "generic"])
 def test_mpc_paths_agree(hip, oracle, monkeypatch, kernel):
-    """All three kernels meet the parity definition."""
+    """Both kernels meet the parity definition."""
     _select_kernel(monkeypatch, kernel)
     p = fx.synthetic_mpc_batch(192, first_id=500)
     o = default_options()
@@ -248,7 +244,7 @@ def test_smaller_shapes_run_padded_on_the_record_kernel(hip, oracle, monkeypatch
     p.arrays = {k: np.ascontiguousarray(np.broadcast_to(a, (B, a.shape[1]))).copy() for k, a in one.arrays.items()}
     p.arrays["x0"] = p.arrays["x0"] * (1.0 + 0.3 * rng.standard_normal((B, nx)))
     s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
-    assert s.query()["lds_bytes"] == 38400, "the record kernel was not selected"
+    assert s.kernel_name() == "fbstab_mpc_r16_kernel<12,4,20>", "the record kernel was not selected"
     s.close()
     o = default_options()
     gpu = _solve_mpc_host(hip, p, o)
@@ -400,23 +396,6 @@ def test_mpc_device_pointers_match_host_pointers(hip):
     assert np.array_equal(out["newton_iters"], host[4]["newton_iters"])
     assert np.array_equal(z.cpu().numpy(), host[0])
     assert np.array_equal(v.cpu().numpy(), host[2])
-
-
-@pytest.mark.parametrize("phases", [2, 3])
-def test_tail_compaction_changes_nothing_but_the_schedule(hip, monkeypatch, phases):
-    """FBSTAB_HIP_COMPACT_PHASES: the batch runs as 2 or 3 launches, wavefronts that
-    thin out park their solves for the next one (R16Queue in fbstab_hip.hip).  A
-    parked solve continues with the very Newton step it was about to take, so
-    every output is bitwise what the single launch gives."""
-    p = fx.synthetic_mpc_batch(700, first_id=2500)
-    o = default_options()
-    ref = _solve_mpc_host(hip, p, o)
-    monkeypatch.setenv("FBSTAB_HIP_COMPACT_PHASES", str(phases))
-    got = _solve_mpc_host(hip, p, o)
-    for a, b in zip(ref[:4], got[:4]):
-        assert np.array_equal(a, b)
-    for f in ("eflag", "newton_iters", "prox_iters", "residual"):
-        assert np.array_equal(ref[4][f], got[4][f]), f
 
 
 def test_two_batches_in_flight_equal_one_at_a_time(hip):
