@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: QPs/sec of the batched FBstab MPC solve
-(BASELINE.json: N=30, nx=12, nu=4, nc=20; config 3 = batch 8192 per GPU).
+(BASELINE.json: N=30, nx=12, nu=4, nc=20; configs[2] = batch 8192 per GPU).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -8,12 +8,22 @@
 One "step" = one fbstab_hip_mpc_solve_batch call over the rank's whole shard
 (cold start, zero initial guess), problem data already resident in HBM.  For
 N > 1 the batch is sharded by global instance id (weak scaling, 8192 QPs per
-GPU) and each step ends with one RCCL gather of the solutions to rank 0.
-Consecutive steps are issued on --pipeline (default 8, one per hardware queue) alternating HIP streams,
-each with its own solver handle and output buffers, the way a stream of
-batches is served: iteration counts differ 10x between QPs, so the tail of
-one batch (a few slow QPs) overlaps the bulk of the next.  --pipeline 1
-serialises the steps.  Rank 0 prints ONE JSON line.
+GPU) and each step ends with ONE RCCL gather of the solution records to rank 0
+(fbstab_amd/sharding.py).  Consecutive steps are issued on --pipeline (default 8,
+one per hardware queue) HIP streams, each with its own solver handle and output
+buffers, the way a stream of batches is served: iteration counts differ 10x
+between QPs, so the tail of one batch (a few slow QPs) overlaps the bulk of the
+next.  Rank 0 prints ONE JSON line.
+
+Besides the contract's keys the line carries, measured in the same run at N = 1:
+  serial          the same steps one at a time (--pipeline 1): latency of a batch
+  ltv_dense_rows  the same shape with per-stage-distinct matrices and dense
+                  constraint rows (no matrix copy shared between stages, no
+                  bound-constraint path in the kernel)
+  dense           BASELINE configs[1]: batched FBstabDense, batch 4096, 50/10/100
+  receding        BASELINE configs[4]: 4096 warm-started closed-loop trajectories
+                  x 200 steps, plant step and retirement on the device
+  cpu_baseline    the oracle on the host cores (bounded sample)
 """
 import argparse
 import json
@@ -32,6 +42,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ALG_BYTES_PER_QP = 217736      # data 188,928 + guess 11,904 + solution 16,864 + SolverOut 40
 FLOP_PER_NEWTON = 0.94e6       # SURVEY.md 8(d), survey-derived flop model
+DENSE_ALG_BYTES_PER_QP = 8160 * 8 + 160 * 8 + 260 * 8 + 40   # data + guess (z,l,v) + solution + SolverOut
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # AMD public MI355X FP64 vector/matrix spec
 
@@ -39,7 +50,7 @@ FP64_PEAK_TFLOPS = 78.6        # AMD public MI355X FP64 vector/matrix spec
 def cpu_baseline(sample_qps: int):
     """The oracle (CPU restatement, -O3) on a bounded sample of the same
     workload: OpenMP-over-batch on all host cores, plus one thread."""
-    from fbstab_amd import fixtures as fx
+    from tools import fixtures as fx
     from oracle.oracle_py import Oracle
     orc = Oracle(False)
     cores = orc.num_threads()
@@ -63,27 +74,28 @@ def cpu_baseline(sample_qps: int):
     }
 
 
-def pmc_traffic(batch: int):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary
-    (FETCH_SIZE and WRITE_SIZE, separate passes; see the note in the file).
-    bench.py cannot run the profiler on itself, so this is the figure of the
-    last profiled build for the same batch, or None."""
+def stored_traffic(batch: int):
+    """HBM bytes per launch of the record kernel from the newest committed
+    rocprofv3 --pmc summary for this batch size (FETCH_SIZE and WRITE_SIZE in
+    separate passes; bench.py cannot run the profiler on itself, so the figure is
+    REPLAYED from profiles/, not measured in this run).  Returns (bytes, source)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if t.get("batch") == batch:
-                return t["hbm_bytes_per_launch_raw"]
+                return t["hbm_bytes_per_launch_raw"], "profiles/" + os.path.basename(path) + " (replayed; build " + \
+                    str(t.get("build", "unrecorded")) + ")"
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="QPs per GPU")
     ap.add_argument("--pipeline", type=int, default=8,
@@ -93,11 +105,13 @@ def main():
                          "(default: rank * batch, the shard bench runs under torch.distributed.run)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="QPs for the CPU baseline (0 disables; default sized for ~15 s)")
+    ap.add_argument("--extras", type=int, default=-1,
+                    help="secondary blocks (serial, ltv_dense_rows, dense, receding): 1/0; default on at N = 1")
     args = ap.parse_args()
 
     import torch
-    from fbstab_amd import fixtures as fx
-    from fbstab_amd import hip_api
+    from tools import fixtures as fx
+    from fbstab_amd import hip_api, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,114 +128,166 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    gpu_t0 = time.time()
 
     B = args.batch
-    P = max(1, args.pipeline)
-    from fbstab_amd import sharding
     first_id, _ = sharding.shard_range(rank, world, B)
     if args.first_id is not None:
         first_id = args.first_id
-    p = fx.synthetic_mpc_batch(B, first_id=first_id)  # shard by global instance id
-    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
-    nvar = p.nz + p.nl + 2 * p.nv
+
+    def upload(p):
+        return {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
 
     class Lane:
         """One pipeline lane: solver handle (own device scratch), stream, outputs."""
 
-        def __init__(self):
-            self.solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B, device=local_rank)
+        def __init__(self, p, gather):
+            self.solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=p.batch, device=local_rank)
             self.stream = torch.cuda.Stream(device=dev)
-            # z, l, v, y side by side in one record per QP so the gather is one buffer
-            self.x = torch.zeros((B, nvar), dtype=torch.float64, device=dev)
-            self.z, self.l = self.x[:, :p.nz], self.x[:, p.nz:p.nz + p.nl]
-            self.v = self.x[:, p.nz + p.nl:p.nz + p.nl + p.nv]
-            self.y = self.x[:, p.nz + p.nl + p.nv:]
-            self.out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
-            self.gx = self.go = None
-            if dist is not None and rank == 0:
-                self.gx = [torch.empty_like(self.x) for _ in range(world)]
-                self.go = [torch.empty_like(self.out) for _ in range(world)]
+            nvar = p.nz + p.nl + 2 * p.nv
+            # z, l, v, y and the SolverOut record (5 doubles) of a QP side by side: the
+            # gather moves ONE buffer
+            self.rec = torch.zeros((p.batch, nvar + sharding.OUT_DOUBLES), dtype=torch.float64, device=dev)
+            self.x = self.rec[:, :nvar]
+            self.z, self.l = self.rec[:, :p.nz], self.rec[:, p.nz:p.nz + p.nl]
+            self.v = self.rec[:, p.nz + p.nl:p.nz + p.nl + p.nv]
+            self.y = self.rec[:, p.nz + p.nl + p.nv:nvar]
+            self.out = torch.zeros((p.batch, 40), dtype=torch.uint8, device=dev)
+            self.grec = None
+            if gather and rank == 0:
+                self.grec = [torch.empty_like(self.rec) for _ in range(world)]
             self.events = []
 
-    lanes = [Lane() for _ in range(P)]
+    def run_mpc(p, data, P, steps, warmup, gather):
+        """`steps` timed solves of the batch `p`, P in flight.  Returns a dict."""
+        lanes = [Lane(p, gather) for _ in range(P)]
 
-    def step(k, timed):
-        ln = lanes[k % P]
-        with torch.cuda.stream(ln.stream):
-            ln.x.zero_()
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(ln.stream)
-            ln.solver.Solve(data, ln.z, ln.l, ln.v, ln.y, out=ln.out,
-                            stream=ln.stream.cuda_stream, async_=True)
-            e1.record(ln.stream)
-            if timed:
-                ln.events.append((e0, e1))
-            if dist is not None:
-                dist.gather(ln.x, ln.gx, dst=0)
-                dist.gather(ln.out, ln.go, dst=0)
+        def step(k, timed):
+            ln = lanes[k % P]
+            with torch.cuda.stream(ln.stream):
+                ln.x.zero_()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(ln.stream)
+                ln.solver.Solve(data, ln.z, ln.l, ln.v, ln.y, out=ln.out,
+                                stream=ln.stream.cuda_stream, async_=True)
+                e1.record(ln.stream)
+                if timed:
+                    ln.events.append((e0, e1))
+                if gather:
+                    sharding.gather_solutions(ln.x, ln.out, dst=0, record=ln.rec, gather_list=ln.grec)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def fence():
+            torch.cuda.synchronize()
+            if gather:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k, False)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = [e0.elapsed_time(e1) for ln in lanes for (e0, e1) in ln.events]
-    solver = lanes[0].solver
-    out = lanes[(args.steps - 1) % P].out
+        for k in range(warmup):
+            step(k, False)
+        fence()
+        w0 = time.time()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k, True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        w1 = time.time()
+        if gather:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kernel_ms = [e0.elapsed_time(e1) for ln in lanes for (e0, e1) in ln.events]
+        # every lane's last results (and, on rank 0, every rank's) are inspected
+        outs = [hip_api.out_to_numpy(ln.out) for ln in lanes[:min(P, steps + warmup)]]
+        if gather and rank == 0:
+            for ln in lanes[:min(P, steps + warmup)]:
+                for g in ln.grec:
+                    outs.append(sharding.unpack_out(g))
+        eflag = np.concatenate([o["eflag"] for o in outs])
+        newton = np.concatenate([o["newton_iters"] for o in outs])
+        res = dict(elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)), ok=bool((eflag == 0).all()),
+                   not_converged=int((eflag != 0).sum()), mean_newton=float(newton.mean()),
+                   query=lanes[0].solver.query(), kernel=lanes[0].solver.kernel_name(), wall=(w0, w1))
+        for ln in lanes:
+            ln.solver.close()
+        del lanes
+        torch.cuda.empty_cache()
+        return res
 
-    o = hip_api.out_to_numpy(out)
-    ok = bool((o["eflag"] == 0).all())
+    P = max(1, args.pipeline)
+    p = fx.synthetic_mpc_batch(B, first_id=first_id)  # shard by global instance id
+    data = upload(p)
+    head = run_mpc(p, data, P, args.steps, args.warmup, dist is not None)
+
+    extras = args.extras if args.extras >= 0 else (1 if world == 1 else 0)
+    blocks = {}
+    if extras and rank == 0:
+        ser = run_mpc(p, data, 1, min(args.steps, 6), 1, False)
+        blocks["serial"] = {"value": B * min(args.steps, 6) / ser["elapsed"], "unit": "QPs/sec",
+                            "ms_per_step": 1e3 * ser["elapsed"] / min(args.steps, 6), "kernel_ms": ser["kernel_ms"],
+                            "steps_in_flight": 1, "all_converged": ser["ok"]}
+        del data
+        torch.cuda.empty_cache()
+        pl = fx.synthetic_mpc_ltv_batch(B, first_id=first_id)
+        dl = upload(pl)
+        nl_steps = max(8, min(args.steps, 24))
+        ltv = run_mpc(pl, dl, P, nl_steps, args.warmup, False)
+        blocks["ltv_dense_rows"] = {
+            "value": B * nl_steps / ltv["elapsed"], "unit": "QPs/sec", "ms_per_step": 1e3 * ltv["elapsed"] / nl_steps,
+            "mean_newton_iters": ltv["mean_newton"], "steps": nl_steps, "steps_in_flight": P,
+            "newton_iters_per_sec": ltv["mean_newton"] * B * nl_steps / ltv["elapsed"],
+            "workload": "same shape and initial states; every stage has its own Q, R, S, A, B, E, L and every "
+                        "constraint row 2-3 nonzeros (tools/fixtures.py: synthetic_mpc_ltv_batch)",
+            "all_converged": ltv["ok"]}
+        del dl, pl
+        torch.cuda.empty_cache()
+        blocks["dense"] = bench_dense(torch, dev, fx, hip_api)
+        blocks["receding"] = bench_receding(torch, dev, fx, hip_api)
+    gpu_t1 = time.time()
+
     if rank == 0:
+        elapsed = head["elapsed"]
         total_qps = world * B * args.steps / elapsed
-        k_ms = float(np.mean(kernel_ms))
-        achieved = ALG_BYTES_PER_QP * B / (k_ms * 1e-3) / 1e9
-        mean_newton = float(o["newton_iters"].mean())
+        per_step_s = elapsed / args.steps
+        achieved = ALG_BYTES_PER_QP * B * world / per_step_s / 1e9 / world  # per GPU
+        k_ms = head["kernel_ms"]
+        traffic, traffic_src = stored_traffic(B)
         rec = {
             "metric": "QPs/sec (batched MPC N=30 nx=12 nu=4 nc=20)",
             "value": total_qps, "unit": "QPs/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * per_step_s,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: batched FBstabMpc, batch=8192 per GPU, "
                                    "N=30 nx=12 nu=4 nc=20, cold start, default options",
                        "batch_per_gpu": B, "global_batch": world * B, "steps_in_flight": P,
                        "parallelism": f"batch sharded over {world} GPU(s)" +
-                                      (", RCCL gather to rank 0" if dist is not None else "")},
+                                      (", one RCCL gather to rank 0 per batch" if dist is not None else "")},
+            # achieved = algorithmic bytes of one batch over the time the GPU spends per
+            # batch (ms_per_step), per GPU; the per-launch figure (duration of one launch
+            # as HIP events and rocprof see it, with `launches_in_flight` sharing the GPU)
+            # is the named extra
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(B),
-                         "kernel": "fbstab_mpc_r16_kernel<12,4,20>", "kernel_ms": k_ms,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_per_step_GBps": (traffic / per_step_s / 1e9) if traffic else None,
+                         "kernel": head["kernel"], "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B,
-                         # `achieved` divides by the duration of one launch as rocprof sees it; with
-                         # P launches sharing the GPU that duration is ~P times the time the GPU
-                         # spends per batch, which ms_per_step measures:
-                         "launches_in_flight": P,
-                         "achieved_per_step": ALG_BYTES_PER_QP * B * world / (elapsed / args.steps) / 1e9,
-                         # what the kernel actually moves (PMC bytes of one launch) per second of this
-                         # run, per GPU: the figure to hold against the HBM peak
-                         "traffic_per_step_GBps": (pmc_traffic(B) or 0.0) / (elapsed / args.steps) / 1e9 or None},
+                         "per_launch": {"achieved": ALG_BYTES_PER_QP * B / (k_ms * 1e-3) / 1e9,
+                                        "frac": ALG_BYTES_PER_QP * B / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "launches_in_flight": P}},
             "fp64": {"model_flop_per_newton_iter": FLOP_PER_NEWTON,
-                     "mean_newton_iters": mean_newton,
-                     # (rate of the whole GPU: flops of one batch over the time per step)
-                     "achieved_tflops": FLOP_PER_NEWTON * mean_newton * B * world / (elapsed / args.steps) / 1e12 / world,
+                     "mean_newton_iters": head["mean_newton"],
+                     # (rate of one GPU: flops of one batch over the time per step)
+                     "achieved_tflops": FLOP_PER_NEWTON * head["mean_newton"] * B / per_step_s / 1e12,
                      "peak_tflops": FP64_PEAK_TFLOPS},
-            "all_converged": ok,
-            "launch": solver.query(),
+            "all_converged": head["ok"], "not_converged": head["not_converged"],
+            "launch": head["query"],
+            "gpu_leg": {"timed_region_unix": [head["wall"][0], head["wall"][1]],
+                        "all_gpu_work_unix": [gpu_t0, gpu_t1]},
         }
+        rec.update(blocks)
         n_cpu = args.cpu_sample
         if n_cpu < 0:
             n_cpu = 256 * max(1, (os.cpu_count() or 1))
@@ -232,6 +298,86 @@ def main():
         print(json.dumps(rec))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
+    """BASELINE configs[1]: batched FBstabDense, batch 4096, nz=50 nl=10 nv=100."""
+    p = fx.synthetic_dense_batch(batch, 50, 10, 100)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((batch, n), dtype=torch.float64, device=dev)
+    L = []
+    for _ in range(lanes):
+        L.append(dict(s=hip_api.FBstabDenseBatch(50, 10, 100, max_batch=batch), st=torch.cuda.Stream(device=dev),
+                      z=mk(50), l=mk(10), v=mk(100), y=mk(100),
+                      out=torch.zeros((batch, 40), dtype=torch.uint8, device=dev)))
+    # one launch alone: kernel time
+    ln = L[0]
+    for _ in range(2):
+        for a in (ln["z"], ln["l"], ln["v"]):
+            a.zero_()
+        ln["s"].Solve(data, ln["z"], ln["l"], ln["v"], ln["y"], out=ln["out"])
+    k_ms = ln["s"].last_kernel_ms()
+
+    def step(k):
+        ln = L[k % lanes]
+        with torch.cuda.stream(ln["st"]):
+            for a in (ln["z"], ln["l"], ln["v"]):
+                a.zero_()
+            ln["s"].Solve(data, ln["z"], ln["l"], ln["v"], ln["y"], out=ln["out"],
+                          stream=ln["st"].cuda_stream, async_=True)
+    for k in range(lanes):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    outs = [hip_api.out_to_numpy(ln["out"]) for ln in L]
+    ok = all((o["eflag"] == 0).all() for o in outs)
+    per_step = dt / steps
+    ach = DENSE_ALG_BYTES_PER_QP * batch / per_step / 1e9
+    r = {"config": "BASELINE configs[1]: batched FBstabDense, batch=4096, nz=50 nl=10 nv=100, cold start",
+         "value": batch * steps / dt, "unit": "QPs/sec", "ms_per_step": 1e3 * per_step, "steps": steps,
+         "steps_in_flight": lanes, "kernel_ms": k_ms, "serial_value": batch / (k_ms * 1e-3),
+         "mean_newton_iters": float(outs[0]["newton_iters"].mean()), "all_converged": ok,
+         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "fbstab_dense_kernel",
+                      "algorithmic_bytes_per_launch": DENSE_ALG_BYTES_PER_QP * batch},
+         "launch": L[0]["s"].query()}
+    for ln in L:
+        ln["s"].close()
+    return r
+
+
+def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200):
+    """BASELINE configs[4]: warm-started receding-horizon sweep, plant step
+    x+ = A x + B u0, retirement of failed trajectories and the warm start all on
+    the device, one C call for the whole sweep (fbstab_hip_mpc_receding_sweep)."""
+    p = fx.synthetic_mpc_batch(trajectories)
+    N, nx, nu, nc = p.sizes()
+    A, Bm = fx.quadrotor_model()
+    s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=trajectories)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((trajectories, n), dtype=torch.float64, device=dev)
+    z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = s.RecedingSweep(data, z, l, v, y, A, Bm, steps, retire=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = r["stats"]
+    res = {"config": "BASELINE configs[4]: 4096 closed-loop trajectories x 200 steps, N=30 nx=12 nu=4 nc=20, "
+                     "warm start (unshifted), x+ = A x + B u0 on the device, failed trajectories retired to the origin",
+           "value": trajectories * steps / dt, "unit": "QPs/sec", "wall_ms_per_step": 1e3 * dt / steps,
+           "kernel_ms_first": float(r["kernel_ms"][0]), "kernel_ms_median": float(np.median(r["kernel_ms"])),
+           "kernel_ms_last": float(r["kernel_ms"][-1]), "trajectories": trajectories, "steps": steps,
+           "retired": int(st["retired_total"][-1]),
+           "mean_newton_first_step": float(st["newton_sum"][0]) / trajectories,
+           "mean_newton_last_step": float(st["newton_sum"][-1]) / trajectories,
+           "host_syncs_per_step": 0}
+    s.close()
+    return res
 
 
 if __name__ == "__main__":

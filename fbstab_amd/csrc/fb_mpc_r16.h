@@ -11,7 +11,7 @@
 //
 //   * Stage record i of a QP = kSlots slots of 16 doubles, lane r of the row
 //     owning element r of every slot:
-//       iterate vectors  z rz zb lb dz wz l rl dl wl | v y vb yb dv adz gam rvm
+//       iterate vectors  z rz zb lb dz wz l rl dl wl+ | v y | vb | yb | dv adz gam rvm
 //       constants        f h b                        (mpc_data.cc:240-289)
 //       factor record    inv(Lc) (rows and columns folded into one triangle
 //                        pair), inv(Pi), t, theta
@@ -63,28 +63,51 @@ struct MpcR16 {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   static constexpr bool kFusedTrial = true;
   static constexpr bool kOwnVectorOps = true;
-  // the loads of stage i+1 are issued during stage i (one wavefront per SIMD:
-  // nothing else covers their latency)
-  static constexpr bool kPrefetch = true;
   static constexpr int NS = NX + NU;
   static constexpr int KS = (NC + 15) / 16;  // constraint slots per lane
   static_assert(NS <= 16, "stage width must fit one DPP row");
 
   // ---- stage record ----------------------------------------------------------
+  // (DL, WLN): WLN(i) = wl(i + 1), the l-block increment the backward sweep forms at
+  // stage i for block i + 1 - kept with dl(i) so that the sweep writes whole pairs;
+  // wl(0) = dx(0) is not stored (readers walk the stages upwards and carry it).
   static constexpr int sZ = 0, sRZ = 1, sZB = 2, sLB = 3, sDZ = 4, sWZ = 5, sL = 6, sRL = 7,
-                       sDL = 8, sWL = 9;
+                       sDL = 8, sWLN = 9;
   static constexpr int sV = 10;              // pairs (V_s, Y_s)
-  static constexpr int sVB = sV + 2 * KS;    // pairs (VB_s, YB_s)
-  static constexpr int sDV = sVB + 2 * KS;   // pairs (DV_s, ADZ_s)
-  static constexpr int sGAM = sDV + 2 * KS;  // pairs (GAM_s, RVM_s)
-  static constexpr int sF = sGAM + 2 * KS, sH = sF + 1;
+  static constexpr int sVB = sV + 2 * KS;             // KS slots vbar (every sweep reads them)
+  static constexpr int sYB = sVB + ((KS + 1) & ~1);   // KS slots ybar (results only)
+  static constexpr int sDV = sYB + ((KS + 1) & ~1);   // pairs (DV_s, ADZ_s)
+  // The barrier terms gamma = g0 / mu and rv / mu of the Newton system
+  // (riccati_linear_solver.cc:91-99) travel in the record from the forward to the
+  // backward sweep.  (Measured and dropped, build knob FB_R16_RECOMPUTE_GAMMA: the
+  // backward sweep forming them again from (v, y, vbar) saves 8 slots of traffic
+  // per stage and costs 90 instructions there - 6 % slower end to end.)
+#if defined(FB_R16_RECOMPUTE_GAMMA)
+  static constexpr bool kStoreGamma = false;
+#else
+  static constexpr bool kStoreGamma = true;
+#endif
+  static constexpr int sGAM = sDV + 2 * KS;  // (kStoreGamma) pairs (GAM_s, RVM_s)
+  static constexpr int sF = sGAM + (kStoreGamma ? 2 * KS : 0), sH = sF + 1;
   static constexpr int sB = sH + 1;          // KS slots
-  // factor record.  inv(Lc) is lower triangular: slot j of fX holds, in lane r,
-  // X[max(j,r)][min(j,r)] - column r of inv(Lc) for j >= r, row r for j <= r.
-  static constexpr int fX = (sB + KS + 1) & ~1;
-  static constexpr int fPinv = fX + 16;                // inv(Pi), NX slots
-  static constexpr int fT = (fPinv + NX + 1) & ~1, fTh = fT + 1;
-  static constexpr int kSlots = fT + 2;
+  // factor record, packed: the lower triangles of inv(Lc) (NS (NS + 1) / 2 values,
+  // row-major: element (j, c <= j) at j (j + 1) / 2 + c) and of the symmetric inv(Pi)
+  // (NX (NX + 1) / 2 values), each cut into slots of 16 consecutive elements - the
+  // pipelined solver is bound by the bytes of this record going out in the forward
+  // sweep and back in the backward sweep.  Lanes get at their own row and column
+  // through a linear image of the triangle in LDS (tri_*).  t rides with the last
+  // slot of inv(Lc), theta with the last one of inv(Pi): whole pairs, each
+  // written at one time.
+  static constexpr int tri(int j) { return j * (j + 1) / 2; }
+  static constexpr int kXTri = tri(NS), kPTri = tri(NX);
+  static constexpr int kXFull = kXTri / 16, kPFull = kPTri / 16;  // full slots; one partial slot follows
+  static_assert(kXTri % 16 != 0 && kPTri % 16 != 0 && kXFull % 2 == 0 && kPFull % 2 == 0,
+                "record layout assumes a partial last slot after an even number of full ones");
+  static constexpr int fX = (sB + KS + 1) & ~1;      // kXFull slots, then the pair (last, t)
+  static constexpr int fXT = fX + kXFull;
+  static constexpr int fP = fXT + 2;                 // kPFull slots, then the pair (last, theta)
+  static constexpr int fPTh = fP + kPFull;
+  static constexpr int kSlots = fPTh + 2;
   static constexpr int kRec = 16 * kSlots;  // doubles per stage
   // Matrix copy ("pack"), a region of its own: stage i's copy sits at
   // pack + i * kPack.  A stage whose matrices are bitwise identical to the
@@ -113,7 +136,11 @@ struct MpcR16 {
   //                   with 16-byte LDS loads;
   //   [kPackLds, ..)  C as [col][k] (A z products) or the 16 x 16 transpose
   //                   buffer (forward sweep); odd strides.
-  static constexpr int CS = NC | 1, TS = 17;
+  static constexpr int CS = NC | 1;
+  // the triangle images: inv(Lc) at 0, inv(Pi) behind it, one dump word for the
+  // lanes that have no element to write
+  static constexpr int kXl = 0, kPl = (kXTri + 15) & ~15, kDump = kPl + ((kPTri + 15) & ~15);
+  static constexpr int TS = (kDump + 16 + 15) / 16;  // 16 * TS doubles hold them
   static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
   static constexpr bool kPackInLds = true;
   static constexpr int kPackLds = kPackInLds ? 16 * kPackLdsSlots : 0;
@@ -528,8 +555,13 @@ struct MpcR16 {
       constexpr int sl = decltype(S_)::value;
       in.vy[sl] = ld2(R, sV + 2 * sl);
       in.da[sl] = ld2(R, sDV + 2 * sl);
-      in.vb[sl] = ld(R, sVB + 2 * sl);
     });
+    ldv<sVB, KS>(R, in.vb);
+  }
+  // wl(i) for a pass that walks the stages upwards: dx(0) on the state lanes at
+  // stage 0, afterwards the WLN the previous stage held.
+  static FB_DEV double wl_of_stage(int i, bool rx, double dz0, double wln_prev) {
+    return i == 0 ? (rx ? dz0 : 0.0) : wln_prev;
   }
   template <int K>
   FB_DEV void norms_at_multi(const C& c, double t0, double beta, double sigma, double alpha,
@@ -545,14 +577,18 @@ struct MpcR16 {
     sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
     TrialIn in;
     load_trial(R0, in);
+    const bool rx = c.tid < NX;
+    double wln = 0.0;
     for (int i = 0; i <= N_; i++) {
       const TrialIn cu = in;
       if (i < N_) load_trial(R0 + (long)(i + 1) * kRec, in);
+      const double wl = wl_of_stage(i, rx, cu.dw[0], wln);
+      wln = cu.dwl[1];
       sfor<0, K>([&](auto Kk) {
         constexpr int k = decltype(Kk)::value;
         const double rzt = fma(tt[k], cu.dw[1], cu.zr[1]);
         const double rzi = rzt + sigma * (fma(tt[k], cu.dw[0], cu.zr[0]) - cu.bb[0]);
-        const double rlt = fma(tt[k], cu.dwl[1], cu.lr[1]);
+        const double rlt = fma(tt[k], wl, cu.lr[1]);
         const double rli = rlt + sigma * (fma(tt[k], cu.dwl[0], cu.lr[0]) - cu.bb[1]);
         s[k] = fma(rzi, rzi, s[k]);
         s[k] = fma(rli, rli, s[k]);
@@ -588,11 +624,15 @@ struct MpcR16 {
     if (t == 0.0) return;
     const int N_ = N;
     double* const R0 = rec;
+    const bool rx = c.tid < NX;
+    double wln = 0.0;
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
       const dbl2 zr = ld2(R, sZ), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+      const double wl = wl_of_stage(i, rx, dw[0], wln);
+      wln = dwl[1];
       st2(R, sZ, fma(t, dw[0], zr[0]), fma(t, dw[1], zr[1]));
-      st2(R, sL, fma(t, dwl[0], lr[0]), fma(t, dwl[1], lr[1]));
+      st2(R, sL, fma(t, dwl[0], lr[0]), fma(t, wl, lr[1]));
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
         const dbl2 vy = ld2(R, sV + 2 * sl), da = ld2(R, sDV + 2 * sl);
@@ -611,13 +651,17 @@ struct MpcR16 {
   struct ZL {
     double z, rz, l, rl, dz, dl;
   };
-  static FB_DEV ZL stepped_zl(const double* R, double t) {
+  // (z, l) blocks of stage i with the step t applied.  Called for i = 0, 1, 2, ...:
+  // wln carries WLN from one stage to the next.
+  static FB_DEV ZL stepped_zl(const double* R, double t, int i, bool rx, double& wln) {
     const dbl2 zr = ld2(R, sZ), bb = ld2(R, sZB), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+    const double wl = wl_of_stage(i, rx, dw[0], wln);
+    wln = dwl[1];
     ZL o;
     o.z = fma(t, dw[0], zr[0]);
     o.rz = fma(t, dw[1], zr[1]);
     o.l = fma(t, dwl[0], lr[0]);
-    o.rl = fma(t, dwl[1], lr[1]);
+    o.rl = fma(t, wl, lr[1]);
     o.dz = o.z - bb[0];
     o.dl = o.l - bb[1];
     return o;
@@ -637,7 +681,8 @@ struct MpcR16 {
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
     double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
     struct VIn {
-      dbl2 vy[KS], da[KS], vb[KS];
+      dbl2 vy[KS], da[KS];
+      double vb[KS];
       dbl2 fh;
       double bs[KS], ABc[NX];
     };
@@ -647,17 +692,18 @@ struct MpcR16 {
         constexpr int sl = decltype(S_)::value;
         in.vy[sl] = ld2(R, sV + 2 * sl);
         in.da[sl] = ld2(R, sDV + 2 * sl);
-        in.vb[sl] = ld2(R, sVB + 2 * sl);
       });
+      ldv<sVB, KS>(R, in.vb);
       if (check) {
         in.fh = ld2(R, sF);
         sfor<0, KS>([&](auto S_) { in.bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value); });
         ldv<pABc, NX>(P0 + po[i], in.ABc);
       }
     };
-    ZL cur = stepped_zl(R0, t);
+    double wln = 0.0;
+    ZL cur = stepped_zl(R0, t, 0, rx, wln);
     ZL nxt = cur;
-    if (N_ > 0) nxt = stepped_zl(R0 + kRec, t);
+    if (N_ > 0) nxt = stepped_zl(R0 + kRec, t, 1, rx, wln);
     VIn vin;
     load_v(0, vin);
     for (int i = 0; i <= N_; i++) {
@@ -665,7 +711,7 @@ struct MpcR16 {
       // (z, l) of stage i+2 and the v group of stage i+1, in flight during this stage
       ZL nn;
       nn.z = nn.rz = nn.l = nn.rl = nn.dz = nn.dl = 0.0;
-      if (i + 2 <= N_) nn = stepped_zl(R + 2 * kRec, t);
+      if (i + 2 <= N_) nn = stepped_zl(R + 2 * kRec, t, i + 2, rx, wln);
       const VIn vc = vin;
       if (i < N_) load_v(i + 1, vin);
       if (i == N_) nxt.z = nxt.rz = nxt.l = nxt.rl = nxt.dz = nxt.dl = 0.0;
@@ -680,7 +726,7 @@ struct MpcR16 {
         constexpr int sl = decltype(S_)::value;
         const double vv = fmax0(fma(t, vc.da[sl][0], vc.vy[sl][0]));
         const double yy = fma(-t, vc.da[sl][1], vc.vy[sl][1]);
-        dvs[sl] = vv - vc.vb[sl][0];
+        dvs[sl] = vv - vc.vb[sl];
         st2(R, sV + 2 * sl, vv, yy);
         st2(R, sDV + 2 * sl, dvs[sl], 0.0);
         s_dx = fma(dvs[sl], dvs[sl], s_dx);
@@ -825,9 +871,14 @@ struct MpcR16 {
         st(R + kRec, sRL, rln);
         s_nat = fma(rln, rln, s_nat);
       }
+      {
+        double vbs[KS], ybs[KS];
+        sfor<0, KS>([&](auto S_) { vbs[decltype(S_)::value] = vy[decltype(S_)::value][0]; ybs[decltype(S_)::value] = vy[decltype(S_)::value][1]; });
+        stv<sVB, KS>(R, vbs);
+        stv<sYB, KS>(R, ybs);
+      }
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        st2(R, sVB + 2 * sl, vy[sl][0], vy[sl][1]);
         const double pn = pnr(vy[sl][1], vy[sl][0], alpha);  // zero on padding lanes
         const double pf = pfb(vy[sl][1], vy[sl][0], alpha);
         s_vo = fma(pn, pn, s_vo);
@@ -863,12 +914,11 @@ struct MpcR16 {
         const dbl2 vy = ld2(R, sV + 2 * sl);
         double vv = vy[0], yy = vy[1];
         if (WHICH == 1) {
-          const dbl2 b = ld2(R, sVB + 2 * sl);
-          vv = b[0];
-          yy = b[1];
+          vv = ld(R, sVB + sl);
+          yy = ld(R, sYB + sl);
         } else if (WHICH == 2) {
           vv = ld(R, sDV + 2 * sl);
-          yy = (vy[1] - ld(R, sVB + 2 * sl + 1)) + ld(R, sB + sl);
+          yy = (vy[1] - ld(R, sYB + sl)) + ld(R, sB + sl);
         }
         if (k < nc_) {
           uv[(long)i * nc_ + k] = vv;
@@ -901,7 +951,7 @@ struct MpcR16 {
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
         const int k = r + 16 * sl;
-        st(R, sVB + 2 * sl, k < nc_ ? dbg[nz + nl + (long)i * nc_ + k] : 0.0);
+        st(R, sVB + sl, k < nc_ ? dbg[nz + nl + (long)i * nc_ + k] : 0.0);
       });
     }
     c.sync();
@@ -921,7 +971,7 @@ struct MpcR16 {
       }
       if (r < nx_) {
         o[nz + (long)i * nx_ + r] = ld(R, sDL);
-        o[2 * nz + nl + 2 * nv + (long)i * nx_ + r] = ld(R, sWL);
+        o[2 * nz + nl + 2 * nv + (long)i * nx_ + r] = i == 0 ? ld(R, sDZ) : ld(R - kRec, sWLN);
         o[3 * nz + 2 * nl + 2 * nv + (long)i * nx_ + r] = ld(R, sRL);
       }
       sfor<0, KS>([&](auto S_) {
@@ -958,8 +1008,35 @@ struct MpcR16 {
       constexpr int s = decltype(S_)::value;
       in.vy[s] = ld2(R, sV + 2 * s);
       in.da[s] = ld2(R, sDV + 2 * s);
-      in.vb[s] = ld(R, sVB + 2 * s);
     });
+    ldv<sVB, KS>(R, in.vb);
+  }
+  // What a backward stage reads of its own iterate vectors (fetched a stage ahead).
+  struct BwdIn {
+    dbl2 zr, bb, lr;
+    dbl2 vy[KS], gr[KS];
+    double vb[KS];
+  };
+  static FB_DEV void load_bwd(const double* R, BwdIn& in) {
+    in.zr = ld2(R, sZ);
+    in.bb = ld2(R, sZB);
+    in.lr = ld2(R, sL);
+    sfor<0, KS>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      in.vy[s] = ld2(R, sV + 2 * s);
+      if constexpr (kStoreGamma) in.gr[s] = ld2(R, sGAM + 2 * s);
+    });
+    ldv<sVB, KS>(R, in.vb);
+  }
+  // (gamma, rv / mu) of constraint k at (v, y) for the subproblem centred at vbar
+  // (riccati_linear_solver.cc:91-99)
+  static FB_DEV dbl2 barrier_terms(double vk, double yk, double vb, double sigma, double alpha, bool real) {
+    const double ys = yk + sigma * (vk - vb);
+    double ph, g0, g1;
+    pfb_all(ys, vk, alpha, &ph, &g0, &g1);
+    const double imu = rcp_fast(g1 + sigma * g0);
+    dbl2 o = {real ? g0 * imu : 0.0, real ? -ph * imu : 0.0};
+    return o;
   }
 
   FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
@@ -986,19 +1063,18 @@ struct MpcR16 {
     bool ok = true;
 
     FB_STAMP_DECL;
-    // kPrefetch: the loads of stage i+1 are issued during stage i's second
-    // Cholesky chain (hand software pipelining, for one wave per SIMD); without
-    // it each stage loads at its top and a second resident wave covers the wait.
+    // The loads of stage i+1 are issued at the top of stage i (hand software
+    // pipelining: with one wavefront per SIMD nothing else covers their latency).
     FwdIn cur;
+    double wln = 0.0;  // WLN of the previous stage = wl of this one
     // offsets of the matrix copies of stages i and i+1 (fetched a stage ahead)
     int pcur = po[0], pnxt = po[N_ > 0 ? 1 : 0];
     int loff = lds_off;  // copy resident in LDS
-    if (kPrefetch) load_fwd(R0, cur);
+    load_fwd(R0, cur);
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
       const int pnn = po[i + 2 <= N_ ? i + 2 : N_];
-      if (!kPrefetch) load_fwd(R, cur);
       stage_pack_s(c, P0, Lp, loff, pcur);
       // Lane id made opaque per iteration: (ro == j) selects are then recomputed
       // where used instead of being hoisted out of the loop as 16+ live masks.
@@ -1014,24 +1090,26 @@ struct MpcR16 {
         const int k = r + 16 * s;
         const double vk = fma(tp, cur.da[s][0], cur.vy[s][0]);
         const double yk = fma(-tp, cur.da[s][1], cur.vy[s][1]);
-        const double ys = yk + sigma * (vk - cur.vb[s]);
-        double ph, g0, g1;
-        pfb_all(ys, vk, alpha, &ph, &g0, &g1);
-        const double imu = rcp_fast(g1 + sigma * g0);
-        Gam[s] = k < NC ? g0 * imu : 0.0;
-        Rvm[s] = k < NC ? -ph * imu : 0.0;
+        const dbl2 bt = barrier_terms(vk, yk, cur.vb[s], sigma, alpha, k < NC);
+        Gam[s] = bt[0];
+        Rvm[s] = bt[1];
         st2(R, sV + 2 * s, vk, yk);
-        st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
+        if constexpr (kStoreGamma) st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
       });
       // pending step on (z, rz), (l, rl); eliminated right-hand side (:222-225)
       const double zz = fma(tp, cur.dw[0], cur.zr[0]);
       const double rzz = fma(tp, cur.dw[1], cur.zr[1]);
       const double ll = fma(tp, cur.dwl[0], cur.lr[0]);
-      const double rll = fma(tp, cur.dwl[1], cur.lr[1]);
+      const double rll = fma(tp, wl_of_stage(i, rx, cur.dw[0], wln), cur.lr[1]);
+      wln = cur.dwl[1];
       st2(R, sZ, zz, rzz);
       st2(R, sL, ll, rll);
       double r1 = -(rzz + sigma * (zz - cur.bb[0]));  // zero where there is no row
       const double r2 = rll + sigma * (ll - cur.bb[1]);
+      FB_SB();
+      // next stage's inputs, a whole stage ahead (the last stage fetches itself once
+      // more: no branch here)
+      load_fwd(i < N_ ? R + kRec : R, cur);
       FB_SB();
       FB_STAMP_LAP(0);
       // K row: H + sigma I (at pivot time) + inv(Pi) block + C' Gamma C (:101-123, :142-145)
@@ -1072,40 +1150,58 @@ struct MpcR16 {
         const double hsum = bc_dot<0, NX>(Pinv, th);
         if (rx) gv = r1 - hsum;
       }
-      // (lanes NX..15 hold no row of inv(Pi): their quarter of every slot is neither
-      // written nor read back - the pipelined solver is bound by these bytes)
-      if (rx) stv<fPinv, NX>(R, Pinv);
+      // inv(Pi_i) joins the record as its lower triangle: rows to the linear image
+      // in LDS, 16 consecutive elements per slot back
+      const int tri_r = (ro * (ro + 1)) >> 1;
+      {
+        c.sync();  // the previous stage has read its images
+        sfor<0, NX>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          Tr[(rx && cc <= ro) ? kPl + tri_r + cc : kDump] = Pinv[cc];
+        });
+        c.sync();
+        double Pp[kPFull + 1];
+        sfor<0, kPFull + 1>([&](auto S_) { Pp[decltype(S_)::value] = Tr[kPl + 16 * decltype(S_)::value + r]; });
+        if (16 * kPFull + r >= kPTri) Pp[kPFull] = 0.0;
+        stv<fP, kPFull>(R, Pp);
+        st2(R, fPTh, Pp[kPFull], th);
+      }
       FB_SB();
       FB_STAMP_LAP(2);
-      // [A B] row r, the right-hand side of the W solve, requested now so that it
-      // arrives behind the first chain
-      double W[NS];
-      ldl<pABr, NS>(Lp, W);
       // ---- Lc = chol(K); columns of inv(Lc) and W = [A B] inv(Lc)' (AM and -P of
       // :149-175) from one pass over Lc
+      double W[NS];
       ok = chol_rows<NS>(K, ro, sigma) && ok;
       if (!ok) { lds_off = loff; return false; }
       double XC[NS];
       FB_STAMP_LAP(3);
       FB_SB();
+      ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
       tri_inv_cols_solve<NS>(K, XC, W, ro);
       FB_STAMP_LAP(4);
       FB_SB();
-      // rows of inv(Lc) through an LDS transpose
+      // columns of inv(Lc) to the linear image of its lower triangle; rows (for t) and
+      // the record's slots come back from it
       double XR[NS];
       c.sync();
-      sfor<0, NS>([&](auto RR) { Tr[decltype(RR)::value * TS + r] = XC[decltype(RR)::value]; });
+      sfor<0, NS>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        Tr[j >= ro ? kXl + tri(j) + r : kDump] = XC[j];
+      });
       c.sync();
-      sfor<0, NS>([&](auto Cc) { XR[decltype(Cc)::value] = Tr[r * TS + decltype(Cc)::value]; });
+      sfor<0, NS>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const double v = Tr[kXl + tri_r + j];
+        XR[j] = j <= ro ? v : 0.0;
+      });
+      double Xp[kXFull + 1];
+      sfor<0, kXFull + 1>([&](auto S_) { Xp[decltype(S_)::value] = Tr[kXl + 16 * decltype(S_)::value + r]; });
+      if (16 * kXFull + r >= kXTri) Xp[kXFull] = 0.0;
       FB_SB();
-      {
-        double Xm[NS];  // column r below the diagonal, row r above it
-        sfor<0, NS>([&](auto J) { Xm[decltype(J)::value] = decltype(J)::value >= ro ? XC[decltype(J)::value] : XR[decltype(J)::value]; });
-        stv<fX, NS>(R, Xm);
-      }
       // t = inv(Lc) g
       const double tvec = bc_dot<0, NS>(XR, gv);
-      st2(R, fT, tvec, th);
+      stv<fX, kXFull>(R, Xp);
+      st2(R, fXT, Xp[kXFull], tvec);
       FB_STAMP_LAP(5);
       FB_SB();
       // theta(i+1) partial = -W t.  (Outside the branch below on purpose: with W used
@@ -1113,9 +1209,6 @@ struct MpcR16 {
       // branch and keeps all 120 broadcasts alive for it - 240 registers.)
       thp = -bc_dot<0, NS>(W, tvec);
       if (i < N_) {
-        FB_SB();
-        // next stage's inputs: in flight during the second chain below
-        if (kPrefetch) load_fwd(R + kRec, cur);
         FB_SB();
         // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L).
         // (Measured and dropped: the two symmetric products with the other lanes'
@@ -1153,77 +1246,95 @@ struct MpcR16 {
 
     // ============ backward sweep (:267-341), fused with dv, A dz, W and the
     // residual norms of the first line-search trial ==========================
+    // One wavefront per SIMD: nothing but this wavefront's own instructions covers
+    // a load.  The factor record of stage i - 1 is therefore requested while stage i
+    // runs, each part into the registers its stage-i counterpart has just left
+    // (inv(Lc) after the two substitutions, inv(Pi) after dl, the [A B] columns after
+    // u), and the stage's own iterate vectors come a stage ahead as one bundle.
     double lp = 0.0;    // dl(i+1), lanes < NX
     double dzn = 0.0;   // dx(i+1), lanes < NX
     double s_in = 0.0, s_out = 0.0;
+    dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1, handed down by stage i+1
+    double lbn = 0.0;
+    double Ac[NX];
+    double Xp[kXFull + 1], Pp[kPFull + 1], tq, thq;  // the packed factor record of the stage
+    auto load_fac = [&](const double* R) {
+      ldv<fX, kXFull>(R, Xp);
+      const dbl2 a = ld2(R, fXT);
+      Xp[kXFull] = a[0];
+      tq = a[1];
+      ldv<fP, kPFull>(R, Pp);
+      const dbl2 b = ld2(R, fPTh);
+      Pp[kPFull] = b[0];
+      thq = b[1];
+    };
+    BwdIn bin;
     pcur = po[N_];
+    {
+      const double* R = R0 + (long)N_ * kRec;
+      load_fac(R);
+      ldv<pABc, NX>(P0 + pcur, Ac);
+      load_bwd(R, bin);
+    }
     for (int i = N_; i >= 0; i--) {
       double* R = R0 + (long)i * kRec;
-      const double* PK = P0 + pcur;
+      const double* Rp = i > 0 ? R - kRec : R;  // the stage fetched next (stage 0 once more at the end)
       stage_pack_s(c, P0, Lp, loff, pcur);
       pcur = po[i > 0 ? i - 1 : 0];
       int ro = r;
       asm volatile("" : "+v"(ro));
-      // With kPrefetch every load of the stage is issued up front (one wave per
-      // SIMD: nothing else covers the latency); otherwise each group is loaded
-      // one step ahead of its use, which keeps ~3 groups live instead of 7.
-      double XC[NS], XR[NS], Cc_[NC], Hr[NS], AB[NS], Ac[NX];
-      dbl2 tth, zr, bb;
-      dbl2 vy[KS], gr[KS];
-      double vb[KS];
-      dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1
-      double lbn = 0.0;
-      auto load_g0 = [&]() { ldv<fX, NS>(R, XC); ldv<pABc, NX>(PK, Ac); tth = ld2(R, fT); };
-      auto load_g1 = [&]() {};
-      auto load_g2 = [&]() {
-        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
-        if (rx) ldv<fPinv, NX>(R, Pinv);
-      };
-      auto load_g3 = [&]() {
-        ldl<pC, NC>(Lp, Cc_);
+      BwdIn cu = bin;
+      load_bwd(Rp, bin);
+      if constexpr (!kStoreGamma) {
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
-          vy[sl] = ld2(R, sV + 2 * sl);
-          gr[sl] = ld2(R, sGAM + 2 * sl);
-          vb[sl] = ld(R, sVB + 2 * sl);
+          cu.gr[sl] = barrier_terms(cu.vy[sl][0], cu.vy[sl][1], cu.vb[sl], sigma, alpha, r + 16 * sl < NC);
         });
-      };
-      auto load_g4 = [&]() {
-        ldl<pK, NS>(Lp, Hr);
-        zr = ld2(R, sZ);
-        bb = ld2(R, sZB);
-      };
-      auto load_g5 = [&]() {
-        ldl<pABr, NS>(Lp, AB);
-        if (i < N_) {
-          lrn = ld2(R + kRec, sL);
-          lbn = ld(R + kRec, sLB);
-        }
-      };
-      load_g0();
-      load_g1();
-      if (kPrefetch) { load_g2(); load_g3(); load_g4(); load_g5(); }
+      }
+      double Cc_[NC], Hr[NS], AB[NS];
+      ldl<pC, NC>(Lp, Cc_);
+      // the stage's triangles to their linear images in LDS; the registers they
+      // leave take the record of the stage below at once
+      const int tri_r = (ro * (ro + 1)) >> 1;
+      c.sync();
+      sfor<0, kXFull + 1>([&](auto S_) { Tr[kXl + 16 * decltype(S_)::value + r] = Xp[decltype(S_)::value]; });
+      sfor<0, kPFull + 1>([&](auto S_) { Tr[kPl + 16 * decltype(S_)::value + r] = Pp[decltype(S_)::value]; });
+      const double tcur = tq, thcur = thq;
+      FB_SB();
+      load_fac(Rp);
       FB_SB();
       // u = [A B]' dl(i+1) (zero at the terminal stage: lp = 0)
       double lpb[NX];
       bc_all<NX>(lp, lpb);
       const double u = dot4<NX>(Ac, lpb);
-      // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
+      ldv<pABc, NX>(P0 + pcur, Ac);
+      c.sync();
+      // column r and row r of inv(Lc), row r of inv(Pi)
+      double XC[NS], XR[NS];
       sfor<0, NS>([&](auto J) {
-        XR[decltype(J)::value] = decltype(J)::value <= ro ? XC[decltype(J)::value] : 0.0;
-        XC[decltype(J)::value] = decltype(J)::value >= ro ? XC[decltype(J)::value] : 0.0;
+        constexpr int j = decltype(J)::value;
+        const double vc = Tr[kXl + tri(j) + r], vr = Tr[kXl + tri_r + j];
+        XC[j] = j >= ro ? vc : 0.0;
+        XR[j] = j <= ro ? vr : 0.0;
       });
-      const double s = tth[0] - bc_dot<0, NS>(XR, u);
-      if (!kPrefetch) { load_g2(); FB_SB(); }
+      sfor<0, NX>([&](auto Cc) {
+        constexpr int cc = decltype(Cc)::value;
+        const double v = Tr[kPl + (cc <= ro ? tri_r + cc : tri(cc) + r)];
+        Pinv[cc] = rx ? v : 0.0;
+      });
+      FB_SB();
+      // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
+      const double s = tcur - bc_dot<0, NS>(XR, u);
       const double dzu = bc_dot<0, NS>(XC, s);
-      if (!kPrefetch) { load_g3(); FB_SB(); }
       // dl = -inv(Pi)(theta + dx)
-      const double tx = tth[1] + dzu;
+      const double tx = thcur + dzu;
       double dli = -bc_dot<0, NX>(Pinv, tx);
       if (!rx) dli = 0.0;
+      FB_SB();
       double dzb[NS];  // [dx; du](i), every lane
       bc_all<NS>(dzu, dzb);
-      if (!kPrefetch) { load_g4(); FB_SB(); }
+      ldl<pK, NS>(Lp, Hr);
+      ldl<pABr, NS>(Lp, AB);
       FB_STAMP_LAP(9);
       // ---- A dz and dv (:329-341) through the LDS copy of C
       C_to_lds(c, Cl, Cc_, r);
@@ -1232,11 +1343,11 @@ struct MpcR16 {
         constexpr int sl = decltype(S_)::value;
         double d = 0.0;
         if (valid) {
-          d = gr[sl][1] + gr[sl][0] * a;
+          d = cu.gr[sl][1] + cu.gr[sl][0] * a;
           // first line-search trial, v block (full_residual.cc:68-71, :99-106)
-          const double vi = vy[sl][0] + d;
-          const double yi = vy[sl][1] - a;
-          const double ys = yi + sigma * (vi - vb[sl]);
+          const double vi = cu.vy[sl][0] + d;
+          const double yi = cu.vy[sl][1] - a;
+          const double ys = yi + sigma * (vi - cu.vb[sl]);
           const double ph = pfb(ys, vi, alpha);
           const double pn = pnr(yi, vi, alpha);
           s_in = fma(ph, ph, s_in);
@@ -1245,7 +1356,6 @@ struct MpcR16 {
         st2(R, sDV + 2 * sl, d, valid ? a : 0.0);
         dvs[sl] = d;
       });
-      if (!kPrefetch) { load_g5(); FB_SB(); }
       // ---- wz = H dz + G'dl + A'dv
       double w;
       {
@@ -1257,11 +1367,11 @@ struct MpcR16 {
                         });
         w = (p[0] + p[1]) + (p[2] + p[3]);
       }
+      double wlv = 0.0;  // wl(i + 1)
       if (i < N_) {
         // l block i+1: wl = -(A dx + B du - dx(i+1)); trial norms (full_residual.cc:60-66)
         const double abz = dot4<NS>(AB, dzb);
-        const double wlv = rx ? -(abz - dzn) : 0.0;
-        st(R + kRec, sWL, wlv);
+        wlv = rx ? -(abz - dzn) : 0.0;
         const double lr = lrn[1] + wlv;
         const double li = lrn[0] + lp;
         const double ri = lr + sigma * (li - lbn);
@@ -1270,26 +1380,26 @@ struct MpcR16 {
       }
       {
         st2(R, sDZ, dzu, w);
-        const double zrr = zr[1] + w;
-        const double zi = zr[0] + dzu;
-        const double ri = zrr + sigma * (zi - bb[0]);
+        const double zrr = cu.zr[1] + w;
+        const double zi = cu.zr[0] + dzu;
+        const double ri = zrr + sigma * (zi - cu.bb[0]);
         s_in = fma(ri, ri, s_in);
         s_out = fma(zrr, zrr, s_out);
       }
-      st(R, sDL, dli);
+      st2(R, sDL, dli, wlv);
       if (i == 0) {
         // l block 0: -(G dz)_0 = dx(0)
-        const dbl2 lr0 = ld2(R, sL);
         const double wl0 = rx ? dzu : 0.0;
-        st(R, sWL, wl0);
-        const double lr = lr0[1] + wl0;
-        const double li = lr0[0] + dli;
-        const double ri = lr + sigma * (li - bb[1]);
+        const double lr = cu.lr[1] + wl0;
+        const double li = cu.lr[0] + dli;
+        const double ri = lr + sigma * (li - cu.bb[1]);
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
       }
       lp = dli;
       dzn = rx ? dzu : 0.0;
+      lrn = cu.lr;
+      lbn = cu.bb[1];
       FB_STAMP_LAP(10);
     }
     lds_off = loff;

@@ -1,7 +1,7 @@
 """Shared helpers for the parity tests."""
 import numpy as np
 
-from fbstab_amd import fixtures as fx
+from tools import fixtures as fx
 
 
 def dense_from_kat(k):

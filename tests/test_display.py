@@ -118,7 +118,8 @@ def test_device_trace_on_the_synthetic_workloads(oracle):
     flat-vector kernel although batches of this shape run on the record kernel)
     and one of the dense workload; the traced solve returns the same solution
     as the batch call."""
-    from fbstab_amd import fixtures as fx, hip_api
+    from fbstab_amd import hip_api
+    from tools import fixtures as fx
     for kind, p in (("mpc", fx.synthetic_mpc_batch(1, first_id=5)),
                     ("dense", fx.synthetic_dense_batch(1, 50, 10, 100))):
         ref = oracle.solve_display(p, opts=default_options())
@@ -143,7 +144,8 @@ def test_device_trace_on_the_synthetic_workloads(oracle):
 
 @pytest.mark.gpu
 def test_traced_solve_argument_errors():
-    from fbstab_amd import fixtures as fx, hip_api
+    from fbstab_amd import hip_api
+    from tools import fixtures as fx
     p = fx.synthetic_dense_batch(1, 20, 5, 40)
     s = hip_api.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=1)
     a = {k: np.ascontiguousarray(v[:1]) for k, v in p.arrays.items()}

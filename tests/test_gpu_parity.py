@@ -10,7 +10,7 @@ All arithmetic is FP64 on both sides."""
 import numpy as np
 import pytest
 
-from fbstab_amd import fixtures as fx
+from tools import fixtures as fx
 from oracle.oracle_py import default_options, reliable_options
 from tests import helpers as H
 

@@ -5,7 +5,7 @@ the kernel arithmetic where no GPU exists; the real parity tests are the
 import numpy as np
 import pytest
 
-from fbstab_amd import fixtures as fx
+from tools import fixtures as fx
 from oracle.oracle_py import default_options, reliable_options
 from tests import helpers as H
 

@@ -15,7 +15,7 @@ def _worker(rank, world, port, per_rank, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from fbstab_amd import fixtures as fx
+    from tools import fixtures as fx
     from fbstab_amd import sharding
     from oracle.oracle_py import Oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +35,7 @@ def _worker(rank, world, port, per_rank, q):
 
 def test_shard_and_gather_equals_single_process(oracle):
     import torch.multiprocessing as mp
-    from fbstab_amd import fixtures as fx
+    from tools import fixtures as fx
     from fbstab_amd import sharding
     world, per_rank = 2, 5
     ctx = mp.get_context("spawn")

@@ -5,7 +5,8 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from fbstab_amd import fixtures as fx, hip_api
+from fbstab_amd import hip_api
+from tools import fixtures as fx
 from oracle.oracle_py import Oracle
 first, n = int(sys.argv[1]), int(sys.argv[2])
 p = fx.synthetic_mpc_batch(n, first_id=first)

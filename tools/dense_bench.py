@@ -5,7 +5,8 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from fbstab_amd import fixtures as fx, hip_api
+from fbstab_amd import hip_api
+from tools import fixtures as fx
 from oracle.oracle_py import Oracle
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nz, nl, nv = 50, 10, 100

@@ -12,7 +12,8 @@ Two groups:
   ``splitmix64`` -> uniform double, keyed by (seed, global instance id,
   element), so that sharding a batch over ranks never changes the data.
 
-Nothing here imports the oracle or the HIP library.
+Nothing here imports the oracle or the HIP library; the module is test and
+benchmark infrastructure, not part of the product package.
 """
 from __future__ import annotations
 
@@ -400,6 +401,51 @@ def synthetic_mpc_batch(batch: int, first_id: int = 0, seed: int = MASTER_SEED,
         else:
             p.arrays[k] = np.ascontiguousarray(
                 np.broadcast_to(one.arrays[k], (batch, one.arrays[k].shape[1])))
+    return p
+
+
+def synthetic_mpc_ltv_batch(batch: int, first_id: int = 0, seed: int = MASTER_SEED,
+                            N: int = 30) -> MpcProblem:
+    """The same plant and initial states as ``synthetic_mpc_batch`` posed as a
+    time-VARYING problem with DENSE constraint rows, which is what the API
+    allows (fbstab_mpc.h:67-81; SURVEY.md 8d assumes no sharing between stages):
+    every stage has its own Q, R, S, A, B (smooth drift along the horizon, a
+    small state-input cross term) and its own E, L, whose rows are mixtures of
+    two or three of the box rows (polytope still containing the origin strictly,
+    so the problems stay feasible).  No two stages share matrices and no
+    constraint row has a single nonzero: the record kernel can neither share
+    matrix copies between stages nor take its bound-constraint path."""
+    base = synthetic_mpc_batch(1, first_id=0, seed=seed, N=N)
+    nx, nu, nc = base.nx, base.nu, base.nc
+    a = {k: v[0].copy() for k, v in base.arrays.items()}
+    Q = a["Q"].reshape(N + 1, nx, nx)
+    R = a["R"].reshape(N + 1, nu, nu)
+    S = a["S"].reshape(N + 1, nx, nu)      # column-major (nu x nx): [col(x), row(u)]
+    A = a["A"].reshape(N, nx, nx)          # [col, row]
+    B = a["B"].reshape(N, nu, nx)          # [col(u), row(x)]
+    E = a["E"].reshape(N + 1, nx, nc)      # [col(x), row(k)]
+    L = a["L"].reshape(N + 1, nu, nc)      # [col(u), row(k)]
+    mix = np.eye(nc)
+    for k in range(nc):
+        mix[k, (k + 3) % nc] += 0.30
+        mix[k, (k + 7) % nc] += 0.15
+    for i in range(N + 1):
+        Q[i] *= 1.0 + 0.02 * i
+        R[i] *= 1.0 + 0.01 * i
+        S[i, 3:6, 0:3] = 0.01 * (1 + i % 4) * np.eye(3)
+        rowmix = mix * (1.0 + 0.02 * (i % 5))
+        E[i] = E[i] @ rowmix.T
+        L[i] = L[i] @ rowmix.T
+        if i < N:
+            A[i] += 1e-3 * i * np.diag(np.linspace(-1.0, 1.0, nx))
+            B[i] *= 1.0 + 0.005 * i
+    d = a["d"].reshape(N + 1, nc)
+    for i in range(N + 1):
+        d[i] = (mix * (1.0 + 0.02 * (i % 5))) @ d[i]
+    p = synthetic_mpc_batch(batch, first_id=first_id, seed=seed, N=N)
+    for k in _MPC_SEQ:
+        if k != "x0":
+            p.arrays[k] = np.ascontiguousarray(np.broadcast_to(a[k], (batch, a[k].shape[0])))
     return p
 
 

@@ -7,7 +7,7 @@ timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1
 tail -n 5 $O/pytest.txt
 python bench.py --cpu-sample 0 > $O/bench.json 2> $O/bench.err
 python bench.py --cpu-sample 0 --pipeline 1 --steps 6 > $O/bench_serial.json 2>> $O/bench.err
-FBSTAB_HIP_LDS_PAD_BYTES=40000 python bench.py --cpu-sample 0 > $O/bench_half_occupancy.json 2>> $O/bench.err
+
 FBSTAB_HIP_LIB=fbstab_amd/var_clock.so python tools/stamp_report.py 8192 > $O/clock_8192.txt 2>&1
 FBSTAB_HIP_LIB=fbstab_amd/var_clock.so python tools/stamp_report.py 4 > $O/clock_4.txt 2>&1
 python - <<PY

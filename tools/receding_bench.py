@@ -17,7 +17,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from fbstab_amd import fixtures as fx, hip_api, receding_horizon as rh  # noqa: E402
+from fbstab_amd import hip_api, receding_horizon as rh  # noqa: E402
+from tools import fixtures as fx  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 20

@@ -9,7 +9,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from fbstab_amd import fixtures as fx, hip_api  # noqa: E402
+from fbstab_amd import hip_api
+from tools import fixtures as fx  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 p = fx.synthetic_mpc_batch(B)
