@@ -45,13 +45,23 @@ struct DenseLayout {
   // k_global != 0: K lives in global scratch (k_doubles per workgroup), not at o_k
   int k_global;
   long k_doubles;
+  // wave != 0 (nz + nl <= 64, K in LDS): the factorisation and the substitutions run
+  // on ONE wavefront with the matrix rows in registers (ldlt_rows) - the first
+  // wavefront of the workgroup; the others wait at a barrier.  The K region then
+  // also holds the multipliers (nk per pivot); one row buffer and the per-row
+  // pivot bookkeeping sit behind it.
+  int wave, o_rowbuf, o_dpiv, o_ord;
 
 #if !defined(FB_HOSTSIM)
   __host__ __device__
 #endif
   void init(int nz_, int nl_, int nv_, int nthreads) {
+    wave = nz_ + nl_ <= 64;
     carve(nz_, nl_, nv_, nthreads, 0);
-    if ((long)lds_doubles * 8 > 160 * 1024 || k_doubles > (1L << 30)) carve(nz_, nl_, nv_, nthreads, 1);
+    if ((long)lds_doubles * 8 > 160 * 1024 || k_doubles > (1L << 30)) {
+      wave = 0;
+      carve(nz_, nl_, nv_, nthreads, 1);
+    }
   }
 
 #if !defined(FB_HOSTSIM)
@@ -63,7 +73,13 @@ struct DenseLayout {
     k_global = kg;
     long s = 0;
     o_k = 0;
-    if (!k_global) s += k_doubles;
+    o_rowbuf = o_dpiv = o_ord = 0;
+    if (!k_global) s += k_doubles;  // (wave: the multipliers of step k at k * nk + row)
+    if (wave) {
+      o_rowbuf = s; s += 64;
+      o_dpiv = s; s += 64;
+      o_ord = s; s += 34;  // 64 ints and the factorisation's verdict
+    }
     o_rhs = s; s += nk;
     o_z = s; s += nz;  o_l = s; s += nl;  o_v = s; s += nv;  o_y = s; s += nv;
     o_zb = s; s += nz; o_lb = s; s += nl; o_vb = s; s += nv; o_yb = s; s += nv;
@@ -244,12 +260,169 @@ struct DenseProblem {
   }
   FB_DEV bool ldlt(const C& c) const {
 #if !defined(FB_HOSTSIM)
+    if constexpr (!KGLOBAL) {
+      if (lay.wave) {
+        // (the verdict travels through LDS: the other wavefronts wait at the barrier)
+        FB_LDS int* okw = (FB_LDS int*)(lds + lay.o_ord) + 64;
+        on_first_wave(c, [&](const auto& w) {
+          const bool ok = ldlt_rows(w);
+          if (w.tid == 0) *okw = ok ? 1 : 0;
+          w.sync();
+        });
+        return *okw != 0;
+      }
+    }
     if (!KGLOBAL && C::nt > 64 && lay.nk <= 64) return ldlt_fused(c);
 #endif
     // (running the whole factorisation on one wavefront was measured too: 27.3 ms
     // against 23.3 on config 2 - the trailing update wants the four of them)
     return ldlt_impl(c);
   }
+
+#if !defined(FB_HOSTSIM)
+  // Pivoted LDL' for n <= 64 on ONE wavefront with the matrix in registers: lane t
+  // holds row t of the (full, symmetric) trailing matrix, Kr[j] = K[t][j].  Same
+  // pivot rule as Eigen::LDLT (largest |diagonal| of what is left, the first maximum
+  // wins), but nothing is swapped: eliminated rows and columns simply drop out of
+  // the pivot search, and the elimination order is kept as a list (perm[k] = row
+  // eliminated at step k).  A step is: the pivot row goes to LDS once (so that every
+  // lane can fetch "its" entry of it, the multiplier column), then every lane updates
+  // its whole row with the pivot row broadcast through v_readlane into scalar
+  // registers - no barrier, no LDS round trip per column.  The multipliers of step k
+  // are stored at Lm[n k + t] for the substitutions (ldlt_solve_rows); the tracked
+  // diagonal feeds the next search.  dense_cholesky_solver.cc:52-79 calls
+  // Eigen::LDLT::compute: right-looking here, left-looking there - the same
+  // factorisation up to rounding.
+  // a[p] for a wavefront-uniform p: a tree of scalar branches ends in one move (the
+  // array lives in registers, which cannot be indexed at run time)
+  template <int LO, int HI>
+  static FB_DEV double pick(const double (&a)[64], int p) {
+    if constexpr (HI - LO == 1) {
+      return a[LO];
+    } else {
+      constexpr int MID = (LO + HI) / 2;
+      return p < MID ? pick<LO, MID>(a, p) : pick<MID, HI>(a, p);
+    }
+  }
+  FB_DEV bool ldlt_rows(const Ctx<64>& c) const {
+    const int n = lay.nk, t = c.tid;
+    const bool in = t < n;
+    double Kr[64];
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      const int jj = j < n ? j : 0, tt = in ? t : 0;
+      const double a = jj <= tt ? K[tt + jj * n] : K[jj + tt * n];  // lower triangle is what was assembled
+      Kr[j] = (in && j < n) ? a : 0.0;
+    }
+    double dg = in ? K[t + t * n] : 0.0;
+    c.sync();  // K has been read: its region now takes the multipliers
+    lds_ptr Lm = lds + lay.o_k;
+    lds_ptr rowbuf = lds + lay.o_rowbuf;
+    bool alive = in;
+    int ord = 64;       // step at which this row was eliminated
+    double dpiv = 0.0;  // its pivot
+    bool found_zero_pivot = false;
+    for (int k = 0; k < n; k++) {
+      double best = alive ? fabs(dg) : -1.0;
+      int p = alive ? t : 64;
+      C::wave_argmax_first(best, p);
+      p = __builtin_amdgcn_readfirstlane(p);
+      const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dg), p),
+                                        __builtin_amdgcn_readlane(__double2loint(dg), p));
+      if (t == 0) perm[k] = p;
+      const bool valid = fabs(d) > 0.0;
+      if (found_zero_pivot && valid) return false;
+      if (!valid) found_zero_pivot = true;
+      typedef double dbl2 __attribute__((ext_vector_type(2)));
+      if (t == p) {
+        // the pivot row goes to LDS once: every lane fetches "its" entry of it (the
+        // multiplier column, by symmetry) and reads the row back as broadcasts
+#pragma unroll
+        for (int j = 0; j < 64; j += 2) {
+          dbl2 v2 = {Kr[j], Kr[j + 1]};
+          *reinterpret_cast<FB_LDS dbl2*>(rowbuf + j) = v2;
+        }
+        alive = false;
+        ord = k;
+        dpiv = d;
+      }
+      c.sync();
+      const double colp = rowbuf[t];  // K[p][t], for K[t][p]
+      const double l = (alive && valid) ? colp * (1.0 / d) : 0.0;
+      if (in) Lm[n * k + t] = l;
+      if (valid) {
+        const double nl_ = -l;
+#pragma unroll
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+          dbl2 sj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) sj[u] = *reinterpret_cast<FB_LDS const dbl2*>(rowbuf + j0 + 2 * u);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            Kr[j0 + 2 * u] = fma(nl_, sj[u][0], Kr[j0 + 2 * u]);
+            Kr[j0 + 2 * u + 1] = fma(nl_, sj[u][1], Kr[j0 + 2 * u + 1]);
+          }
+        }
+        dg = fma(nl_, colp, dg);
+      }
+      c.sync();  // rowbuf is rewritten by the next pivot
+    }
+    (lds + lay.o_dpiv)[t] = dpiv;
+    ((FB_LDS int*)(lds + lay.o_ord))[t] = ord;
+    c.sync();
+    return true;
+  }
+
+  // rhs <- K^{-1} rhs with the factors of ldlt_rows (P' L^{-T} D^{+} L^{-1} P of
+  // dense_cholesky_solver.cc:112 with the permutation implicit in the elimination
+  // order).  Lane t owns entry t of the right-hand side throughout.
+  FB_DEV void ldlt_solve_rows(const Ctx<64>& c) const {
+    const int n = lay.nk, t = c.tid;
+    const bool in = t < n;
+    lds_ptr Lm = lds + lay.o_k;
+    const double dpiv = (lds + lay.o_dpiv)[t];
+    const int ord = ((FB_LDS int*)(lds + lay.o_ord))[t];
+    double x = in ? rhs[t] : 0.0;
+    // L y = b: step k hands the entry of the row eliminated at step k to all later rows
+    for (int k0 = 0; k0 < n - 1; k0 += 8) {
+      double lk[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) lk[u] = (in && k0 + u < n - 1) ? Lm[n * (k0 + u) + t] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + u < n ? k0 + u : n - 1;
+        const int p = __builtin_amdgcn_readfirstlane(perm[k]);
+        const double xk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), p),
+                                           __builtin_amdgcn_readlane(__double2loint(x), p));
+        x = fma(-lk[u], xk, x);  // the multiplier is 0 for rows eliminated up to step k
+      }
+    }
+    x = (in && fabs(dpiv) > DBL_MIN) ? x / dpiv : 0.0;  // pseudo-inverse of D
+    // L' w = y: the entry of the row eliminated at step k goes to the rows eliminated
+    // before it, each of which reads the multiplier it gave that row at its own step
+    for (int k0 = n - 1; k0 > 0; k0 -= 8) {
+      double lk[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 - u > 0 ? k0 - u : 0;
+        const int p = __builtin_amdgcn_readfirstlane(perm[k]);
+        lk[u] = (k0 - u > 0 && ord < k) ? Lm[n * ord + p] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 - u > 0 ? k0 - u : 0;
+        const int p = __builtin_amdgcn_readfirstlane(perm[k]);
+        const double xk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), p),
+                                           __builtin_amdgcn_readlane(__double2loint(x), p));
+        x = fma(-lk[u], xk, x);
+      }
+    }
+    c.sync();
+    if (in) rhs[t] = x;
+    c.sync();
+  }
+#endif
 
 #if !defined(FB_HOSTSIM)
   // ldlt_impl for n <= 64 on a multi-wavefront workgroup with its phases fused:
@@ -322,6 +495,9 @@ struct DenseProblem {
     on_first_wave(c, [&](const auto& w) {
       typedef typename std::remove_cv<typename std::remove_reference<decltype(w)>::type>::type W;
       if constexpr (W::nt == 64) {
+        if constexpr (!KGLOBAL) {
+          if (lay.wave) { ldlt_solve_rows(w); return; }
+        }
         if (lay.nk <= 64) ldlt_solve_wave(w);
         else ldlt_solve_impl(w);
       } else {
@@ -519,7 +695,7 @@ struct DenseProblem {
     // K = [H + sigma I + A'Gamma A  .; G  -sigma I] (lower; :52-69) and the
     // eliminated right-hand side (:98-104).
 #if !defined(FB_HOSTSIM) && !defined(FB_DENSE_NO_MFMA)
-    if (lay.a_lds && C::nt == 256 && nz <= 64 && (nv & 3) == 0) {
+    if (lay.a_lds && (C::nt & 63) == 0 && nz <= 64 && (nv & 3) == 0) {
       // E = H + sigma I + A' Gamma A on the matrix cores: one QP per workgroup, so
       // v_mfma_f64_16x16x4 fits - the 16x16 tiles of the lower triangle of the
       // (padded) 64x64 product are dealt to the four wavefronts, each tile
@@ -532,7 +708,7 @@ struct DenseProblem {
       const int kq = lane >> 4, ij = lane & 15;
       const int nt16 = (nz + 15) >> 4;
       const int ntiles = nt16 * (nt16 + 1) / 2;
-      for (int t0 = wave; t0 < ntiles; t0 += 4) {
+      for (int t0 = wave; t0 < ntiles; t0 += C::nt / 64) {
         // tile index -> (I, J), I >= J (row-major over the lower triangle)
         int I = 0, rem = t0;
         while (rem > I) { rem -= I + 1; I++; }

@@ -255,6 +255,73 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
 #endif
 }
 
+// Closed-loop step of the receding-horizon sweep (fbstab_hip_mpc_receding_sweep):
+// one thread per trajectory.  u0 = first input of the solution just computed,
+// x0 <- A x0 + B u0 (the SimulationInputs of the reference's generator,
+// fbstab/test/ocp_generator.h:31-38); (z, l, v) stay where they are and are the
+// next step's initial guess, unshifted (the reference has no shift logic;
+// fbstab_algorithm-impl.h:140 starts from whatever the caller's Variable holds).
+// With `retire`, a trajectory whose solve did not end in SUCCESS is parked at the
+// origin for the rest of the sweep (x0 = 0, guess 0), as a controller's fallback
+// would: its QP is then solved by the zero vector in one proximal iteration.
+// stats[step] = {sum of Newton iterations, solves that ended in SUCCESS,
+// trajectories retired so far, largest Newton count}.
+__global__ void fbstab_receding_plant_kernel(int batch, int nx, int nu, int nz, int nl, int nv, const double* A,
+                                             long long sA, const double* B, long long sB, double* x0, long long sx0,
+                                             VarBatchArgs x, const fbstab_solver_out_t* out, int* retired,
+                                             int retire, double* u_log, unsigned long long* stats) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = q < batch;
+  fbstab_solver_out_t o;
+  o.eflag = FBSTAB_SUCCESS;
+  o.newton_iters = 0;
+  if (live) o = out[q];
+  double* z = x.base[0] + (live ? q : 0) * x.stride[0];
+  double* xs = x0 + (live ? q : 0) * sx0;
+  bool gone = live && retired[q] != 0;
+  if (live && retire && !gone && o.eflag != FBSTAB_SUCCESS) {
+    gone = true;
+    retired[q] = 1;
+    for (int i = 0; i < nz; i++) z[i] = 0.0;
+    double* l = x.base[1] + q * x.stride[1];
+    double* v = x.base[2] + q * x.stride[2];
+    for (int i = 0; i < nl; i++) l[i] = 0.0;
+    for (int i = 0; i < nv; i++) v[i] = 0.0;
+  }
+  {
+    // statistics: one set of atomics per wavefront (thousands of same-address atomics
+    // a step would cost more than the solve)
+    int ns = live ? o.newton_iters : 0, ok = (live && o.eflag == FBSTAB_SUCCESS) ? 1 : 0, gn = gone ? 1 : 0, mx = ns;
+    for (int m = 32; m >= 1; m >>= 1) {
+      ns += __shfl_xor(ns, m, 64);
+      ok += __shfl_xor(ok, m, 64);
+      gn += __shfl_xor(gn, m, 64);
+      const int om = __shfl_xor(mx, m, 64);
+      mx = om > mx ? om : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&stats[0], (unsigned long long)ns);
+      atomicAdd(&stats[1], (unsigned long long)ok);
+      atomicAdd(&stats[2], (unsigned long long)gn);
+      atomicMax(&stats[3], (unsigned long long)mx);
+    }
+  }
+  if (!live) return;
+  double u[8], xn[64];
+  for (int j = 0; j < nu && j < 8; j++) u[j] = gone ? 0.0 : z[nx + j];
+  if (u_log)
+    for (int j = 0; j < nu && j < 8; j++) u_log[(long long)q * nu + j] = u[j];
+  const double* Aq = A + q * sA;
+  const double* Bq = B + q * sB;
+  for (int r = 0; r < nx; r++) {
+    double acc = 0.0;
+    for (int c = 0; c < nx; c++) acc = fma(Aq[r + c * nx], xs[c], acc);
+    for (int j = 0; j < nu && j < 8; j++) acc = fma(Bq[r + j * nx], u[j], acc);
+    xn[r] = gone ? 0.0 : acc;
+  }
+  for (int r = 0; r < nx; r++) xs[r] = xn[r];
+}
+
 // KGLOBAL: K in a per-workgroup global scratch (fb_dense.h); the argument is
 // empty for the LDS instance, like the trace buffer for the untraced ones.
 template <bool KGLOBAL>
@@ -268,7 +335,7 @@ struct KScratchArg<true> {
 };
 
 template <int NT, bool TRACE = false, bool KGLOBAL = false>
-__global__ __launch_bounds__(NT) void fbstab_dense_kernel(DenseLayout lay, DenseBatchArgs data,
+__global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_kernel(DenseLayout lay, DenseBatchArgs data,
                                                           VarBatchArgs x,
                                                           fbstab_solver_out_t* out,
                                                           fbstab_options_t opts, int* counter,
@@ -337,6 +404,12 @@ struct SolverBase {
   double* d_var[4] = {nullptr, nullptr, nullptr, nullptr};
   long long var_len[4] = {0, 0, 0, 0};
   fbstab_solver_out_t* d_out = nullptr;
+  fbstab_solver_out_t* d_out_only = nullptr;  // FBSTAB_HIP_OUT_ON_HOST: device side of the records
+
+  int ensure_out() {
+    if (!d_out_only) HIP_TRY(hipMalloc(&d_out_only, sizeof(fbstab_solver_out_t) * (size_t)max_batch));
+    return FBSTAB_HIP_OK;
+  }
 
   int release() {
     (void)hipSetDevice(device);
@@ -345,6 +418,7 @@ struct SolverBase {
     for (int i = 0; i < 4; i++)
       if (d_var[i]) (void)hipFree(d_var[i]);
     if (d_out) (void)hipFree(d_out);
+    if (d_out_only) (void)hipFree(d_out_only);
     if (scratch) (void)hipFree(scratch);
     if (counter) (void)hipFree(counter);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -687,9 +761,15 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
   MpcBatchArgs a;
   VarBatchArgs v;
   fbstab_solver_out_t* d_out = out;
+  const bool out_host = dev_ptrs && (flags & FBSTAB_HIP_OUT_ON_HOST);
   if (dev_ptrs) {
     for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { a.base[i] = data->base[i]; a.stride[i] = data->stride[i]; }
     for (int i = 0; i < 4; i++) { v.base[i] = x->base[i]; v.stride[i] = x->stride[i]; }
+    if (out_host) {
+      rc = h->ensure_out();
+      if (rc != FBSTAB_HIP_OK) return rc;
+      d_out = h->d_out_only;
+    }
   } else {
     rc = h->ensure_staging();
     if (rc != FBSTAB_HIP_OK) return rc;
@@ -756,6 +836,11 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     HIP_TRY(hipStreamSynchronize(s));
     const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     for (int i = 0; i < batch; i++) out[i].solve_time = dt;
+  } else if (out_host) {
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(fbstab_solver_out_t) * batch, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    for (int i = 0; i < batch; i++) out[i].solve_time = dt;
   } else if (!(flags & FBSTAB_HIP_ASYNC)) {
     HIP_TRY(hipStreamSynchronize(s));
   }
@@ -778,6 +863,61 @@ int fbstab_hip_mpc_solve_traced(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
   rc = mpc_solve_impl(h, 1, data, x, out, FBSTAB_HIP_HOST_POINTERS, nullptr, tb.dev());
   if (rc != FBSTAB_HIP_OK) return rc;
   return tb.close(trace, capacity, count);
+}
+
+// BASELINE configs[4]: `steps` closed-loop steps without a host round trip in
+// between - solve, plant step, solve, ... queued on one stream.
+int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
+                                  const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                  const fbstab_receding_plant_t* plant, int steps, int retire,
+                                  double* u_log, unsigned long long* stats, float* kernel_ms, void* stream) {
+  int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
+  if (rc != FBSTAB_HIP_OK) return rc;
+  if (!plant || !plant->A || !plant->B || steps < 0)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "plant matrices and a non-negative step count are required");
+  if (h->lay.nx > 64 || h->lay.nu > 8)
+    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "receding sweep: nx <= 64 and nu <= 8");
+  if (batch == 0 || steps == 0) return FBSTAB_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  DevBuf d_ret, d_stats;
+  HIP_TRY(hipMalloc(&d_ret.p, sizeof(int) * (size_t)batch));
+  HIP_TRY(hipMalloc(&d_stats.p, sizeof(unsigned long long) * 4 * (size_t)steps));
+  HIP_TRY(hipMemsetAsync(d_ret.p, 0, sizeof(int) * (size_t)batch, s));
+  HIP_TRY(hipMemsetAsync(d_stats.p, 0, sizeof(unsigned long long) * 4 * (size_t)steps, s));
+  std::vector<hipEvent_t> ev;
+  struct EvGuard {
+    std::vector<hipEvent_t>& e;
+    ~EvGuard() { for (hipEvent_t x : e) (void)hipEventDestroy(x); }
+  } guard{ev};
+  if (kernel_ms) {
+    ev.resize(2 * (size_t)steps, nullptr);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  }
+  VarBatchArgs v;
+  for (int i = 0; i < 4; i++) { v.base[i] = x->base[i]; v.stride[i] = x->stride[i]; }
+  const fbk::MpcLayout& L = h->lay;
+  double* x0 = const_cast<double*>(data->base[FBSTAB_MPC_x0]);
+  const int flags = FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_ASYNC | FBSTAB_HIP_KEEP_MATRICES;
+  h->kept_batch = -1;  // the first step builds the matrix copies
+  for (int k = 0; k < steps; k++) {
+    if (kernel_ms) HIP_TRY(hipEventRecord(ev[2 * k], s));
+    rc = mpc_solve_impl(h, batch, data, x, out, flags, s, nullptr);
+    if (rc != FBSTAB_HIP_OK) return rc;
+    if (kernel_ms) HIP_TRY(hipEventRecord(ev[2 * k + 1], s));
+    hipLaunchKernelGGL(fbstab_receding_plant_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, batch, L.nx, L.nu,
+                       L.nz, L.nl, L.nv, plant->A, plant->stride_A, plant->B, plant->stride_B, x0,
+                       data->stride[FBSTAB_MPC_x0], v, out, static_cast<int*>(d_ret.p), retire,
+                       u_log ? u_log + (long long)k * batch * L.nu : nullptr,
+                       static_cast<unsigned long long*>(d_stats.p) + 4 * k);
+  }
+  HIP_TRY(hipGetLastError());
+  if (stats)
+    HIP_TRY(hipMemcpyAsync(stats, d_stats.p, sizeof(unsigned long long) * 4 * (size_t)steps, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (kernel_ms)
+    for (int k = 0; k < steps; k++) HIP_TRY(hipEventElapsedTime(&kernel_ms[k], ev[2 * k], ev[2 * k + 1]));
+  return FBSTAB_HIP_OK;
 }
 
 // Diagnostics for the tests: one Newton step of the device path at (x, xbar,
@@ -874,8 +1014,20 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   if (max_batch < 1) return fail(FBSTAB_HIP_ERR_ARGUMENT, "max_batch must be positive");
   fbstab_dense_solver* s = new (std::nothrow) fbstab_dense_solver();
   if (!s) return fail(FBSTAB_HIP_ERR_DEVICE, "out of host memory");
+  // Four wavefronts per QP; for nz + nl <= 64 the factorisation itself runs on the
+  // first of them with the KKT matrix in registers (fb_dense.h: ldlt_rows).
+  // FBSTAB_HIP_DENSE_THREADS=64 selects one wavefront per QP for everything
+  // (measured slower: the matrix-vector phases want the four of them).
   s->threads = kDenseThreads;
+  {
+    const char* th = getenv("FBSTAB_HIP_DENSE_THREADS");
+    if (th && atoi(th) == 64 && nz + nl <= 64) s->threads = 64;
+  }
   s->lay.init(nz, nl, nv, s->threads);
+  if (s->threads == 64 && (s->lay.k_global || !s->lay.a_lds)) {  // does not fit that way
+    s->threads = kDenseThreads;
+    s->lay.init(nz, nl, nv, s->threads);
+  }
   s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
   if (s->lds_bytes > kLdsLimitBytes) {
     delete s;
@@ -883,7 +1035,8 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  const void* kern = s->lay.k_global
+  const void* kern = s->threads == 64 ? reinterpret_cast<const void*>(fbstab_dense_kernel<64>)
+                     : s->lay.k_global
                          ? reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads, false, true>)
                          : reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads>);
   hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
@@ -954,9 +1107,15 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
   DenseBatchArgs a;
   VarBatchArgs v;
   fbstab_solver_out_t* d_out = out;
+  const bool out_host = dev_ptrs && (flags & FBSTAB_HIP_OUT_ON_HOST);
   if (dev_ptrs) {
     for (int i = 0; i < FBSTAB_DENSE_NARR; i++) { a.base[i] = data->base[i]; a.stride[i] = data->stride[i]; }
     for (int i = 0; i < 4; i++) { v.base[i] = x->base[i]; v.stride[i] = x->stride[i]; }
+    if (out_host) {
+      rc = h->ensure_out();
+      if (rc != FBSTAB_HIP_OK) return rc;
+      d_out = h->d_out_only;
+    }
   } else {
     rc = h->ensure_staging();
     if (rc != FBSTAB_HIP_OK) return rc;
@@ -991,11 +1150,20 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
     hipLaunchKernelGGL(kern, dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a, v, d_out, h->opts,
                        h->counter, 1, TraceArg<true>{d_trace}, KScratchArg<true>{h->scratch});
   } else if (d_trace) {
+    // the traced instance is the four-wavefront kernel with a layout of its own
+    fbk::DenseLayout tl;
+    tl.init(h->lay.nz, h->lay.nl, h->lay.nv, kDenseThreads);
+    const int tlds = tl.lds_doubles * (int)sizeof(double);
+    if (tl.k_global || tlds > kLdsLimitBytes)
+      return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "traced dense solve: layout does not fit");
     auto kern = fbstab_dense_kernel<kDenseThreads, true>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a, v, d_out, h->opts,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, tlds));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kDenseThreads), tlds, s, tl, a, v, d_out, h->opts,
                        h->counter, 1, TraceArg<true>{d_trace}, KScratchArg<false>());
+  } else if (h->threads == 64) {
+    hipLaunchKernelGGL(fbstab_dense_kernel<64>, dim3(grid), dim3(64), h->lds_bytes, s, h->lay, a, v, d_out,
+                       h->opts, h->counter, batch, TraceArg<false>(), KScratchArg<false>());
   } else if (h->lay.k_global) {
     hipLaunchKernelGGL((fbstab_dense_kernel<kDenseThreads, false, true>), dim3(grid), dim3(h->threads),
                        h->lds_bytes, s, h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>(),
@@ -1015,6 +1183,11 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
       if (rc != FBSTAB_HIP_OK) return rc;
     }
     HIP_TRY(hipMemcpyAsync(out, h->d_out, sizeof(fbstab_solver_out_t) * batch, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    for (int i = 0; i < batch; i++) out[i].solve_time = dt;
+  } else if (out_host) {
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(fbstab_solver_out_t) * batch, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     for (int i = 0; i < batch; i++) out[i].solve_time = dt;

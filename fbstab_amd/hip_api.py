@@ -81,6 +81,10 @@ class _VarBatch(C.Structure):
     _fields_ = [("base", C.c_void_p * 4), ("stride", C.c_longlong * 4)]
 
 
+class _Plant(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("stride_A", C.c_longlong), ("stride_B", C.c_longlong)]
+
+
 _lib = None
 
 
@@ -116,6 +120,9 @@ def load_library() -> C.CDLL:
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.fbstab_hip_mpc_kernel_name.restype = C.c_char_p
     lib.fbstab_hip_mpc_kernel_name.argtypes = [C.c_void_p]
+    lib.fbstab_hip_mpc_receding_sweep.argtypes = [
+        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
     lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
     _lib = lib
@@ -126,7 +133,7 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_last_error", "fbstab_hip_device_count",
     "fbstab_hip_mpc_create", "fbstab_hip_mpc_destroy", "fbstab_hip_mpc_set_options",
     "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch",
-    "fbstab_hip_mpc_solve_traced",
+    "fbstab_hip_mpc_solve_traced", "fbstab_hip_mpc_receding_sweep",
     "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_kernel_name",
     "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
@@ -323,6 +330,50 @@ class FBstabMpcBatch(_SolverBase):
         display returned as records (fbstab_hip_mpc_solve_traced)."""
         return _solve_traced(self, _MpcBatch(), MPC_SEQ, self.seq_len, data,
                              (self.nz, self.nl, self.nv, self.nv), z, l, v, y, capacity)
+
+    def RecedingSweep(self, data, z, l, v, y, A, B, steps: int, retire: bool = True,
+                      log_inputs: bool = False, stream: int = 0):
+        """fbstab_hip_mpc_receding_sweep: ``steps`` warm-started closed-loop steps on
+        the device (torch CUDA tensors; ``data["x0"]`` is advanced in place, ``z, l,
+        v, y`` hold the last solution).  ``A``/``B``: the simulation model as
+        ``(nx, nx)``/``(nx, nu)`` numpy arrays shared by all trajectories.  Returns
+        ``dict(out, stats, kernel_ms[, u])`` with ``stats`` a structured array per
+        step (newton_sum, success, retired_total, newton_max)."""
+        import torch
+        b = _MpcBatch()
+        B_ = None
+        for i, (k, n) in enumerate(zip(MPC_SEQ, self.seq_len)):
+            p, st, d = _ptr_stride(data[k], n)
+            assert d, "device tensors only"
+            b.base[i], b.stride[i] = p, st
+            B_ = data[k].shape[0] if B_ is None else B_
+        vb = _VarBatch()
+        for i, (a, n) in enumerate(zip((z, l, v, y), (self.nz, self.nl, self.nv, self.nv))):
+            p, st, d = _ptr_stride(a, n)
+            assert d and a.shape[0] == B_
+            vb.base[i], vb.stride[i] = p, st
+        dev = z.device
+        Ad = torch.from_numpy(np.asfortranarray(A).T.copy().reshape(-1)).to(dev)   # column-major image
+        Bd = torch.from_numpy(np.asfortranarray(B).T.copy().reshape(-1)).to(dev)
+        plant = _Plant(Ad.data_ptr(), Bd.data_ptr(), 0, 0)
+        out = torch.zeros((B_, 40), dtype=torch.uint8, device=dev)
+        stats = np.zeros((steps, 4), dtype=np.uint64)
+        kms = np.zeros(steps, dtype=np.float32)
+        u = torch.zeros((steps, B_, self.nu), dtype=torch.float64, device=dev) if log_inputs else None
+        if not stream:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(self._lib, self._lib.fbstab_hip_mpc_receding_sweep(
+            self._h, B_, C.byref(b), C.byref(vb), out.data_ptr(), C.byref(plant), steps, 1 if retire else 0,
+            u.data_ptr() if u is not None else None, stats.ctypes.data, kms.ctypes.data,
+            C.c_void_p(stream) if stream else None))
+        st = np.zeros(steps, dtype=[("newton_sum", np.int64), ("success", np.int64),
+                                    ("retired_total", np.int64), ("newton_max", np.int64)])
+        for j, n in enumerate(st.dtype.names):
+            st[n] = stats[:, j].astype(np.int64)
+        r = dict(out=out, stats=st, kernel_ms=kms)
+        if u is not None:
+            r["u"] = u
+        return r
 
 
     def debug_newton(self, data, z, l, v, zb, lb, vb):

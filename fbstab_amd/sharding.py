@@ -4,8 +4,8 @@ The path shards embarrassingly: QPs are independent (the reference solver
 objects share nothing between Solve calls, fbstab_mpc.cc:75-86), so rank g of W
 owns the contiguous block of global instance ids ``[g*B, (g+1)*B)`` and there is
 no collective on the data path.  The only exchange is ONE gather of the
-solutions ``(z,l,v,y)`` and ``SolverOut`` records to rank 0 at the end of a
-batch (RCCL over xGMI when the tensors live on GPUs; the same code runs over
+solutions ``(z,l,v,y)`` and ``SolverOut`` records, fused into one record per QP,
+to rank 0 at the end of a batch (RCCL over xGMI when the tensors live on GPUs; the same code runs over
 gloo on CPU tensors in the tests).
 """
 from __future__ import annotations
@@ -21,23 +21,42 @@ def shard_range(rank: int, world: int, per_rank_batch: int) -> Tuple[int, int]:
     return rank * per_rank_batch, (rank + 1) * per_rank_batch
 
 
-def gather_solutions(x, out, dst: int = 0, gather_x: Optional[List] = None,
-                     gather_out: Optional[List] = None):
-    """One gather of this rank's solution records ``x`` (``(B, nz+nl+2nv)``
-    float64) and ``out`` (``(B, 40)`` uint8 SolverOut records) to ``dst``.
-    Returns ``(X, O)`` stacked in global instance order on ``dst``, ``(None,
-    None)`` elsewhere.  ``gather_x/out`` may supply preallocated receive lists."""
+OUT_DOUBLES = 5   # one 40-byte SolverOut record (include/fbstab_types.h) as float64 columns
+
+
+def unpack_out(record):
+    """SolverOut records (numpy structured array) from the last ``OUT_DOUBLES``
+    float64 columns of gathered solution records."""
+    import numpy as np
+    from fbstab_amd.hip_api import OUT_DTYPE
+    tail = record[:, -OUT_DOUBLES:].contiguous().cpu().numpy()
+    return np.frombuffer(tail.tobytes(), dtype=OUT_DTYPE).copy()
+
+
+def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[List] = None):
+    """ONE gather of this rank's results to ``dst``: the solutions ``x``
+    (``(B, nz+nl+2nv)`` float64) and the ``out`` records (``(B, 40)`` uint8
+    SolverOut) travel side by side in one ``(B, nvar + 5)`` float64 record per QP.
+    ``record``: optional preallocated record buffer whose first columns ARE ``x``
+    (then only the 40 bytes per QP of ``out`` are copied); ``gather_list``:
+    optional preallocated receive buffers on ``dst``.  Returns ``(X, O)`` stacked in
+    global instance order on ``dst`` (``O`` as uint8 ``(W*B, 40)``), ``(None,
+    None)`` elsewhere."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
     rank = dist.get_rank()
+    nvar = x.shape[1]
+    if record is None:
+        record = torch.empty((x.shape[0], nvar + OUT_DOUBLES), dtype=x.dtype, device=x.device)
+        record[:, :nvar] = x
+    record[:, nvar:] = out.view(torch.float64).view(-1, OUT_DOUBLES)
     if rank == dst:
-        gather_x = gather_x or [torch.empty_like(x) for _ in range(world)]
-        gather_out = gather_out or [torch.empty_like(out) for _ in range(world)]
+        gather_list = gather_list or [torch.empty_like(record) for _ in range(world)]
     else:
-        gather_x = gather_out = None
-    dist.gather(x, gather_x, dst=dst)
-    dist.gather(out, gather_out, dst=dst)
+        gather_list = None
+    dist.gather(record, gather_list, dst=dst)
     if rank != dst:
         return None, None
-    return torch.cat(gather_x, dim=0), torch.cat(gather_out, dim=0)
+    full = torch.cat(gather_list, dim=0)
+    return full[:, :nvar], full[:, nvar:].contiguous().view(torch.uint8).view(-1, 40)

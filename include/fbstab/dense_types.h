@@ -18,6 +18,7 @@
 namespace fbstab {
 typedef Eigen::VectorXd VectorXd;
 typedef Eigen::MatrixXd MatrixXd;
+typedef Eigen::Vector4d Vector4d;
 #define FBSTAB_FACADE_HAS_EIGEN 1
 }  // namespace fbstab
 #else
@@ -49,6 +50,20 @@ class VectorXd {
 
  private:
   std::vector<double> d_;
+};
+
+// s = (N, nx, nu, nc) of FBstabMpc(const Eigen::Vector4d&) (fbstab_mpc.h:130, :168)
+class Vector4d {
+ public:
+  Vector4d() { v_[0] = v_[1] = v_[2] = v_[3] = 0.0; }
+  Vector4d(double a, double b, double c, double d) { v_[0] = a; v_[1] = b; v_[2] = c; v_[3] = d; }
+  int size() const { return 4; }
+  double& operator()(int i) { return v_[i]; }
+  double operator()(int i) const { return v_[i]; }
+  const double* data() const { return v_; }
+
+ private:
+  double v_[4];
 };
 
 class MatrixXd {

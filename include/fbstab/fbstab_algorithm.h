@@ -112,11 +112,11 @@ inline SolverOut FromC(const fbstab_solver_out_t& c) {
 
 // The display of the reference (fbstab_algorithm-impl.h:411-541).
 //
-// Display::FINAL (batch path): the summary block with the total residual, which
-// is what SolverOut carries.  Display::ITER / ITER_DETAILED: Solve() runs
-// fbstab_hip_*_solve_traced and PrintTrace() formats the records it returns,
-// line for line as the reference prints them, including the |rz| |rl| |rv|
-// columns of the summary block.
+// Every level above OFF prints the component norms |rz| |rl| |rv| of the residual
+// (FINAL in its summary block, impl:493-541 - the reference's DEFAULT level), which
+// SolverOut does not carry: Solve() then runs fbstab_hip_*_solve_traced and
+// PrintTrace() formats the records it returns, line for line as the reference
+// prints them.  Display::OFF takes the batch kernels.
 inline const char* ExitMessage(ExitFlag e) {
   switch (e) {
     case ExitFlag::SUCCESS: return " Success\n";
@@ -140,17 +140,6 @@ void PrintSummaryHead(const SolverOut& s, const AlgorithmParameters& p, const Ou
   snprintf(buff, 100, "Proximal iterations: %d out of %d\n", s.prox_iters, p.max_prox_iters);
   os.Print(buff);
   snprintf(buff, 100, "Newton iterations: %d out of %d\n", s.newton_iters, p.max_newton_iters);
-  os.Print(buff);
-}
-
-template <class OutStream>
-void PrintFinal(const SolverOut& s, const AlgorithmParameters& p, const OutStream& os) {
-  if (p.display_level < Display::FINAL) return;
-  char buff[100];
-  PrintSummaryHead(s, p, os);
-  snprintf(buff, 100, "%10s  %10s\n", "|r|", "Tolerance");
-  os.Print(buff);
-  snprintf(buff, 100, "%10.4e  %10.4e\n\n", s.residual, p.abs_tol);
   os.Print(buff);
 }
 

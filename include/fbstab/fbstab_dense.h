@@ -27,6 +27,10 @@ class FBstabDense {
   // Non-owning column-major views (the reference uses Eigen::Map).
   struct MatRef {
     MatRef(const double* p, int r, int c) : ptr(p), r_(r), c_(c) {}
+    // from any column-major view with data() / rows() / cols(): Eigen::Map<MatrixXd>
+    template <class M>
+    MatRef(const M& m, decltype(static_cast<void>(m.data()), static_cast<void>(m.rows()), 0) = 0)
+        : ptr(m.data()), r_(static_cast<int>(m.rows())), c_(static_cast<int>(m.cols())) {}
     const double* data() const { return ptr; }
     int rows() const { return r_; }
     int cols() const { return c_; }
@@ -36,6 +40,10 @@ class FBstabDense {
   };
   struct VecRef {
     VecRef(double* p, int n_) : ptr(p), n(n_) {}
+    // from any view with data() / size(): Eigen::Map<VectorXd>
+    template <class V>
+    VecRef(const V& v, decltype(static_cast<void>(v.data()), static_cast<void>(v.size()), 0) = 0)
+        : ptr(const_cast<double*>(v.data())), n(static_cast<int>(v.size())) {}
     double* data() const { return ptr; }
     int size() const { return n; }
     double& operator()(int i) const { return ptr[i]; }
@@ -48,6 +56,11 @@ class FBstabDense {
     ProblemDataRef() = delete;
     ProblemDataRef(const MatRef* H_, const VecRef* f_, const MatRef* G_, const VecRef* h_,
                    const MatRef* A_, const VecRef* b_)
+        : H(*H_), G(*G_), A(*A_), f(*f_), h(*h_), b(*b_) {}
+    // the reference's signature: pointers to Eigen::Map<MatrixXd> / Eigen::Map<VectorXd>
+    // (fbstab_dense.h:69-74), or to any types with the same accessors
+    template <class M, class V>
+    ProblemDataRef(const M* H_, const V* f_, const M* G_, const V* h_, const M* A_, const V* b_)
         : H(*H_), G(*G_), A(*A_), f(*f_), h(*h_), b(*b_) {}
     MatRef H, G, A;
     VecRef f, h, b;
@@ -62,6 +75,9 @@ class FBstabDense {
   struct VariableRef {
     VariableRef() = delete;
     VariableRef(VecRef* z_, VecRef* l_, VecRef* v_, VecRef* y_) : z(*z_), l(*l_), v(*v_), y(*y_) {}
+    // the reference's signature: pointers to Eigen::Map<VectorXd> (fbstab_dense.h:97-100)
+    template <class V>
+    VariableRef(V* z_, V* l_, V* v_, V* y_) : z(*z_), l(*l_), v(*v_), y(*y_) {}
     void fill(double a) { z.fill(a); l.fill(a); v.fill(a); y.fill(a); }
     VecRef z, l, v, y;
   };
@@ -78,6 +94,10 @@ class FBstabDense {
     opts_ = DefaultOptions();
   }
   ~FBstabDense() { fbstab_hip_dense_destroy(h_); }
+
+  // Where the memory behind qp and x lives (see FBstabMpc::SetMemory).
+  enum class Memory { HOST, DEVICE };
+  void SetMemory(Memory m) { memory_ = m; }
 
   // fbstab_dense.h:136-149 (DenseData validation dense_data.h:53-66,
   // ValidateInputs fbstab_dense.h:167-180)
@@ -107,8 +127,17 @@ class FBstabDense {
     v.base[0] = x->z.data(); v.base[1] = x->l.data(); v.base[2] = x->v.data(); v.base[3] = x->y.data();
     v.stride[0] = nz_; v.stride[1] = nl_; v.stride[2] = nv_; v.stride[3] = nv_;
     fbstab_solver_out_t out;
-    if (opts_.display_level >= Display::ITER) {
-      // per-iteration display (impl:411-488): the traced solve returns its lines as records
+    if (memory_ == Memory::DEVICE) {
+      if (opts_.display_level != Display::OFF)
+        throw std::runtime_error("In FBstabDense::Solve: device-resident data is solved with Display::OFF.");
+      if (fbstab_hip_dense_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_OUT_ON_HOST,
+                                       nullptr) != FBSTAB_HIP_OK)
+        throw std::runtime_error(std::string("In FBstabDense::Solve: ") + fbstab_hip_last_error());
+      return detail::FromC(out);
+    }
+    if (opts_.display_level >= Display::FINAL) {
+      // every display level prints component norms (|rz| |rl| |rv|, impl:411-541):
+      // the traced solve returns the lines of the reference's display as records
       std::vector<fbstab_trace_record_t> rec(detail::TraceCapacity(opts_));
       int n = 0;
       if (fbstab_hip_dense_solve_traced(h_, &b, &v, &out, rec.data(), static_cast<int>(rec.size()), &n) !=
@@ -121,9 +150,7 @@ class FBstabDense {
     }
     if (fbstab_hip_dense_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_HOST_POINTERS, nullptr) != FBSTAB_HIP_OK)
       throw std::runtime_error(std::string("In FBstabDense::Solve: ") + fbstab_hip_last_error());
-    SolverOut s = detail::FromC(out);
-    detail::PrintFinal(s, opts_, os);
-    return s;
+    return detail::FromC(out);
   }
   template <class InputData, class InputVariable>
   SolverOut Solve(const InputData& qp, InputVariable* x) {
@@ -143,6 +170,7 @@ class FBstabDense {
  private:
   int nz_, nl_, nv_;
   Options opts_;
+  Memory memory_ = Memory::HOST;
   fbstab_dense_handle_t h_ = nullptr;
 };
 

@@ -40,6 +40,11 @@ class FBstabMpc {
   };
   struct VectorRef {
     VectorRef(double* p, int n_) : ptr(p), n(n_) {}
+    // from anything that views a vector of doubles through data() / size(), the
+    // reference's Eigen::Map<Eigen::VectorXd> in particular (fbstab_mpc.h:139-150)
+    template <class V>
+    VectorRef(V& v, decltype(static_cast<void>(v.data()), static_cast<void>(v.size()), 0) = 0)
+        : ptr(v.data()), n(static_cast<int>(v.size())) {}
     double* data() const { return ptr; }
     int size() const { return n; }
     double& operator()(int i) const { return ptr[i]; }
@@ -68,11 +73,21 @@ class FBstabMpc {
     Variable(int N, int nx, int nu, int nc)
         : z(VectorXd::Zero((N + 1) * (nx + nu))), l(VectorXd::Zero((N + 1) * nx)),
           v(VectorXd::Zero((N + 1) * nc)), y(VectorXd::Zero((N + 1) * nc)) {}
+    // s = (N, nx, nu, nc), sizes carried as doubles like the reference's
+    // Eigen::Vector4d (fbstab_mpc.h:130, fbstab_mpc.cc:45)
+    explicit Variable(const Vector4d& s)
+        : Variable(static_cast<int>(s(0)), static_cast<int>(s(1)), static_cast<int>(s(2)), static_cast<int>(s(3))) {}
     VectorXd z, l, v, y;
   };
-  // fbstab_mpc.h:139-150
+  // fbstab_mpc.h:139-150.  The arguments are views (taken by value like the
+  // reference's Eigen::Map arguments): VectorRef itself, Eigen::Map<VectorXd>, or any
+  // type with data() / size().
   struct VariableRef {
     VariableRef(VectorRef z_, VectorRef l_, VectorRef v_, VectorRef y_) : z(z_), l(l_), v(v_), y(y_) {}
+    template <class V>
+    VariableRef(V z_, V l_, V v_, V y_, decltype(static_cast<void>(z_.data()), 0) = 0)
+        : z(z_.data(), static_cast<int>(z_.size())), l(l_.data(), static_cast<int>(l_.size())),
+          v(v_.data(), static_cast<int>(v_.size())), y(y_.data(), static_cast<int>(y_.size())) {}
     void fill(double a) { z.fill(a); l.fill(a); v.fill(a); y.fill(a); }
     VectorRef z, l, v, y;
   };
@@ -90,7 +105,19 @@ class FBstabMpc {
       throw std::runtime_error(std::string("In FBstabMpc::FBstabMpc: ") + fbstab_hip_last_error());
     opts_ = DefaultOptions();
   }
+  // s = (N, nx, nu, nc) (fbstab_mpc.h:168, fbstab_mpc.cc:91)
+  explicit FBstabMpc(const Vector4d& s, int device = 0)
+      : FBstabMpc(static_cast<int>(s(0)), static_cast<int>(s(1)), static_cast<int>(s(2)), static_cast<int>(s(3)),
+                  device) {}
   ~FBstabMpc() { fbstab_hip_mpc_destroy(h_); }
+
+  // Where the memory behind qp and x lives.  The reference's ProblemDataRef /
+  // VariableRef exist so that a caller's buffers are used without copies
+  // (fbstab_mpc.h:90-150); here those buffers may be DEVICE memory: after
+  // SetMemory(Memory::DEVICE) Solve hands the pointers to the kernel as they are
+  // (no staging copies; display levels above OFF need host memory).
+  enum class Memory { HOST, DEVICE };
+  void SetMemory(Memory m) { memory_ = m; }
 
   // fbstab_mpc.h:181-195
   template <class InputData, class InputVariable, class OutStream>
@@ -112,8 +139,17 @@ class FBstabMpc {
     v.base[0] = x->z.data(); v.base[1] = x->l.data(); v.base[2] = x->v.data(); v.base[3] = x->y.data();
     v.stride[0] = nz_; v.stride[1] = nl_; v.stride[2] = nv_; v.stride[3] = nv_;
     fbstab_solver_out_t out;
-    if (opts_.display_level >= Display::ITER) {
-      // per-iteration display (impl:411-488): the traced solve returns its lines as records
+    if (memory_ == Memory::DEVICE) {
+      if (opts_.display_level != Display::OFF)
+        throw std::runtime_error("In FBstabMpc::Solve: device-resident data is solved with Display::OFF.");
+      if (fbstab_hip_mpc_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_OUT_ON_HOST,
+                                     nullptr) != FBSTAB_HIP_OK)
+        throw std::runtime_error(std::string("In FBstabMpc::Solve: ") + fbstab_hip_last_error());
+      return detail::FromC(out);
+    }
+    if (opts_.display_level >= Display::FINAL) {
+      // every display level prints component norms (|rz| |rl| |rv|, impl:411-541):
+      // the traced solve returns the lines of the reference's display as records
       std::vector<fbstab_trace_record_t> rec(detail::TraceCapacity(opts_));
       int n = 0;
       if (fbstab_hip_mpc_solve_traced(h_, &b, &v, &out, rec.data(), static_cast<int>(rec.size()), &n) !=
@@ -126,9 +162,7 @@ class FBstabMpc {
     }
     if (fbstab_hip_mpc_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_HOST_POINTERS, nullptr) != FBSTAB_HIP_OK)
       throw std::runtime_error(std::string("In FBstabMpc::Solve: ") + fbstab_hip_last_error());
-    SolverOut s = detail::FromC(out);
-    detail::PrintFinal(s, opts_, os);
-    return s;
+    return detail::FromC(out);
   }
   template <class InputData, class InputVariable>
   SolverOut Solve(const InputData& qp, InputVariable* x) {
@@ -181,6 +215,7 @@ class FBstabMpc {
 
   int N_, nx_, nu_, nc_, nz_, nl_, nv_;
   Options opts_;
+  Memory memory_ = Memory::HOST;
   fbstab_mpc_handle_t h_ = nullptr;
 };
 

@@ -73,7 +73,12 @@ enum fbstab_hip_flags {
    * unflagged one, build them.  Ignored where it cannot be honoured (batch
    * larger than the resident QP slots, kernels without such copies); results
    * are the same with or without it. */
-  FBSTAB_HIP_KEEP_MATRICES = 4
+  FBSTAB_HIP_KEEP_MATRICES = 4,
+  /* With FBSTAB_HIP_DEVICE_POINTERS: `out` is a HOST array all the same.  The call
+   * then waits for the solve and copies the SolverOut records back (the zero-copy
+   * single-QP path of the C++ facade: ProblemDataRef / VariableRef over device
+   * memory, fbstab_mpc.h:90-150, with the SolverOut returned by value). */
+  FBSTAB_HIP_OUT_ON_HOST = 8
 };
 
 /* Index of each MPC sequence in fbstab_mpc_batch_t (FBstabMpc::ProblemData
@@ -140,6 +145,38 @@ int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t handle, int batch,
 int fbstab_hip_mpc_solve_traced(fbstab_mpc_handle_t handle, const fbstab_mpc_batch_t* data,
                                 const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
                                 fbstab_trace_record_t* trace, int capacity, int* count);
+/* Warm-started receding-horizon sweep on the device (BASELINE configs[4]): `steps`
+ * closed-loop steps of `batch` independent trajectories queued on one stream with
+ * no host round trip in between.  Step k solves the batch as
+ * fbstab_hip_mpc_solve_batch would (FBstabMpc::Solve, fbstab_mpc.h:181-195, with
+ * the previous step's (z, l, v) as the initial guess, unshifted - what a caller of
+ * the reference gets by passing the same Variable again, fbstab_algorithm-impl.h:140)
+ * and then advances every trajectory's initial state with the simulation model the
+ * reference's generator hands out (OcpGenerator::SimulationInputs,
+ * fbstab/test/ocp_generator.h:31-38):  x0 <- A x0 + B u0,  u0 = the first input of
+ * the solution.  All pointers are DEVICE pointers; data->base[FBSTAB_MPC_x0] is
+ * updated in place (it must be writable), x holds the last step's solution on
+ * return, out its SolverOut records.  The matrix sequences must not change during
+ * the sweep (FBSTAB_HIP_KEEP_MATRICES semantics).
+ *   retire != 0: a trajectory whose solve does not end in SUCCESS is parked at the
+ *                origin for the rest of the sweep (x0 = 0, zero guess, u0 = 0).
+ *   u_log:   NULL or device array [steps][batch][nu] receiving every u0.
+ *   stats:   NULL or HOST array [steps][4]: sum of Newton iterations, solves ended in
+ *            SUCCESS, trajectories retired so far, largest Newton count of the step.
+ *   kernel_ms: NULL or HOST array [steps]: device time of each step's solve.
+ * Synchronous: returns when the sweep has finished. */
+typedef struct fbstab_receding_plant_t {
+  const double* A;      /* nx x nx, column-major */
+  const double* B;      /* nx x nu, column-major */
+  long long stride_A;   /* doubles between trajectories; 0 = one plant for all */
+  long long stride_B;
+} fbstab_receding_plant_t;
+int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t handle, int batch, const fbstab_mpc_batch_t* data,
+                                  const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
+                                  const fbstab_receding_plant_t* plant, int steps, int retire,
+                                  double* u_log, unsigned long long* stats, float* kernel_ms,
+                                  void* stream);
+
 /* Device time of the solver kernel in the most recent solve_batch call on this
  * handle, measured with HIP events on the stream it ran on (ms; < 0 if none). */
 double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t handle);

@@ -11,6 +11,11 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
+
+// device memory for the zero-copy test: the HIP runtime's C API, no device code here
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
 
 #include "fbstab/fbstab_dense.h"
 #include "fbstab/fbstab_mpc.h"
@@ -229,6 +234,129 @@ static void LongHorizonRefAndServo() {
   }
 }
 
+
+// Stand-ins for Eigen::Map<Eigen::VectorXd> / Eigen::Map<Eigen::MatrixXd> (Eigen is
+// not in this image): the accessors a user's Map offers, nothing of the facade's.
+struct MockVecMap {
+  MockVecMap(double* p, long n) : p_(p), n_(n) {}
+  double* data() const { return p_; }
+  long size() const { return n_; }
+  double* p_;
+  long n_;
+};
+struct MockMatMap {
+  MockMatMap(double* p, long r, long c) : p_(p), r_(r), c_(c) {}
+  double* data() const { return p_; }
+  long rows() const { return r_; }
+  long cols() const { return c_; }
+  long size() const { return r_ * c_; }
+  double* p_;
+  long r_, c_;
+};
+
+// The reference's Ref constructors take Eigen::Map arguments (fbstab_dense.h:69-74,
+// :97-100 by pointer; fbstab_mpc.h:139-150 by value): any type with the same
+// accessors binds, and the 4-vector forms of the MPC constructors exist
+// (fbstab_mpc.h:130, :168).
+static void MapTypedRefsAndVector4() {
+  {  // DegenerateQP once more, through Map-like user types
+    const int n = 2, m = 0, q = 5;
+    double zm[2] = {0, 0}, lm[1] = {0}, vm[5] = {0, 0, 0, 0, 0}, ym[5] = {0, 0, 0, 0, 0};
+    MockVecMap z(zm, n), l(lm, m), v(vm, q), y(ym, q);
+    FBstabDense::VariableRef x0(&z, &l, &v, &y);
+    double Hmem[4] = {1, 0, 0, 0}, fmem[2] = {1, 0}, Gmem[1] = {0}, hmem[1] = {0};
+    double Amem[10] = {0, 1, 0, -1, 0, 0, 0, 1, 0, -1}, bmem[5] = {0, 3, 3, -1, -1};
+    MockMatMap H(Hmem, n, n), G(Gmem, m, n), A(Amem, q, n);
+    MockVecMap f(fmem, n), h(hmem, m), b(bmem, q);
+    FBstabDense::ProblemDataRef data(&H, &f, &G, &h, &A, &b);
+    FBstabDense solver(n, m, q);
+    solver.UpdateOptions(DenseOpts());
+    SolverOut out = solver.Solve(data, &x0);
+    EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+    EXPECT_NEAR(zm[0], 1, 1e-8);
+    EXPECT_TRUE(zm[1] >= 1 && zm[1] <= 3);
+  }
+  {  // DoubleIntegrator(2) with VariableRef over Map-like views and sizes as a 4-vector
+    Ocp ocp;
+    ocp.DoubleIntegrator(2);
+    const Vector4d s(ocp.N, ocp.nx, ocp.nu, ocp.nc);
+    FBstabMpc::Variable sized(s);
+    EXPECT_TRUE(sized.z.size() == 9 && sized.l.size() == 6 && sized.v.size() == 18 && sized.y.size() == 18);
+    std::vector<double> zm(9, 0.0), lm(6, 0.0), vm(18, 0.0), ym(18, 0.0);
+    FBstabMpc::VariableRef x(MockVecMap(zm.data(), 9), MockVecMap(lm.data(), 6), MockVecMap(vm.data(), 18),
+                             MockVecMap(ym.data(), 18));
+    FBstabMpc solver(s);
+    solver.UpdateOptions(MpcOpts());
+    FBstabMpc::ProblemDataRef ref(&ocp.data.Q, &ocp.data.R, &ocp.data.S, &ocp.data.q, &ocp.data.r, &ocp.data.A,
+                                  &ocp.data.B, &ocp.data.c, &ocp.data.E, &ocp.data.L, &ocp.data.d, &ocp.data.x0);
+    SolverOut out = solver.Solve(ref, &x);
+    EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+    EXPECT_NEAR(zm[2], 0.311688311338095, 1e-8);
+    EXPECT_NEAR(lm[0], -5.24675324688535, 1e-8);
+  }
+}
+
+// ProblemDataRef / VariableRef over DEVICE memory: Solve passes the pointers on
+// as they are (FBstabMpc::SetMemory, FBSTAB_HIP_DEVICE_POINTERS | OUT_ON_HOST).
+struct DeviceArray {
+  explicit DeviceArray(const std::vector<double>& h) : n(h.size()) {
+    if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(double) * (n ? n : 1)) != hipSuccess) p = nullptr;
+    if (p && n) (void)hipMemcpy(p, h.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+  }
+  DeviceArray(const double* h, size_t n_) : DeviceArray(std::vector<double>(h, h + n_)) {}
+  ~DeviceArray() { if (p) (void)hipFree(p); }
+  std::vector<double> host() const {
+    std::vector<double> h(n);
+    if (n) (void)hipMemcpy(h.data(), p, sizeof(double) * n, hipMemcpyDeviceToHost);
+    return h;
+  }
+  double* p = nullptr;
+  size_t n;
+};
+
+static void DeviceResidentRefs() {
+  Ocp ocp;
+  ocp.DoubleIntegrator(20);
+  const FBstabMpc::ProblemData& d = ocp.data;
+  DeviceArray Q(d.Q.data(), d.Q.size()), R(d.R.data(), d.R.size()), S(d.S.data(), d.S.size()),
+      q(d.q.data(), d.q.size()), r(d.r.data(), d.r.size()), A(d.A.data(), d.A.size()), B(d.B.data(), d.B.size()),
+      c(d.c.data(), d.c.size()), E(d.E.data(), d.E.size()), L(d.L.data(), d.L.size()), dd(d.d.data(), d.d.size()),
+      x0(d.x0.data(), d.x0.size());
+  const int N = ocp.N, nx = ocp.nx, nu = ocp.nu, nc = ocp.nc;
+  FBstabMpc::ProblemDataRef ref;
+  ref.Q = MapMatrixSequence(Q.p, N + 1, nx, nx); ref.R = MapMatrixSequence(R.p, N + 1, nu, nu);
+  ref.S = MapMatrixSequence(S.p, N + 1, nu, nx); ref.q = MapMatrixSequence(q.p, N + 1, nx, 1);
+  ref.r = MapMatrixSequence(r.p, N + 1, nu, 1); ref.A = MapMatrixSequence(A.p, N, nx, nx);
+  ref.B = MapMatrixSequence(B.p, N, nx, nu); ref.c = MapMatrixSequence(c.p, N, nx, 1);
+  ref.E = MapMatrixSequence(E.p, N + 1, nc, nx); ref.L = MapMatrixSequence(L.p, N + 1, nc, nu);
+  ref.d = MapMatrixSequence(dd.p, N + 1, nc, 1);
+  ref.SetX0(MockVecMap(x0.p, nx));
+  const int nz = (N + 1) * (nx + nu), nl = (N + 1) * nx, nv = (N + 1) * nc;
+  DeviceArray z(std::vector<double>(nz, 0.0)), l(std::vector<double>(nl, 0.0)), v(std::vector<double>(nv, 0.0)),
+      y(std::vector<double>(nv, 0.0));
+  FBstabMpc::VariableRef x(MockVecMap(z.p, nz), MockVecMap(l.p, nl), MockVecMap(v.p, nv), MockVecMap(y.p, nv));
+  FBstabMpc solver(N, nx, nu, nc);
+  solver.UpdateOptions(MpcOpts());
+  solver.SetMemory(FBstabMpc::Memory::DEVICE);
+  SolverOut out = solver.Solve(ref, &x);
+  EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+  EXPECT_TRUE(out.residual <= 1e-6);
+  EXPECT_TRUE(out.newton_iters == 9 && out.prox_iters == 4);  // as from host memory (LongHorizonRefAndServo)
+  // the solution is in the caller's device buffers; the host path gives the same numbers
+  FBstabMpc::Variable xh(N, nx, nu, nc);
+  FBstabMpc host_solver(N, nx, nu, nc);
+  host_solver.UpdateOptions(MpcOpts());
+  host_solver.Solve(ocp.data, &xh);
+  const std::vector<double> zd = z.host(), vd = v.host();
+  for (int i = 0; i < nz; i++) EXPECT_TRUE(zd[i] == xh.z(i));
+  for (int i = 0; i < nv; i++) EXPECT_TRUE(vd[i] == xh.v(i));
+  // display needs host memory
+  FBstabMpc::Options o = MpcOpts();
+  o.display_level = Display::FINAL;
+  solver.UpdateOptions(o);
+  EXPECT_THROW(solver.Solve(ref, &x));
+}
+
 static void ErrorBehaviour() {
   EXPECT_THROW(FBstabMpc(0, 2, 1, 6));     // fbstab_mpc.cc:62-65
   EXPECT_THROW(FBstabDense(2, -1, 2));     // fbstab_dense.cc:19-23
@@ -260,12 +388,13 @@ class StringOutput : public OutputStream<StringOutput> {
   std::string* s_;
 };
 
-// `facade_tests display`: FeasibleQP and DoubleIntegrator(2) at Display::ITER and
-// ITER_DETAILED (default options), text between markers; tests/test_facade.py
-// compares it with what the reference prints (tests/golden/reference_display.json).
+// `facade_tests display`: FeasibleQP and DoubleIntegrator(2) at Display::FINAL (the
+// reference's default level), ITER and ITER_DETAILED (default options), text between
+// markers; tests/test_facade.py compares it with what the reference prints
+// (tests/golden/reference_display.json).
 static int DisplayMode() {
-  const Display levels[2] = {Display::ITER, Display::ITER_DETAILED};
-  for (int k = 0; k < 2; k++) {
+  const Display levels[3] = {Display::FINAL, Display::ITER, Display::ITER_DETAILED};
+  for (int k = 0; k < 3; k++) {
     {
       FBstabDense::Variable x0(2, 0, 2);
       FBstabDense::ProblemData data(2, 0, 2);
@@ -310,6 +439,8 @@ int main(int argc, char** argv) {
   InfeasibleAndUnboundedQP();
   DoubleIntegrator();
   LongHorizonRefAndServo();
+  MapTypedRefsAndVector4();
+  DeviceResidentRefs();
   ErrorBehaviour();
   printf(g_fail ? "%d FAILED\n" : "ALL FACADE TESTS PASSED\n", g_fail);
   return g_fail ? 1 : 0;

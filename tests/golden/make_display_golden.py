@@ -2,7 +2,7 @@
 """Generates tests/golden/reference_display.json: the text the REFERENCE's own
 display functions (PrintIterHeader/IterLine/DetailedHeader/DetailedLine/
 DetailedFooter/PrintFinal, fbstab_algorithm-impl.h:411-541) print at
-Display::ITER and Display::ITER_DETAILED for the known-answer problems of
+Display::FINAL, ITER and ITER_DETAILED for the known-answer problems of
 reference_kats.json.  The text is produced by oracle/_ref/libfbstab_ref.so,
 i.e. by the reference's FBstabAlgorithm<> template compiled from
 /root/reference where it lies and writing into an OutputStream subclass that
@@ -33,12 +33,12 @@ def main():
     kats = json.load(open(os.path.join(HERE, "reference_kats.json")))
     ref = Oracle(True)
     out = {"_comment": "Display text printed by the reference's own FBstabAlgorithm<> "
-                       "(see make_display_golden.py); level 2 = Display::ITER, 3 = ITER_DETAILED.",
+                       "(see make_display_golden.py); level 1 = Display::FINAL (the default), 2 = ITER, 3 = ITER_DETAILED.",
            "cases": []}
     for kind, idx in CASES:
         k = kats[kind + "_end_to_end"][idx]
         p = H.dense_from_kat(k) if kind == "dense" else H.mpc_from_kat(k)
-        for level in (2, 3):
+        for level in (1, 2, 3):
             r = ref.solve_display(p, opts=default_options(display_level=level))
             text = re.sub(r"Time elapsed: \S+ ms", "Time elapsed: <t> ms", r[5])
             out["cases"].append(dict(kind=kind, index=idx, name=k["name"], N=k.get("N"),

@@ -16,8 +16,9 @@ def _build():
     subprocess.check_call(
         ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
          "-o", EXE, os.path.join(ROOT, "tests", "cpp", "facade_tests.cc"),
-         "-L" + os.path.join(ROOT, "fbstab_amd"), "-lfbstab_hip",
-         "-Wl,-rpath," + os.path.join(ROOT, "fbstab_amd")])
+         "-I/opt/rocm/include", "-L" + os.path.join(ROOT, "fbstab_amd"), "-lfbstab_hip",
+         "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "fbstab_amd"),
+         "-Wl,-rpath,/opt/rocm/lib"])
 
 
 def test_facade_compiles_as_cxx11():
@@ -34,7 +35,7 @@ def test_facade_reference_style_tests():
 
 @pytest.mark.gpu
 def test_facade_iter_display_is_the_reference_display():
-    """Display::ITER / ITER_DETAILED through the facade and a user OutputStream:
+    """Display::FINAL (the reference's default) / ITER / ITER_DETAILED through the facade and a user OutputStream:
     the text equals what the reference prints for the same problems
     (tests/golden/reference_display.json, produced by the reference's own print
     functions), numbers to 5e-4 relative / 1e-7 absolute."""
@@ -45,7 +46,7 @@ def test_facade_iter_display_is_the_reference_display():
     r = subprocess.run([EXE, "display"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     blocks = re.findall(r"===BEGIN (\w+) (\w+) (\d)===\n(.*?)===END===", r.stdout, flags=re.S)
-    assert len(blocks) == 4
+    assert len(blocks) == 6
     with open(os.path.join(ROOT, "tests", "golden", "reference_display.json")) as f:
         golden = json.load(f)["cases"]
     for kind, name, level, text in blocks:

@@ -722,3 +722,223 @@ def test_receding_horizon_sweep_matches_oracle(hip, oracle):
     assert flips <= (T * S) // 50, flips
     # warm starts pay off: later steps need fewer Newton iterations than the cold first one
     assert g[-1]["out"]["newton_iters"].mean() < g[0]["out"]["newton_iters"].mean()
+
+
+def _oracle_closed_loop(oracle, p, A, B, steps, retire=True):
+    """The sweep fbstab_hip_mpc_receding_sweep runs, restated with the oracle as the
+    solver: warm start unshifted, x0 <- A x0 + B u0, failed trajectories parked at
+    the origin.  Returns per-step dicts (u0, out, retired)."""
+    N, nx, nu, nc = p.sizes()
+    T = p.batch
+    x0 = p.arrays["x0"].copy()
+    z, l, v = np.zeros((T, p.nz)), np.zeros((T, p.nl)), np.zeros((T, p.nv))
+    gone = np.zeros(T, dtype=bool)
+    log = []
+    for _ in range(steps):
+        q = fx.MpcProblem(N, nx, nu, nc)
+        q.arrays = dict(p.arrays)
+        q.arrays["x0"] = np.ascontiguousarray(x0)
+        z, l, v, y, out = oracle.solve_mpc(q, (z, l, v), nthreads=oracle.num_threads())
+        if retire:
+            new = ~gone & (out["eflag"] != 0)
+            gone |= new
+            z[new] = 0.0
+            l[new] = 0.0
+            v[new] = 0.0
+        u0 = np.where(gone[:, None], 0.0, z[:, nx:nx + nu])
+        log.append(dict(u0=u0.copy(), out=out.copy(), retired=gone.copy()))
+        x0 = np.where(gone[:, None], 0.0, x0 @ A.T + u0 @ B.T)
+    return log, x0
+
+
+def test_receding_sweep_on_the_device_matches_the_oracle_loop(hip, oracle):
+    """fbstab_hip_mpc_receding_sweep (plant step, warm start and retirement on the
+    device, no host round trip between steps) against the same loop run with the
+    oracle: 48 trajectories x 12 steps, among them two that start far outside the
+    region the constraints allow and are retired."""
+    import torch
+    T, S = 48, 12
+    p = fx.synthetic_mpc_batch(T, first_id=7000)
+    p.arrays["x0"][5, 6:9] = [2.5, -2.5, 2.5]     # attitude far beyond its bound: infeasible
+    p.arrays["x0"][17, 3:6] = [40.0, -40.0, 40.0]
+    N, nx, nu, nc = p.sizes()
+    A, B = fx.quadrotor_model()
+    dev = torch.device("cuda:0")
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=T)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+    z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    r = s.RecedingSweep(data, z, l, v, y, A, B, S, retire=True, log_inputs=True)
+    ref, x_end = _oracle_closed_loop(oracle, p, A, B, S)
+    u = r["u"].cpu().numpy()
+    assert ref[-1]["retired"].sum() >= 1, "the test wants at least one retired trajectory"
+    for k in range(S):
+        assert r["stats"]["retired_total"][k] == ref[k]["retired"].sum(), k
+        assert r["stats"]["success"][k] == (ref[k]["out"]["eflag"] == 0).sum(), k
+        # (a QP on its way to an infeasibility verdict may take a few dozen iterations
+        # more or less than the oracle's; the feasible ones agree to a handful)
+        good = ref[k]["out"]["eflag"] == 0
+        slack = max(4, T // 8) + int(ref[k]["out"]["newton_iters"][~good].sum())
+        assert abs(int(r["stats"]["newton_sum"][k]) - int(ref[k]["out"]["newton_iters"].sum())) <= slack, k
+        np.testing.assert_allclose(u[k], ref[k]["u0"], atol=2e-5)
+    np.testing.assert_allclose(data["x0"].cpu().numpy(), x_end, atol=2e-5)
+    assert (r["kernel_ms"] > 0).all()
+    s.close()
+
+
+def test_config5_full_sweep_with_an_oracle_subset(hip, oracle):
+    """BASELINE configs[4] at full size: 4096 trajectories x 200 steps on the device.
+    The trajectories are independent, so the 64 of them with ids 0, 64, 128, ... are
+    also run through the oracle loop: same retirements, inputs equal to 2e-5 at every
+    one of the 200 steps.  For the whole batch: the warm start pays (one or two Newton
+    iterations per solve at the end), every solve of a non-retired trajectory
+    succeeds, retired ones are few."""
+    import torch
+    T, S = 4096, 200
+    p = fx.synthetic_mpc_batch(T)
+    N, nx, nu, nc = p.sizes()
+    A, B = fx.quadrotor_model()
+    dev = torch.device("cuda:0")
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=T)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+    z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    r = s.RecedingSweep(data, z, l, v, y, A, B, S, retire=True, log_inputs=True)
+    st = r["stats"]
+    assert st["retired_total"][-1] <= T // 50
+    assert (st["success"] + st["retired_total"] >= T).all()       # nobody fails twice
+    assert st["newton_sum"][-1] <= 2 * T and st["newton_sum"][0] > 10 * T
+    sub = np.arange(0, T, 64)
+    q = fx.MpcProblem(N, nx, nu, nc)
+    q.arrays = {k: np.ascontiguousarray(a[sub]) for k, a in p.arrays.items()}
+    ref, x_end = _oracle_closed_loop(oracle, q, A, B, S)
+    u = r["u"][:, torch.from_numpy(sub).to(dev)].cpu().numpy()
+    gone_gpu = np.abs(data["x0"].cpu().numpy()[sub]).max(axis=1) == 0.0
+    assert np.array_equal(gone_gpu, ref[-1]["retired"]) or ref[-1]["retired"].sum() == 0
+    for k in range(S):
+        np.testing.assert_allclose(u[k], ref[k]["u0"], atol=2e-5, err_msg=f"step {k}")
+    np.testing.assert_allclose(data["x0"].cpu().numpy()[sub], x_end, atol=2e-5)
+    s.close()
+
+
+# -- VERDICT r1 item 3: parity coverage on the record kernel ---------------------------
+def test_mpc_reliable_options_on_the_record_kernel(hip, oracle, monkeypatch):
+    """ReliableOptions (impl:61-74: sigma0 1e-4, beta 0.9, monotone line search, 40
+    trials, tolerances 1e-4 / 1e-6) on the record kernel, BASELINE shape, against
+    the oracle under the same options."""
+    _select_kernel(monkeypatch, "r16")
+    p = fx.synthetic_mpc_batch(128, first_id=30000)
+    o = reliable_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    assert (cpu[4]["eflag"] == 0).all()
+    _assert_parity(gpu, cpu, o.abs_tol)
+
+
+def _ray_mpc(contradictory_inputs, N=4):
+    """A double integrator with zero Hessian and the cost -x1: without constraints on
+    the first input the problem is unbounded below (dual infeasible, exit flag 4).
+    With `contradictory_inputs` a second input that no state depends on is asked to
+    be <= -1 and >= 1 as well (the oracle still reports the dual certificate first)."""
+    A = np.array([[1.0, 1.0], [0.0, 1.0]])
+    if contradictory_inputs:
+        B = np.array([[0.0, 0.0], [1.0, 0.0]])
+        E, L, d = np.zeros((2, 2)), np.array([[0.0, 1.0], [0.0, -1.0]]), np.array([1.0, 1.0])
+    else:
+        B = np.array([[0.0], [1.0]])
+        E, L, d = np.zeros((1, 2)), np.zeros((1, 1)), np.array([-1.0])   # 0 <= 1: vacuous
+    nu = B.shape[1]
+    g = fx.OcpGenerator()
+    g.CopyOverHorizon(np.zeros((2, 2)), np.zeros((nu, nu)), np.zeros((nu, 2)), np.array([-1.0, 0.0]), np.zeros(nu),
+                      A, B, np.zeros(2), E, L, d, np.zeros(2), N)
+    return g.GetFBstabInput()
+
+
+@pytest.mark.parametrize("contradictory_inputs", [False, True])
+def test_mpc_infeasibility_certificates_on_the_record_kernel(hip, oracle, monkeypatch, contradictory_inputs):
+    """FullFeasibility::CheckFeasibility (full_feasibility.cc:25-88) for MPC data: an
+    unbounded problem (DUAL_INFEASIBLE) alone and with contradictory constraints on
+    top; a batch that also holds the primal-infeasible and a solvable variant.  Exit
+    flags equal the oracle's and the certificate x = dx agrees in direction."""
+    _select_kernel(monkeypatch, "r16")
+    one = _ray_mpc(contradictory_inputs)
+    N, nx, nu, nc = one.sizes()
+    p = fx.MpcProblem(N, nx, nu, nc)
+    p.arrays = {k: np.repeat(a, 3, axis=0) for k, a in one.arrays.items()}
+    # QP 1: bounded by a quadratic cost; QP 2: another ray (cost 2x the first)
+    p.arrays["Q"][1] = np.tile(np.eye(nx).reshape(-1), N + 1)
+    p.arrays["R"][1] = np.tile(np.eye(nu).reshape(-1), N + 1)
+    p.arrays["q"][2] *= 2.0
+    if contradictory_inputs:
+        p.arrays["d"][1] = np.tile([-1.0, -1.0], N + 1)   # QP 1 feasible: |u2| <= 1
+    o = default_options()
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=3)
+    assert s.kernel_name().startswith("fbstab_mpc_r16_kernel")
+    s.close()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o)
+    assert cpu[4]["eflag"].tolist() == [4, 0, 4], cpu[4]["eflag"]
+    assert np.array_equal(gpu[4]["eflag"], cpu[4]["eflag"])
+    assert np.array_equal(gpu[4]["prox_iters"], cpu[4]["prox_iters"])
+    for b in (0, 2):   # certificates: the same ray up to scale and rounding
+        for g, c in ((gpu[0][b], cpu[0][b]), (gpu[2][b], cpu[2][b])):
+            if np.abs(c).max() > 0:
+                cosang = float(g @ c) / (np.linalg.norm(g) * np.linalg.norm(c))
+                assert cosang > 1 - 1e-6, (b, cosang)
+    assert np.abs(gpu[0][1] - cpu[0][1]).max() <= 1e-5 * (1 + np.abs(cpu[0][1]).max())
+
+
+def test_saturate_error_is_exit_flag_6(hip, oracle, monkeypatch):
+    """tools::saturate throws when its lower bound exceeds the upper one
+    (tools/utilities.h:19-28).  Two ways in: inner_tol_min > inner_tol_max at the
+    first use (impl:150-151), and a residual that has fallen below inner_tol_min at
+    a later proximal iteration while the outer test has not passed yet (impl:179-180).
+    The reference (and the oracle) throw out of Solve; the device reports exit flag 6
+    for that QP, which the C++ facade turns back into the same exception."""
+    _select_kernel(monkeypatch, "r16")
+    p = fx.synthetic_mpc_batch(8, first_id=77)
+    for o in (default_options(inner_tol_min=1e-2, inner_tol_max=1e-3),
+              default_options(inner_tol_min=1e-3, abs_tol=1e-9)):
+        with pytest.raises(RuntimeError, match="saturate"):
+            oracle.solve_mpc(p, opts=o)
+        gpu = _solve_mpc_host(hip, p, o)
+        assert (gpu[4]["eflag"] == 6).all(), gpu[4]["eflag"]
+    d = fx.synthetic_dense_batch(4, 20, 5, 40)
+    o = default_options(inner_tol_min=1e-2, inner_tol_max=1e-3)
+    with pytest.raises(RuntimeError, match="saturate"):
+        oracle.solve_dense(d, opts=o)
+    assert (_solve_dense_host(hip, d, o)[4]["eflag"] == 6).all()
+
+
+def test_config4_all_eight_shards(hip, oracle):
+    """BASELINE configs[3]: ids 0..65535 in eight shards of 8192, as eight ranks would
+    hold them (here one GPU, one shard after the other).  For every shard: exit
+    flags equal the oracle's for ALL QPs, Newton counts equal on >= 99 %.  Over the
+    whole batch: the ten ids the oracle runs to the 200-iteration limit are the ones
+    the device reports, and the Newton totals agree to 1e-4."""
+    import torch
+    dev = torch.device("cuda:0")
+    B = 8192
+    o = default_options()
+    s = hip.FBstabMpcBatch(30, 12, 4, 20, max_batch=B)
+    s.UpdateOptions(_opts(hip, o))
+    tot_g = tot_c = 0
+    limit_g, limit_c = [], []
+    for shard in range(8):
+        p = fx.synthetic_mpc_batch(B, first_id=shard * B)
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        og = hip.out_to_numpy(s.Solve(data, z, l, v, y))
+        oc = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())[4]
+        assert np.array_equal(og["eflag"], oc["eflag"]), shard
+        dn = np.abs(og["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
+        assert (dn == 0).mean() >= 0.99 and dn.max() <= 4, (shard, (dn != 0).sum(), dn.max())
+        tot_g += int(og["newton_iters"].sum())
+        tot_c += int(oc["newton_iters"].sum())
+        limit_g += (shard * B + np.nonzero(og["eflag"] == 2)[0]).tolist()
+        limit_c += (shard * B + np.nonzero(oc["eflag"] == 2)[0]).tolist()
+        del data
+    s.close()
+    assert limit_g == limit_c == [11960, 15020, 32011, 32547, 36083, 37816, 46092, 50603, 55479, 56432]
+    assert abs(tot_g - tot_c) <= 1e-4 * tot_c, (tot_g, tot_c)

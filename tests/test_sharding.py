@@ -26,8 +26,22 @@ def _worker(rank, world, port, per_rank, q):
     z, l, v, y, out = Oracle(False).solve_mpc(p)
     x = torch.from_numpy(np.concatenate([z, l, v, y], axis=1))
     o = torch.from_numpy(np.frombuffer(out.tobytes(), dtype=np.uint8).reshape(len(out), 40).copy())
+    calls = []
+    real_gather = dist.gather
+    dist.gather = lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1]
     X, O = sharding.gather_solutions(x, o, dst=0)
+    # the way bench.py calls it: the solver writes into the first columns of a
+    # preallocated record, receive buffers are preallocated on rank 0
+    rec = torch.zeros((x.shape[0], x.shape[1] + sharding.OUT_DOUBLES), dtype=torch.float64)
+    rec[:, :x.shape[1]] = x
+    glist = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+    X2, O2 = sharding.gather_solutions(rec[:, :x.shape[1]], o, dst=0, record=rec, gather_list=glist)
+    dist.gather = real_gather
+    assert len(calls) == 2, "one collective per batch"
     if rank == 0:
+        assert torch.equal(X, X2) and torch.equal(O, O2)
+        unpacked = np.concatenate([sharding.unpack_out(g) for g in glist])
+        assert np.array_equal(unpacked["newton_iters"], np.frombuffer(O.numpy().tobytes(), dtype=out.dtype)["newton_iters"])
         q.put((X.numpy(), O.numpy()))
     dist.barrier()
     dist.destroy_process_group()
