@@ -57,15 +57,19 @@ struct VarBatchPtrs {
 // zero-padded.
 // KEEP: instance for FBSTAB_HIP_KEEP_MATRICES (QP q lives in slot q from call to
 // call; with `reuse` set the matrix copies of the previous call are still valid).
-template <int NX, int NU, int NC, bool EXACT = true, bool KEEP = false>
+template <int NX, int NU, int NC, bool EXACT = true, bool KEEP = false, int RQ = 1>
 struct MpcR16 {
-  typedef Ctx16 C;
+  typedef CtxRow<RQ> C;
+  // lanes per QP (RQ = 1: one 16-lane DPP row, four QPs per wavefront; RQ = 2: a row
+  // pair, two QPs per wavefront - fb_row16.h), QPs per wavefront
+  static constexpr int LPQ = 16 * RQ, kQpPerWave = 64 / LPQ;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   static constexpr bool kFusedTrial = true;
   static constexpr bool kOwnVectorOps = true;
   static constexpr int NS = NX + NU;
-  static constexpr int KS = (NC + 15) / 16;  // constraint slots per lane
-  static_assert(NS <= 16, "stage width must fit one DPP row");
+  static constexpr int NSP = RQ == 1 ? 16 : ((NS + 1) & ~1);  // slots of a row of a stage matrix
+  static constexpr int KS = (NC + LPQ - 1) / LPQ;  // constraint slots per lane
+  static_assert(NS <= LPQ, "stage width must fit the QP's lanes");
 
   // ---- stage record ----------------------------------------------------------
   // (DL, WLN): WLN(i) = wl(i + 1), the l-block increment the backward sweep forms at
@@ -95,20 +99,16 @@ struct MpcR16 {
   // (NX (NX + 1) / 2 values), each cut into slots of 16 consecutive elements - the
   // pipelined solver is bound by the bytes of this record going out in the forward
   // sweep and back in the backward sweep.  Lanes get at their own row and column
-  // through a linear image of the triangle in LDS (tri_*).  t rides with the last
-  // slot of inv(Lc), theta with the last one of inv(Pi): whole pairs, each
-  // written at one time.
+  // through a linear image of the triangle in LDS (tri_*).  t rides behind the
+  // slots of inv(Lc), theta behind those of inv(Pi): each group is written at
+  // one time.
   static constexpr int tri(int j) { return j * (j + 1) / 2; }
   static constexpr int kXTri = tri(NS), kPTri = tri(NX);
-  static constexpr int kXFull = kXTri / 16, kPFull = kPTri / 16;  // full slots; one partial slot follows
-  static_assert(kXTri % 16 != 0 && kPTri % 16 != 0 && kXFull % 2 == 0 && kPFull % 2 == 0,
-                "record layout assumes a partial last slot after an even number of full ones");
-  static constexpr int fX = (sB + KS + 1) & ~1;      // kXFull slots, then the pair (last, t)
-  static constexpr int fXT = fX + kXFull;
-  static constexpr int fP = fXT + 2;                 // kPFull slots, then the pair (last, theta)
-  static constexpr int fPTh = fP + kPFull;
-  static constexpr int kSlots = fPTh + 2;
-  static constexpr int kRec = 16 * kSlots;  // doubles per stage
+  static constexpr int nXs = (kXTri + LPQ - 1) / LPQ, nPs = (kPTri + LPQ - 1) / LPQ;  // slots of each triangle
+  static constexpr int fX = (sB + KS + 1) & ~1;          // nXs slots, then t
+  static constexpr int fP = fX + ((nXs + 2) & ~1);       // nPs slots, then theta
+  static constexpr int kSlots = fP + ((nPs + 2) & ~1);
+  static constexpr int kRec = LPQ * kSlots;  // doubles per stage
   // Matrix copy ("pack"), a region of its own: stage i's copy sits at
   // pack + i * kPack.  A stage whose matrices are bitwise identical to the
   // previous stage's reads that stage's copy instead (poff[i], the offset of
@@ -117,16 +117,16 @@ struct MpcR16 {
   // three cache-resident 8 KB copies per QP rather than N + 1 from HBM.
   // Time-varying data simply gets poff[i] = i * kPack.
   static constexpr int pK = 0;                         // row r of [Q S'; S R], 16 slots
-  static constexpr int pC = pK + 16;                   // column r of C = [E L], NC slots
+  static constexpr int pC = pK + NSP;                  // column r of C = [E L], NC slots
   static constexpr int pABr = pC + ((NC + 1) & ~1);    // row r of [A B], 16 slots
-  static constexpr int pABc = pABr + 16;               // column r of [A B], NX slots
+  static constexpr int pABc = pABr + NSP;              // column r of [A B], NX slots
   static constexpr int kPackSlots = (pABc + NX + 1) & ~1;
-  static constexpr int kPack = 16 * kPackSlots;
+  static constexpr int kPack = LPQ * kPackSlots;
   // poff[N+1] ints and the flag word
   static constexpr long hdr_doubles(int N) { return ((N + 1) / 2 + 16) & ~15L; }
   static constexpr long ws_doubles(int N) { return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1); }
 
-  static constexpr int off(int slot) { return (slot >> 1) * 32 + (slot & 1); }
+  static constexpr int off(int slot) { return (slot >> 1) * 2 * LPQ + (slot & 1); }
 
   // LDS of one row:
   //   [0, kPackLds)   the matrix copy the current stage uses, minus the [A B]
@@ -139,15 +139,18 @@ struct MpcR16 {
   static constexpr int CS = NC | 1;
   // the triangle images: inv(Lc) at 0, inv(Pi) behind it, one dump word for the
   // lanes that have no element to write
-  static constexpr int kXl = 0, kPl = (kXTri + 15) & ~15, kDump = kPl + ((kPTri + 15) & ~15);
-  static constexpr int TS = (kDump + 16 + 15) / 16;  // 16 * TS doubles hold them
+  static constexpr int kXl = 0, kPl = LPQ * nXs, kDump = kPl + LPQ * nPs;
+  static constexpr int TS = (kDump + 16 + LPQ - 1) / LPQ;  // LPQ * TS doubles hold them
   static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
   static constexpr bool kPackInLds = true;
-  static constexpr int kPackLds = kPackInLds ? 16 * kPackLdsSlots : 0;
+  static constexpr int kPackLds = kPackInLds ? LPQ * kPackLdsSlots : 0;
   // this lane's view of the matrix copy in use
   typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
-  static constexpr int kLdsDoubles = kPackLds + 16 * (CS > TS ? CS : TS);
-  static constexpr int kLdsPerRow = ((kLdsDoubles + 31) & ~31) + 16;
+  static constexpr int kLdsDoubles = kPackLds + LPQ * (CS > TS ? CS : TS);
+  // region stride: 16 doubles mod 32 (bank placement of neighbouring QPs) and at least
+  // 24 spare doubles behind the images for the solver loop's parked scalars
+  static constexpr int kLdsBase = ((kLdsDoubles + 31) & ~31) + 16;
+  static constexpr int kLdsPerRow = kLdsBase - kLdsDoubles >= 24 ? kLdsBase : kLdsBase + 32;
 
   // ---- state -------------------------------------------------------------------
   double* rec;   // this row's records, lane offset included
@@ -189,11 +192,11 @@ struct MpcR16 {
   double pend_t;
 
   FB_DEV void bind(double* ws_row, lds_ptr lds_row, lds_iptr lpo_row, const MpcBatchPtrs* d,
-                   const VarBatchPtrs* x, long q_, int N_, int lane16) {
+                   const VarBatchPtrs* x, long q_, int N_, int lane) {
     lds_off = -1;
     poff = reinterpret_cast<int*>(ws_row);
     lpo = lpo_row;
-    pack = ws_row + hdr_doubles(N_) + 2 * lane16;
+    pack = ws_row + hdr_doubles(N_) + 2 * lane;
     rec = pack + (long)kPack * (N_ + 1);
     lds = lds_row;
     data = d;
@@ -220,7 +223,7 @@ struct MpcR16 {
     static_assert((S0 & 1) == 0, "slot ranges start on a pair");
     sfor<0, (CNT + 1) / 2>([&](auto P_) {
       constexpr int pr = decltype(P_)::value;
-      const dbl2 t = *reinterpret_cast<const dbl2*>(R + (S0 / 2 + pr) * 32);
+      const dbl2 t = *reinterpret_cast<const dbl2*>(R + (S0 / 2 + pr) * 2 * LPQ);
       out[2 * pr] = t[0];
       if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
     });
@@ -231,9 +234,9 @@ struct MpcR16 {
     sfor<0, CNT / 2>([&](auto P_) {
       constexpr int pr = decltype(P_)::value;
       dbl2 t = {in[2 * pr], in[2 * pr + 1]};
-      *reinterpret_cast<dbl2*>(R + (S0 / 2 + pr) * 32) = t;
+      *reinterpret_cast<dbl2*>(R + (S0 / 2 + pr) * 2 * LPQ) = t;
     });
-    if constexpr (CNT & 1) R[(S0 / 2 + CNT / 2) * 32] = in[CNT - 1];
+    if constexpr (CNT & 1) R[(S0 / 2 + CNT / 2) * 2 * LPQ] = in[CNT - 1];
   }
 
   // Makes the matrix copy at offset `off` the one resident in LDS (row-uniform).
@@ -258,9 +261,9 @@ struct MpcR16 {
       constexpr int c0 = decltype(Ch)::value * kChunk;
       constexpr int cn = c0 + kChunk < kPairs ? kChunk : kPairs - c0;
       dbl2 t[kChunk];
-      sfor<0, cn>([&](auto I) { t[decltype(I)::value] = *reinterpret_cast<const dbl2*>(src + (c0 + decltype(I)::value) * 32); });
+      sfor<0, cn>([&](auto I) { t[decltype(I)::value] = *reinterpret_cast<const dbl2*>(src + (c0 + decltype(I)::value) * 2 * LPQ); });
       sfor<0, cn>([&](auto I) {
-        *reinterpret_cast<FB_LDS dbl2*>(dst + (c0 + decltype(I)::value) * 32) = t[decltype(I)::value];
+        *reinterpret_cast<FB_LDS dbl2*>(dst + (c0 + decltype(I)::value) * 2 * LPQ) = t[decltype(I)::value];
       });
     });
     c.sync();
@@ -275,7 +278,7 @@ struct MpcR16 {
     static_assert((S0 & 1) == 0 && S0 + CNT <= kPackLdsSlots, "inside the LDS image, on a pair");
     sfor<0, (CNT + 1) / 2>([&](auto P_) {
       constexpr int pr = decltype(P_)::value;
-      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + (S0 / 2 + pr) * 32);
+      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + (S0 / 2 + pr) * 2 * LPQ);
       out[2 * pr] = t[0];
       if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
     });
@@ -288,7 +291,7 @@ struct MpcR16 {
   FB_DEV void rows_of_C_times(lds_ptr Cl, const double (&zb)[NS], int r, Out&& out) const {
     sfor<0, KS>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
-      const int k = r + 16 * s;
+      const int k = r + LPQ * s;
       const int kk = k < NC ? k : 0;
       double clk[NS];
       sfor<0, NS>([&](auto Cc) { clk[decltype(Cc)::value] = Cl[decltype(Cc)::value * CS + kk]; });
@@ -312,12 +315,12 @@ struct MpcR16 {
                  *px0 = arr(FBSTAB_MPC_x0), *pc = arr(FBSTAB_MPC_c);
     double s = 0.0;
     const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
-    for (int i = c.tid; i < (N_ + 1) * nx_; i += 16) s += pq[i] * pq[i];
-    for (int i = c.tid; i < (N_ + 1) * nu_; i += 16) s += pr[i] * pr[i];
-    for (int i = c.tid; i < (N_ + 1) * nc_; i += 16) s += pd[i] * pd[i];
-    for (int i = c.tid; i < nx_; i += 16) s += px0[i] * px0[i];
-    for (int i = c.tid; i < N_ * nx_; i += 16) s += pc[i] * pc[i];
-    return sqrt(row_reduce<OpSum16>(s));
+    for (int i = c.tid; i < (N_ + 1) * nx_; i += LPQ) s += pq[i] * pq[i];
+    for (int i = c.tid; i < (N_ + 1) * nu_; i += LPQ) s += pr[i] * pr[i];
+    for (int i = c.tid; i < (N_ + 1) * nc_; i += LPQ) s += pd[i] * pd[i];
+    for (int i = c.tid; i < nx_; i += LPQ) s += px0[i] * px0[i];
+    for (int i = c.tid; i < N_ * nx_; i += LPQ) s += pc[i] * pc[i];
+    return sqrt(qp_reduce<RQ, OpSum16>(s));
   }
 
   // x <- caller's guess, y = b - A z (impl:334-347, full_variable.cc:47-53), and
@@ -343,8 +346,8 @@ struct MpcR16 {
     const lds_iptr lp = lpo;
     bool single = true;  // no constraint row with two nonzeros seen so far (row-uniform)
     int canon = 0;  // offset of the copy the previous stage uses (row-uniform)
-    double lastKr[16], lastABr[16], lastCc[NC], lastABc[NX];  // that copy's values, this lane's share
-    sfor<0, 16>([&](auto Cc_) { lastKr[decltype(Cc_)::value] = lastABr[decltype(Cc_)::value] = 0.0; });
+    double lastKr[NSP], lastABr[NSP], lastCc[NC], lastABc[NX];  // that copy's values, this lane's share
+    sfor<0, NSP>([&](auto Cc_) { lastKr[decltype(Cc_)::value] = lastABr[decltype(Cc_)::value] = 0.0; });
     sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = 0.0; });
     sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = 0.0; });
     for (int i = 0; i <= N_; i++) {
@@ -360,8 +363,8 @@ struct MpcR16 {
         ldv<pC, NC>(P0 + kept, Cc);  // only C is needed here (y = b - A z)
       } else {
         // matrices (the caller's arrays have the problem's own strides nx, nu, nc)
-        double Kr[16], ABr[16], ABc[NX];
-        sfor<0, 16>([&](auto Cc_) {
+        double Kr[NSP], ABr[NSP], ABc[NX];
+        sfor<0, NSP>([&](auto Cc_) {
           constexpr int cc = decltype(Cc_)::value;
           double kv = 0.0, ab = 0.0;
           if constexpr (cc < NX) {
@@ -396,28 +399,28 @@ struct MpcR16 {
           });
         }
         {
-          const int rowsh = 16 * ((threadIdx.x & 63) >> 4);
+          const int rowsh = LPQ * ((threadIdx.x & 63) / LPQ);
           sfor<0, NC>([&](auto Kk) {
             const unsigned long long m = __ballot(Cc[decltype(Kk)::value] != 0.0);
-            single = single && __popc((unsigned)(m >> rowsh) & 0xffffu) <= 1;
+            single = single && __popc((unsigned)(m >> rowsh) & (unsigned)((1ull << LPQ) - 1ull)) <= 1;
           });
         }
         // A stage whose matrices equal (bitwise) those of the previous stage
         // shares its copy: nothing is written for it.
         bool differs = i == 0;
-        sfor<0, 16>([&](auto Cc_) {
+        sfor<0, NSP>([&](auto Cc_) {
           constexpr int cc = decltype(Cc_)::value;
           differs = differs || !(Kr[cc] == lastKr[cc]) || !(ABr[cc] == lastABr[cc]);
         });
         sfor<0, NC>([&](auto Kk) { differs = differs || !(Cc[decltype(Kk)::value] == lastCc[decltype(Kk)::value]); });
         sfor<0, NX>([&](auto J) { differs = differs || !(ABc[decltype(J)::value] == lastABc[decltype(J)::value]); });
-        if (row_reduce<OpMax16>(differs ? 1.0 : 0.0) > 0.0) {
+        if (qp_reduce<RQ, OpMax16>(differs ? 1.0 : 0.0) > 0.0) {
           canon = i * kPack;
-          stv<pK, 16>(PK, Kr);
-          stv<pABr, 16>(PK, ABr);
+          stv<pK, NSP>(PK, Kr);
+          stv<pABr, NSP>(PK, ABr);
           stv<pC, NC>(PK, Cc);
           stv<pABc, NX>(PK, ABc);
-          sfor<0, 16>([&](auto Cc_) {
+          sfor<0, NSP>([&](auto Cc_) {
             lastKr[decltype(Cc_)::value] = Kr[decltype(Cc_)::value];
             lastABr[decltype(Cc_)::value] = ABr[decltype(Cc_)::value];
           });
@@ -440,11 +443,11 @@ struct MpcR16 {
       st2(R, sDZ, 0.0, 0.0);
       st2(R, sDL, 0.0, 0.0);
       double zb[NS];
-      bc_all<NS>(zz, zb);
+      bc_all<NS, RQ>(zz, zb);
       C_to_lds(c, Cl, Cc, r);
       rows_of_C_times(Cl, zb, r, [&](auto S_, bool valid, double az) {
         constexpr int s = decltype(S_)::value;
-        const int k = r + 16 * s;
+        const int k = r + LPQ * s;
         const bool real = valid && k < nc_;
         const double b = real ? -pd[(long)i * nc_ + k] : 0.0;
         const double vv = real ? uv[(long)i * nc_ + k] : 0.0;
@@ -493,13 +496,13 @@ struct MpcR16 {
         hn = ld(R + kRec, sH);
       }
       double zb[NS], lnb[NX];
-      bc_all<NS>(zz, zb);
-      bc_all<NX>(ln, lnb);
+      bc_all<NS, RQ>(zz, zb);
+      bc_all<NX, RQ>(ln, lnb);
       double s = fh[0] + dot4<NS>(Kr, zb);
       s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
       {
         double p[4] = {s, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(vs[decltype(I)::value >> 4]); },
+        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(vs[decltype(I)::value / LPQ]); },
                         [&](auto I, double t) {
                           constexpr int k = decltype(I)::value;
                           p[k & 3] = fma(Cc[k], t, p[k & 3]);
@@ -533,7 +536,7 @@ struct MpcR16 {
         s = fma(p, p, s);
       });
     }
-    return sqrt(row_reduce<OpSum16>(s));
+    return sqrt(qp_reduce<RQ, OpSum16>(s));
   }
 
   // (Ei, Eo) at x + t dx for the K step lengths t0 beta^k in one pass
@@ -611,8 +614,8 @@ struct MpcR16 {
     }
     sfor<0, K>([&](auto Kk) {
       constexpr int k = decltype(Kk)::value;
-      Ei[k] = sqrt(row_reduce<OpSum16>(s[k]));
-      Eo[k] = sqrt(row_reduce<OpSum16>(s[K + k]));
+      Ei[k] = sqrt(qp_reduce<RQ, OpSum16>(s[k]));
+      Eo[k] = sqrt(qp_reduce<RQ, OpSum16>(s[K + k]));
     });
   }
 
@@ -741,13 +744,13 @@ struct MpcR16 {
         const double (&bs)[KS] = vc.bs;
         const double (&ABc)[NX] = vc.ABc;
         double dzb[NS], dlnb[NX];
-        bc_all<NS>(cur.dz, dzb);
-        bc_all<NX>(nxt.dl, dlnb);
+        bc_all<NS, RQ>(cur.dz, dzb);
+        bc_all<NX, RQ>(nxt.dl, dlnb);
         m_hdz = fmax(m_hdz, fabs(dot4<NS>(Kr, dzb)));
         m_dz = fmax(m_dz, fabs(cur.dz));
         {
           double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? cur.dl : 0.0), 0.0, 0.0, 0.0};
-          bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
+          bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
                           [&](auto I, double tt) {
                             constexpr int k = decltype(I)::value;
                             p[k & 3] = fma(Cc[k], tt, p[k & 3]);
@@ -775,12 +778,12 @@ struct MpcR16 {
       nxt = nn;
     }
     c.sync();
-    *dx_norm = sqrt(row_reduce<OpSum16>(s_dx));
+    *dx_norm = sqrt(qp_reduce<RQ, OpSum16>(s_dx));
     if (!check) return kFeasible;
-    const double d1 = row_reduce<OpMax16>(m_adz), d2 = row_reduce<OpMax16>(m_gdz),
-                 d3 = row_reduce<OpMax16>(m_hdz), w = row_reduce<OpMax16>(m_dz),
-                 p1 = row_reduce<OpMax16>(m_atv), u = row_reduce<OpMax16>(m_u);
-    const double d4 = row_reduce<OpSum16>(s_fdz), p2 = row_reduce<OpSum16>(s_p2);
+    const double d1 = qp_reduce<RQ, OpMax16>(m_adz), d2 = qp_reduce<RQ, OpMax16>(m_gdz),
+                 d3 = qp_reduce<RQ, OpMax16>(m_hdz), w = qp_reduce<RQ, OpMax16>(m_dz),
+                 p1 = qp_reduce<RQ, OpMax16>(m_atv), u = qp_reduce<RQ, OpMax16>(m_u);
+    const double d4 = qp_reduce<RQ, OpSum16>(s_fdz), p2 = qp_reduce<RQ, OpSum16>(s_p2);
     bool dual_feasible = true, primal_feasible = true;
     if ((d1 <= w * tol) && (d2 <= tol * w) && (d3 <= tol * w) && (d4 < 0) && (w > 1e-14))
       dual_feasible = false;
@@ -845,13 +848,13 @@ struct MpcR16 {
       const double zz = zl[0], ll = zl[1];
       st2(R, sZB, zz, ll);
       double zb[NS], lnb[NX];
-      bc_all<NS>(zz, zb);
-      bc_all<NX>(zln[1], lnb);
+      bc_all<NS, RQ>(zz, zb);
+      bc_all<NX, RQ>(zln[1], lnb);
       double s = fh[0] + dot4<NS>(Kr, zb);
       s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
       {
         double p[4] = {s, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(vy[decltype(I)::value >> 4][0]); },
+        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(vy[decltype(I)::value / LPQ][0]); },
                         [&](auto I, double t) {
                           constexpr int k = decltype(I)::value;
                           p[k & 3] = fma(Cc[k], t, p[k & 3]);
@@ -887,9 +890,9 @@ struct MpcR16 {
       zl = zln;
     }
     c.sync();
-    const double nat = row_reduce<OpSum16>(s_nat);
-    *Ek = sqrt(nat + row_reduce<OpSum16>(s_vo));
-    *Ei0 = sqrt(nat + row_reduce<OpSum16>(s_vi));
+    const double nat = qp_reduce<RQ, OpSum16>(s_nat);
+    *Ek = sqrt(nat + qp_reduce<RQ, OpSum16>(s_vo));
+    *Ei0 = sqrt(nat + qp_reduce<RQ, OpSum16>(s_vi));
   }
 
   // ---- results ---------------------------------------------------------------------
@@ -910,7 +913,7 @@ struct MpcR16 {
       if (r < nx_) ul[(long)i * nx_ + r] = ll;
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        const int k = r + 16 * sl;
+        const int k = r + LPQ * sl;
         const dbl2 vy = ld2(R, sV + 2 * sl);
         double vv = vy[0], yy = vy[1];
         if (WHICH == 1) {
@@ -950,7 +953,7 @@ struct MpcR16 {
       st2(R, sZB, zi >= 0 ? dbg[zi] : 0.0, r < nx_ ? dbg[nz + (long)i * nx_ + r] : 0.0);
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        const int k = r + 16 * sl;
+        const int k = r + LPQ * sl;
         st(R, sVB + sl, k < nc_ ? dbg[nz + nl + (long)i * nc_ + k] : 0.0);
       });
     }
@@ -976,7 +979,7 @@ struct MpcR16 {
       }
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
-        const int k = r + 16 * sl;
+        const int k = r + LPQ * sl;
         if (k < nc_) {
           o[nz + nl + (long)i * nc_ + k] = ld(R, sDV + 2 * sl);
           o[nz + nl + nv + (long)i * nc_ + k] = ld(R, sDV + 2 * sl + 1);
@@ -1087,7 +1090,7 @@ struct MpcR16 {
       double Gam[KS], Rvm[KS];
       sfor<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
-        const int k = r + 16 * s;
+        const int k = r + LPQ * s;
         const double vk = fma(tp, cur.da[s][0], cur.vy[s][0]);
         const double yk = fma(-tp, cur.da[s][1], cur.vy[s][1]);
         const dbl2 bt = barrier_terms(vk, yk, cur.vb[s], sigma, alpha, k < NC);
@@ -1116,7 +1119,7 @@ struct MpcR16 {
       sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] += Pinv[decltype(Cc)::value]; });
       {
         double p[4] = {r1, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(Rvm[decltype(I)::value >> 4]); },
+        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(Rvm[decltype(I)::value / LPQ]); },
                         [&](auto I, double rk) {
                           constexpr int k = decltype(I)::value;
                           p[k & 3] = fma(-Cc_[k], rk, p[k & 3]);
@@ -1129,15 +1132,16 @@ struct MpcR16 {
         sfor<0, NS>([&](auto Cc) { s = (ro == decltype(Cc)::value) ? K[decltype(Cc)::value] : s; });
         sfor<0, NC>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          const double gc = bc<(k & 15)>(Gam[k >> 4]) * Cc_[k];  // Gamma_k C[k][r]
+          const double gc = bcr<RQ, (k % LPQ)>(Gam[k / LPQ]) * Cc_[k];  // Gamma_k C[k][r]
           s = fma(gc, Cc_[k], s);
         });
         sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = (ro == decltype(Cc)::value) ? s : K[decltype(Cc)::value]; });
       } else {
         sfor<0, NC>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          const double gc = bc<(k & 15)>(Gam[k >> 4]) * Cc_[k];  // Gamma_k C[k][r]
-          bc_pipeline<NS>([&](auto I) { return bc<decltype(I)::value>(Cc_[k]); },
+          const double gc = bcr<RQ, (k % LPQ)>(Gam[k / LPQ]) * Cc_[k];  // Gamma_k C[k][r]
+          const Spread<RQ> cks = spread<RQ>(Cc_[k]);
+          bc_pipeline<NS>([&](auto I) { return bcs<RQ, decltype(I)::value>(cks); },
                           [&](auto I, double t) { K[decltype(I)::value] = fma(gc, t, K[decltype(I)::value]); });
         });
       }
@@ -1147,7 +1151,7 @@ struct MpcR16 {
       const double th = thp + r2;
       double gv = r1;
       {
-        const double hsum = bc_dot<0, NX>(Pinv, th);
+        const double hsum = bc_dot<0, NX, RQ>(Pinv, th);
         if (rx) gv = r1 - hsum;
       }
       // inv(Pi_i) joins the record as its lower triangle: rows to the linear image
@@ -1160,24 +1164,24 @@ struct MpcR16 {
           Tr[(rx && cc <= ro) ? kPl + tri_r + cc : kDump] = Pinv[cc];
         });
         c.sync();
-        double Pp[kPFull + 1];
-        sfor<0, kPFull + 1>([&](auto S_) { Pp[decltype(S_)::value] = Tr[kPl + 16 * decltype(S_)::value + r]; });
-        if (16 * kPFull + r >= kPTri) Pp[kPFull] = 0.0;
-        stv<fP, kPFull>(R, Pp);
-        st2(R, fPTh, Pp[kPFull], th);
+        double Pp[nPs + 1];
+        sfor<0, nPs>([&](auto S_) { Pp[decltype(S_)::value] = Tr[kPl + LPQ * decltype(S_)::value + r]; });
+        if (LPQ * (nPs - 1) + r >= kPTri) Pp[nPs - 1] = 0.0;
+        Pp[nPs] = th;
+        stv<fP, nPs + 1>(R, Pp);
       }
       FB_SB();
       FB_STAMP_LAP(2);
       // ---- Lc = chol(K); columns of inv(Lc) and W = [A B] inv(Lc)' (AM and -P of
       // :149-175) from one pass over Lc
       double W[NS];
-      ok = chol_rows<NS>(K, ro, sigma) && ok;
+      ok = chol_rows<NS, RQ>(K, ro, sigma) && ok;
       if (!ok) { lds_off = loff; return false; }
       double XC[NS];
       FB_STAMP_LAP(3);
       FB_SB();
       ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
-      tri_inv_cols_solve<NS>(K, XC, W, ro);
+      tri_inv_cols_solve<NS, RQ>(K, XC, W, ro);
       FB_STAMP_LAP(4);
       FB_SB();
       // columns of inv(Lc) to the linear image of its lower triangle; rows (for t) and
@@ -1194,20 +1198,20 @@ struct MpcR16 {
         const double v = Tr[kXl + tri_r + j];
         XR[j] = j <= ro ? v : 0.0;
       });
-      double Xp[kXFull + 1];
-      sfor<0, kXFull + 1>([&](auto S_) { Xp[decltype(S_)::value] = Tr[kXl + 16 * decltype(S_)::value + r]; });
-      if (16 * kXFull + r >= kXTri) Xp[kXFull] = 0.0;
+      double Xp[nXs + 1];
+      sfor<0, nXs>([&](auto S_) { Xp[decltype(S_)::value] = Tr[kXl + LPQ * decltype(S_)::value + r]; });
+      if (LPQ * (nXs - 1) + r >= kXTri) Xp[nXs - 1] = 0.0;
       FB_SB();
       // t = inv(Lc) g
-      const double tvec = bc_dot<0, NS>(XR, gv);
-      stv<fX, kXFull>(R, Xp);
-      st2(R, fXT, Xp[kXFull], tvec);
+      const double tvec = bc_dot<0, NS, RQ>(XR, gv);
+      Xp[nXs] = tvec;
+      stv<fX, nXs + 1>(R, Xp);
       FB_STAMP_LAP(5);
       FB_SB();
       // theta(i+1) partial = -W t.  (Outside the branch below on purpose: with W used
       // only inside it, the optimiser sinks the W half of the fused solve into the
       // branch and keeps all 120 broadcasts alive for it - 240 registers.)
-      thp = -bc_dot<0, NS>(W, tvec);
+      thp = -bc_dot<0, NS, RQ>(W, tvec);
       if (i < N_) {
         FB_SB();
         // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L).
@@ -1218,23 +1222,25 @@ struct MpcR16 {
         sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = 0.0; });
         sfor<0, NS>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          bc_pipeline<NX>([&](auto I) { return bc<decltype(I)::value>(W[k]); },
+          const Spread<RQ> wks = spread<RQ>(W[k]);
+          bc_pipeline<NX>([&](auto I) { return bcs<RQ, decltype(I)::value>(wks); },
                           [&](auto I, double t) { Pn[decltype(I)::value] = fma(W[k], t, Pn[decltype(I)::value]); });
         });
         sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = rx ? Pn[decltype(Cc)::value] : 0.0; });
         FB_SB();
         FB_STAMP_LAP(7);
-        ok = chol_rows<NX>(Pn, ro, sigma) && ok;
+        ok = chol_rows<NX, RQ>(Pn, ro, sigma) && ok;
         if (!ok) { lds_off = loff; return false; }
         FB_SB();
         double T[NX];
-        tri_inv_cols<NX>(Pn, T, ro);
+        tri_inv_cols<NX, RQ>(Pn, T, ro);
         FB_SB();
         // inv(Pi)[r][cc] = sum_k T[k][r] T[k][cc], T[k][cc] = lane cc's T[k] (zero for k < cc)
         sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
         sfor<0, NX>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          bc_pipeline<k + 1>([&](auto I) { return bc<decltype(I)::value>(T[k]); },
+          const Spread<RQ> tks = spread<RQ>(T[k]);
+          bc_pipeline<k + 1>([&](auto I) { return bcs<RQ, decltype(I)::value>(tks); },
                              [&](auto I, double t) { Pinv[decltype(I)::value] = fma(T[k], t, Pinv[decltype(I)::value]); });
         });
         sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = rx ? Pinv[decltype(Cc)::value] : 0.0; });
@@ -1257,16 +1263,10 @@ struct MpcR16 {
     dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1, handed down by stage i+1
     double lbn = 0.0;
     double Ac[NX];
-    double Xp[kXFull + 1], Pp[kPFull + 1], tq, thq;  // the packed factor record of the stage
+    double Xp[nXs + 1], Pp[nPs + 1];  // the packed factor record of the stage: triangle slots, then t / theta
     auto load_fac = [&](const double* R) {
-      ldv<fX, kXFull>(R, Xp);
-      const dbl2 a = ld2(R, fXT);
-      Xp[kXFull] = a[0];
-      tq = a[1];
-      ldv<fP, kPFull>(R, Pp);
-      const dbl2 b = ld2(R, fPTh);
-      Pp[kPFull] = b[0];
-      thq = b[1];
+      ldv<fX, nXs + 1>(R, Xp);
+      ldv<fP, nPs + 1>(R, Pp);
     };
     BwdIn bin;
     pcur = po[N_];
@@ -1288,7 +1288,7 @@ struct MpcR16 {
       if constexpr (!kStoreGamma) {
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
-          cu.gr[sl] = barrier_terms(cu.vy[sl][0], cu.vy[sl][1], cu.vb[sl], sigma, alpha, r + 16 * sl < NC);
+          cu.gr[sl] = barrier_terms(cu.vy[sl][0], cu.vy[sl][1], cu.vb[sl], sigma, alpha, r + LPQ * sl < NC);
         });
       }
       double Cc_[NC], Hr[NS], AB[NS];
@@ -1297,15 +1297,15 @@ struct MpcR16 {
       // leave take the record of the stage below at once
       const int tri_r = (ro * (ro + 1)) >> 1;
       c.sync();
-      sfor<0, kXFull + 1>([&](auto S_) { Tr[kXl + 16 * decltype(S_)::value + r] = Xp[decltype(S_)::value]; });
-      sfor<0, kPFull + 1>([&](auto S_) { Tr[kPl + 16 * decltype(S_)::value + r] = Pp[decltype(S_)::value]; });
-      const double tcur = tq, thcur = thq;
+      sfor<0, nXs>([&](auto S_) { Tr[kXl + LPQ * decltype(S_)::value + r] = Xp[decltype(S_)::value]; });
+      sfor<0, nPs>([&](auto S_) { Tr[kPl + LPQ * decltype(S_)::value + r] = Pp[decltype(S_)::value]; });
+      const double tcur = Xp[nXs], thcur = Pp[nPs];
       FB_SB();
       load_fac(Rp);
       FB_SB();
       // u = [A B]' dl(i+1) (zero at the terminal stage: lp = 0)
       double lpb[NX];
-      bc_all<NX>(lp, lpb);
+      bc_all<NX, RQ>(lp, lpb);
       const double u = dot4<NX>(Ac, lpb);
       ldv<pABc, NX>(P0 + pcur, Ac);
       c.sync();
@@ -1324,15 +1324,15 @@ struct MpcR16 {
       });
       FB_SB();
       // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
-      const double s = tcur - bc_dot<0, NS>(XR, u);
-      const double dzu = bc_dot<0, NS>(XC, s);
+      const double s = tcur - bc_dot<0, NS, RQ>(XR, u);
+      const double dzu = bc_dot<0, NS, RQ>(XC, s);
       // dl = -inv(Pi)(theta + dx)
       const double tx = thcur + dzu;
-      double dli = -bc_dot<0, NX>(Pinv, tx);
+      double dli = -bc_dot<0, NX, RQ>(Pinv, tx);
       if (!rx) dli = 0.0;
       FB_SB();
       double dzb[NS];  // [dx; du](i), every lane
-      bc_all<NS>(dzu, dzb);
+      bc_all<NS, RQ>(dzu, dzb);
       ldl<pK, NS>(Lp, Hr);
       ldl<pABr, NS>(Lp, AB);
       FB_STAMP_LAP(9);
@@ -1360,7 +1360,7 @@ struct MpcR16 {
       double w;
       {
         double p[4] = {dot4<NS>(Hr, dzb) + (u - dli), 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bc<(decltype(I)::value & 15)>(dvs[decltype(I)::value >> 4]); },
+        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
                         [&](auto I, double t) {
                           constexpr int k = decltype(I)::value;
                           p[k & 3] = fma(Cc_[k], t, p[k & 3]);
@@ -1403,8 +1403,8 @@ struct MpcR16 {
       FB_STAMP_LAP(10);
     }
     lds_off = loff;
-    *trial_inner2 = row_reduce<OpSum16>(s_in);
-    *trial_outer2 = row_reduce<OpSum16>(s_out);
+    *trial_inner2 = qp_reduce<RQ, OpSum16>(s_in);
+    *trial_outer2 = qp_reduce<RQ, OpSum16>(s_out);
     return true;
   }
 };

@@ -64,10 +64,70 @@ FB_DEV double row_reduce(double x) {
   return x;
 }
 
-// Thread context of one 16-lane row (a "virtual workgroup" of 16 threads).
-struct Ctx16 {
-  int tid;  // lane within the row
-  static constexpr int nt = 16;
+// ---- QPs spanning R 16-lane rows of the wavefront --------------------------------
+// R = 1: one QP per DPP row (stage width nx + nu <= 16).  R = 2: an even/odd row
+// pair per QP (width <= 32).  DPP reaches the lanes of a row only; the other row of
+// the pair comes through v_permlane16_swap_b32 (gfx950), which for (x, x) returns
+// the even rows' values replicated into both rows of each pair and the odd rows'
+// likewise (tools/probes/permlane_probe.hip prints the map).  A value that is
+// broadcast from many lanes is "spread" once - two swaps for a double - and every
+// broadcast from it is then the same single v_mov_b64_dpp as for R = 1.
+template <int R>
+struct Spread;
+template <>
+struct Spread<1> {
+  double v;
+};
+template <>
+struct Spread<2> {
+  double lo, hi;  // the even row's and the odd row's values, each present in both rows
+};
+template <int R>
+FB_DEV Spread<R> spread(double x) {
+  if constexpr (R == 1) {
+    return Spread<1>{x};
+  } else {
+    const unsigned xl = __double2loint(x), xh = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+    return Spread<2>{__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1])};
+  }
+}
+// value of lane J of this lane's QP (16 R lanes)
+template <int R, int J>
+FB_DEV double bcs(const Spread<R>& s) {
+  if constexpr (R == 1) return bc<J>(s.v);
+  else if constexpr (J < 16) return bc<J>(s.lo);
+  else return bc<J - 16>(s.hi);
+}
+template <int R, int J>
+FB_DEV double bcr(double x) { return bcs<R, J>(spread<R>(x)); }
+template <int R, int J>
+FB_DEV int bcri(int x) {
+  if constexpr (R == 1) {
+    return bci<J>(x);
+  } else {
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    return J < 16 ? bci<(J & 15)>((int)a[0]) : bci<(J & 15)>((int)a[1]);
+  }
+}
+// all-lanes reduction over the QP: every lane gets the same bits
+template <int R, class Op>
+FB_DEV double qp_reduce(double x) {
+  x = row_reduce<Op>(x);
+  if constexpr (R == 2) {
+    const Spread<2> s = spread<2>(x);
+    x = Op::apply(s.lo, s.hi);
+  }
+  return x;
+}
+
+// Thread context of one QP's lanes (a "virtual workgroup" of 16 R threads).
+template <int R>
+struct CtxRow {
+  int tid;  // lane within the QP
+  static constexpr int nt = 16 * R;
+  static constexpr int rows = R;
   FB_DEV void sync() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
@@ -76,19 +136,15 @@ struct Ctx16 {
   template <int K>
   FB_DEV void sum(double (&v)[K]) const {
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = row_reduce<OpSum16>(v[k]);
+    for (int k = 0; k < K; k++) v[k] = qp_reduce<R, OpSum16>(v[k]);
   }
   template <int K>
   FB_DEV void max(double (&v)[K]) const {
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = row_reduce<OpMax16>(v[k]);
-  }
-  // Number of the wavefront's four rows for which the (row-uniform) predicate
-  // holds; wavefront-uniform.
-  static FB_DEV int rows_where(bool pred) {
-    return __builtin_popcountll(__ballot(pred) & 0x0001000100010001ull);
+    for (int k = 0; k < K; k++) v[k] = qp_reduce<R, OpMax16>(v[k]);
   }
 };
+typedef CtxRow<1> Ctx16;
 
 // Pins the emitted instruction order at this point.  The 64-bit DPP move has a
 // result latency of ~17 cycles while a wave can issue one FP64/DPP instruction
@@ -157,7 +213,7 @@ FB_DEV double rsqrt_full(double d) {
 // Pivot j + 1's dependent chain (broadcast, rsqrt levels, scaling) is issued one
 // level at a time between the rank-1 update instructions of pivot j, which do
 // not depend on it: the chain's latency is covered instead of exposed.
-template <int N>
+template <int N, int R = 1>
 FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
   bool ok = true;
   RsqrtChain ch;
@@ -170,7 +226,7 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
     if constexpr (lv == 0) {
       // the caller's "+ diag_add * I" is applied here, at pivot time: no per-lane
       // (r == j) selects, which the compiler would otherwise hoist and keep live
-      ch.d = bc<j>(a[j]) + diag_add;
+      ch.d = bcr<R, j>(a[j]) + diag_add;
       ok = ok && (ch.d > 0.0);
     } else if constexpr (lv <= RsqrtChain::kStages) {
       ch.template stage<lv - 1>();
@@ -185,10 +241,11 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int cnt = N - j - 1;
-    const double ljj = lj, nljj = nlj;  // this pivot's column (lj is rewritten by level 6)
+    const double nljj = nlj;  // this pivot's column (lj is rewritten by level 6)
+    const Spread<R> ljs = spread<R>(lj);
     // column j + 1 first: the next pivot's chain hangs on it
     bc_pipeline<cnt>(
-        [&](auto I) { return bc<j + 1 + decltype(I)::value>(ljj); },
+        [&](auto I) { return bcs<R, j + 1 + decltype(I)::value>(ljs); },
         [&](auto I, double t) {
           constexpr int i = decltype(I)::value;
           a[j + 1 + i] = fma(nljj, t, a[j + 1 + i]);
@@ -208,18 +265,19 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
 // Column r of inv(L) for the row-held factor of chol_rows (a[k] = L[r][k],
 // a[r] = 1/L[r][r]).  Column-oriented: once x[k] is known it is folded into every
 // later row's sum, so only one FMA and one multiply per row sit on the chain.
-template <int N>
+template <int N, int R = 1>
 FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
   sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
-  double dg = bc<0>(a[0]);  // 1 / L[k][k], fetched one column ahead
+  double dg = bcr<R, 0>(a[0]);  // 1 / L[k][k], fetched one column ahead
   sfor<0, N>([&](auto K) {
     constexpr int k = decltype(K)::value;
     if constexpr (k == 0) x[0] *= dg;
     const double nx = -x[k];
-    if constexpr (k + 1 < N) dg = bc<k + 1>(a[k + 1]);
+    if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
+    const Spread<R> aks = spread<R>(a[k]);
     FB_SB();
     bc_pipeline<N - k - 1>(
-        [&](auto I) { return bc<k + 1 + decltype(I)::value>(a[k]); },
+        [&](auto I) { return bcs<R, k + 1 + decltype(I)::value>(aks); },
         [&](auto I, double t) {
           constexpr int i = decltype(I)::value;
           x[k + 1 + i] = fma(t, nx, x[k + 1 + i]);
@@ -237,10 +295,10 @@ FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
 // Both recurrences consume the same broadcasts L[m][k], so the product
 // B inv(Lc)' costs one more FMA per broadcast instead of a broadcast-FMA pair of
 // its own per element.
-template <int N>
+template <int N, int R = 1>
 FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)[N], int r) {
   sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
-  double dg = bc<0>(a[0]);  // 1 / L[k][k], fetched one column ahead
+  double dg = bcr<R, 0>(a[0]);  // 1 / L[k][k], fetched one column ahead
   sfor<0, N>([&](auto K) {
     constexpr int k = decltype(K)::value;
     if constexpr (k == 0) {
@@ -248,10 +306,11 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
       w[0] *= dg;
     }
     const double nx = -x[k], nw = -w[k];
-    if constexpr (k + 1 < N) dg = bc<k + 1>(a[k + 1]);
+    if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
+    const Spread<R> aks = spread<R>(a[k]);
     FB_SB();
     bc_pipeline<N - k - 1>(
-        [&](auto I) { return bc<k + 1 + decltype(I)::value>(a[k]); },
+        [&](auto I) { return bcs<R, k + 1 + decltype(I)::value>(aks); },
         [&](auto I, double t) {
           constexpr int i = decltype(I)::value;
           x[k + 1 + i] = fma(t, nx, x[k + 1 + i]);
@@ -267,10 +326,11 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
 
 // acc = sum_c m[c] * (lane c's v), c in [B, E): four partial sums so that the
 // FMAs do not form one dependent chain.
-template <int B, int E, int N>
+template <int B, int E, int R = 1, int N>
 FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
   double p[4] = {init, 0.0, 0.0, 0.0};
-  bc_pipeline<E - B>([&](auto I) { return bc<B + decltype(I)::value>(v); },
+  const Spread<R> vs = spread<R>(v);
+  bc_pipeline<E - B>([&](auto I) { return bcs<R, B + decltype(I)::value>(vs); },
                      [&](auto I, double t) {
                        constexpr int i = decltype(I)::value;
                        p[i & 3] = fma(m[B + i], t, p[i & 3]);
@@ -279,9 +339,10 @@ FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
 }
 
 // out[c] = lane c's v, c in [0, N)
-template <int N>
+template <int N, int R = 1>
 FB_DEV void bc_all(double v, double (&out)[N]) {
-  sfor<0, N>([&](auto Cc) { out[decltype(Cc)::value] = bc<decltype(Cc)::value>(v); });
+  const Spread<R> vs = spread<R>(v);
+  sfor<0, N>([&](auto Cc) { out[decltype(Cc)::value] = bcs<R, decltype(Cc)::value>(vs); });
   FB_SB();
 }
 // sum_c m[c] * b[c], c in [0, N), four partial sums

@@ -182,9 +182,9 @@ struct R16Queue {
   bool reuse;
   bool taken = false;  // (KEEP) this row has had its one QP
 
-  static __device__ __forceinline__ int tid() { return threadIdx.x & 15; }
-  static __device__ __forceinline__ int row() { return threadIdx.x >> 4; }
-  static __device__ __forceinline__ int home() { return blockIdx.x * 4 + row(); }
+  static __device__ __forceinline__ int tid() { return threadIdx.x & (P::LPQ - 1); }
+  static __device__ __forceinline__ int row() { return threadIdx.x / P::LPQ; }  // QP slot of the wavefront
+  static __device__ __forceinline__ int home() { return blockIdx.x * P::kQpPerWave + row(); }
   static __device__ __forceinline__ lds_ptr lds() {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
     return (lds_ptr)smem_ + row() * P::kLdsPerRow;
@@ -195,7 +195,7 @@ struct R16Queue {
   // the row's table of matrix-copy offsets, behind the four row regions
   __device__ __forceinline__ typename P::lds_iptr lpo() const {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
-    return (typename P::lds_iptr)((lds_ptr)smem_ + 4 * P::kLdsPerRow) + row() * P::lpo_ints(N);
+    return (typename P::lds_iptr)((lds_ptr)smem_ + P::kQpPerWave * P::kLdsPerRow) + row() * P::lpo_ints(N);
   }
   __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
 
@@ -208,7 +208,7 @@ struct R16Queue {
       taken = true;
     } else {
       if (tid() == 0) q = atomicAdd(&ctl[0], 1);
-      q = bci<0>(q);
+      q = bcri<P::LPQ / 16, 0>(q);
     }
     if (q >= batch) return -1;
     pp.bind(slot_ptr(home()), lds(), lpo(), data, x, q, N, tid());
@@ -219,18 +219,18 @@ struct R16Queue {
 
 // KEEP (FBSTAB_HIP_KEEP_MATRICES): QP q is solved in slot q, so that the slot's
 // matrix copies survive from call to call; `reuse` says they are valid already.
-template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false>
+template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false, int R = 1>
 __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
     int* counter, int batch, int N, int reuse, double* dbg) {
-  typedef MpcR16<NX, NU, NC, EXACT, KEEP> P;
+  typedef MpcR16<NX, NU, NC, EXACT, KEEP, R> P;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 #if defined(FB_ANY_STAMP)
   const long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
 #endif
   const int lane = threadIdx.x;
-  Ctx16 ctx;
-  ctx.tid = lane & 15;
+  typename P::C ctx;
+  ctx.tid = lane & (P::LPQ - 1);
   P p;
   R16Queue<P, KEEP> qu;
   qu.data = &data;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
   if constexpr (DBG) {
     if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
-    Solver<P, Ctx16> solver(p, ctx, opts);
+    Solver<P, typename P::C> solver(p, ctx, opts);
     solver.solve_stream(qu, out);
   }
 #if defined(FB_ANY_STAMP)
@@ -568,27 +568,29 @@ struct fbstab_mpc_solver : SolverBase {
 };
 
 namespace {
-template <int NX, int NU, int NC>
-long long r16_ws_doubles(int N) { return fbk::MpcR16<NX, NU, NC>::ws_doubles(N); }
-template <int NX, int NU, int NC>
+template <int NX, int NU, int NC, int R>
+long long r16_ws_doubles(int N) { return fbk::MpcR16<NX, NU, NC, true, false, R>::ws_doubles(N); }
+template <int NX, int NU, int NC, int R>
 int r16_lds_bytes(int N) {
-  typedef fbk::MpcR16<NX, NU, NC> R;
-  return 4 * R::kLdsPerRow * (int)sizeof(double) + 4 * R::lpo_ints(N) * (int)sizeof(int);
+  typedef fbk::MpcR16<NX, NU, NC, true, false, R> P;
+  return P::kQpPerWave * (P::kLdsPerRow * (int)sizeof(double) + P::lpo_ints(N) * (int)sizeof(int));
 }
-template <int NX, int NU, int NC>
+// R: 16-lane rows of the wavefront per QP (1: four QPs per wavefront, stage width
+// <= 16; 2: two QPs per wavefront, stage width <= 32)
+template <int NX, int NU, int NC, int R = 1>
 RecordInstance r16_instance(const char* name) {
   RecordInstance r;
   r.name = name;
   r.nx = NX; r.nu = NU; r.nc = NC;
-  r.qps_per_wg = 4;
-  r.lds_bytes = r16_lds_bytes<NX, NU, NC>;
-  r.ws_doubles = r16_ws_doubles<NX, NU, NC>;
-  r.solve = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, false, false>);
-  r.solve_keep = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, false, true>);
-  r.probe = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, true, false, false>);
-  r.solve_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, true, false>);
-  r.solve_keep_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, true, true>);
-  r.probe_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, true, true, false>);
+  r.qps_per_wg = 4 / R;
+  r.lds_bytes = r16_lds_bytes<NX, NU, NC, R>;
+  r.ws_doubles = r16_ws_doubles<NX, NU, NC, R>;
+  r.solve = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, false, false, R>);
+  r.solve_keep = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, false, true, R>);
+  r.probe = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, true, false, false, R>);
+  r.solve_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, true, false, R>);
+  r.solve_keep_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, false, true, true, R>);
+  r.probe_exact = reinterpret_cast<const void*>(fbstab_mpc_r16_kernel<NX, NU, NC, true, true, false, R>);
   return r;
 }
 // The record-kernel instances compiled into the library, smallest first: a shape
@@ -596,6 +598,9 @@ RecordInstance r16_instance(const char* name) {
 const RecordInstance* record_instances(int* count) {
   static const RecordInstance table[] = {
       r16_instance<12, 4, 20>("fbstab_mpc_r16_kernel<12,4,20>"),
+      // two 16-lane rows per QP: 16 < nx + nu <= 23 (the reference's copolymerization
+      // reactor, nx = 18, nu = 5, nc = 10: fbstab/test/ocp_generator.cc:73-174)
+      r16_instance<18, 5, 10, 2>("fbstab_mpc_r32_kernel<18,5,10>"),
   };
   *count = (int)(sizeof(table) / sizeof(table[0]));
   return table;
