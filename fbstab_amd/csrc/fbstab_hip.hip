@@ -369,6 +369,30 @@ __global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_kernel(Den
   }
 }
 
+// Diagnostic probe for the dense path (tests only): one Newton step at (x, xbar,
+// sigma0) for QP 0 of the batch arrays, see newton_probe.
+template <int NT>
+__global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_probe_kernel(DenseLayout lay, DenseBatchArgs data,
+                                                                                VarBatchArgs x,
+                                                                                fbstab_options_t opts, double* dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  lds_ptr lds = (lds_ptr)smem;
+  typedef Ctx<NT> C;
+  C ctx;
+  ctx.tid = threadIdx.x;
+  ctx.red = lds + lay.o_red;
+  DenseData D;
+  D.H = data.base[FBSTAB_DENSE_H];
+  D.f = data.base[FBSTAB_DENSE_f];
+  D.G = data.base[FBSTAB_DENSE_G];
+  D.h = data.base[FBSTAB_DENSE_h];
+  D.A = data.base[FBSTAB_DENSE_A];
+  D.b = data.base[FBSTAB_DENSE_b];
+  DenseProblem<C, false> p;
+  p.bind(lay, D, x.base[0], x.base[1], x.base[2], x.base[3], lds, nullptr);
+  newton_probe(p, ctx, opts, dbg);
+}
+
 // ---------------------------------------------------------------------------
 thread_local std::string g_error;
 
@@ -1218,6 +1242,57 @@ int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t h, const fbstab_dense_ba
   rc = dense_solve_impl(h, 1, data, x, out, FBSTAB_HIP_HOST_POINTERS, nullptr, tb.dev());
   if (rc != FBSTAB_HIP_OK) return rc;
   return tb.close(trace, capacity, count);
+}
+
+// Diagnostics for the tests: one Newton step of the dense device path
+// (DenseCholeskySolver::Initialize + Solve, dense_cholesky_solver.cc:32-127) at
+// (x, xbar, sigma0) for ONE QP given by host pointers; io as in
+// fbstab_hip_mpc_debug_newton.  K in LDS only (nz + nl up to ~140).
+int fbstab_hip_dense_debug_newton(fbstab_dense_handle_t h, const fbstab_dense_batch_t* data,
+                                  const fbstab_var_batch_t* x, double* io) {
+  if (!h || !data || !x || !io) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
+  if (h->lay.k_global) return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "dense probe: K must fit the LDS");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = h->ensure_staging();
+  if (rc != FBSTAB_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  DenseBatchArgs a;
+  VarBatchArgs v;
+  for (int i = 0; i < FBSTAB_DENSE_NARR; i++) {
+    rc = h->upload(data->base[i], h->arr_len[i], h->arr_len[i], 1, h->d_arr[i], &a.stride[i], s);
+    if (rc != FBSTAB_HIP_OK) return rc;
+    a.base[i] = h->d_arr[i];
+  }
+  for (int i = 0; i < 4; i++) {
+    long long st;
+    if (i < 3) {
+      rc = h->upload(x->base[i], h->var_len[i], h->var_len[i], 1, h->d_var[i], &st, s);
+      if (rc != FBSTAB_HIP_OK) return rc;
+    }
+    v.base[i] = h->d_var[i];
+    v.stride[i] = h->var_len[i];
+  }
+  const fbk::DenseLayout& L = h->lay;
+  const size_t n_io = (size_t)(3 * L.nz + 3 * L.nl + 2 * L.nv + 1);
+  DevBuf d_io_buf;
+  HIP_TRY(hipMalloc(&d_io_buf.p, n_io * sizeof(double)));
+  double* d_io = static_cast<double*>(d_io_buf.p);
+  HIP_TRY(hipMemcpyAsync(d_io, io, sizeof(double) * (L.nz + L.nl + L.nv), hipMemcpyHostToDevice, s));
+  if (h->threads == 64) {
+    auto kern = fbstab_dense_probe_kernel<64>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                h->lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(64), h->lds_bytes, s, h->lay, a, v, h->opts, d_io);
+  } else {
+    auto kern = fbstab_dense_probe_kernel<kDenseThreads>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                h->lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kDenseThreads), h->lds_bytes, s, h->lay, a, v, h->opts, d_io);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(io, d_io, sizeof(double) * n_io, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FBSTAB_HIP_OK;
 }
 
 double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t h) { return h ? h->last_kernel_ms() : -1.0; }

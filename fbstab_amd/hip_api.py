@@ -138,7 +138,7 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
     "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_traced",
-    "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
+    "fbstab_hip_dense_debug_newton", "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
 
 
 class FBstabHipError(RuntimeError):
@@ -425,6 +425,42 @@ class FBstabDenseBatch(_SolverBase):
         return self._solve(_DenseBatch(), DENSE_ARR, self.arr_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
                            stream, async_)
+
+    def debug_newton(self, data, z, l, v, zb, lb, vb):
+        """Tests only: one Newton step of the dense device path at (x, xbar, sigma0,
+        alpha of the current options) for ONE QP (numpy arrays).  Returns
+        dict(dz, dl, dv, adz, wz, wl, rz, rl, ok)."""
+        lib = self._lib
+        lib.fbstab_hip_dense_debug_newton.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        b = _DenseBatch()
+        keep = []
+        for i, k in enumerate(DENSE_ARR):
+            a = np.ascontiguousarray(np.asarray(data[k], dtype=np.float64).reshape(-1))
+            if a.size == 0:
+                a = np.zeros(1)
+            keep.append(a)
+            b.base[i] = a.ctypes.data
+            b.stride[i] = a.size
+        vb_ = _VarBatch()
+        xs = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1)) for a in (z, l, v)]
+        xs.append(np.zeros(self.nv))
+        for i, a in enumerate(xs):
+            if a.size == 0:
+                a = xs[i] = np.zeros(1)
+            vb_.base[i] = a.ctypes.data
+            vb_.stride[i] = a.size
+        nz, nl, nv = self.nz, self.nl, self.nv
+        io = np.zeros(3 * nz + 3 * nl + 2 * nv + 1)
+        io[:nz + nl + nv] = np.concatenate([np.ravel(zb), np.ravel(lb), np.ravel(vb)])
+        _check(lib, lib.fbstab_hip_dense_debug_newton(self._h, C.byref(b), C.byref(vb_), io.ctypes.data))
+        names = ("dz", "dl", "dv", "adz", "wz", "wl", "rz", "rl")
+        sizes = (nz, nl, nv, nv, nz, nl, nz, nl)
+        out, o = {}, 0
+        for n, sz in zip(names, sizes):
+            out[n] = io[o:o + sz].copy()
+            o += sz
+        out["ok"] = bool(io[o] > 0.5)
+        return out
 
     def SolveTraced(self, data, z, l, v, y, capacity: int = 4096):
         """One QP (``(1, n)`` numpy arrays) with the reference's per-iteration

@@ -213,6 +213,11 @@ int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t handle, int batch,
 int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t handle, const fbstab_dense_batch_t* data,
                                   const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
                                   fbstab_trace_record_t* trace, int capacity, int* count);
+/* As fbstab_hip_mpc_debug_newton, for the dense path (DenseCholeskySolver::Initialize +
+ * Solve, dense_cholesky_solver.cc:32-127).  io: [zbar, lbar, vbar] in,
+ * [dz, dl, dv, A*dz, W_z, W_l, r_z, r_l, ok] out. */
+int fbstab_hip_dense_debug_newton(fbstab_dense_handle_t handle, const fbstab_dense_batch_t* data,
+                                  const fbstab_var_batch_t* x, double* io);
 double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t handle);
 int fbstab_hip_dense_query(fbstab_dense_handle_t handle, long long* scratch_bytes,
                            int* lds_bytes, int* workgroups, int* threads);

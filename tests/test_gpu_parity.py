@@ -983,3 +983,30 @@ def test_reactor_shape_runs_on_the_two_row_record_kernel(hip, oracle):
     gpu = _solve_mpc_host(hip, p, o)
     cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
     _assert_parity(gpu, cpu, o.abs_tol)
+
+
+@pytest.mark.parametrize("shape", [(50, 10, 100), (20, 5, 40), (30, 20, 64), (64, 0, 128)])
+def test_dense_newton_step_matches_oracle(hip, oracle, shape):
+    """One Newton step of the dense device path (K assembly on the matrix cores,
+    pivoted LDL' on register-held rows for nz + nl <= 64, substitutions) against the
+    oracle's DenseCholeskySolver (Eigen's pivoted LDLT restated,
+    dense_cholesky_solver.cc:32-127) at a random point, sigma = 1, 1e-4 and 1e-8."""
+    nz, nl, nv = shape
+    p = fx.synthetic_dense_batch(1, nz, nl, nv, first_id=123)
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=1)
+    rng = np.random.default_rng(9)
+    z, l = rng.standard_normal(nz), rng.standard_normal(nl)
+    v = np.abs(rng.standard_normal(nv))
+    zb, lb, vb = 0.5 * z, 0.5 * l, 0.5 * v
+    for sigma, tol in ((1.0, 1e-12), (1e-4, 1e-10), (1e-8, 1e-7)):
+        s.UpdateOptions(hip.DefaultOptions(sigma0=sigma, sigma_max=100.0))
+        g = s.debug_newton({k: a[0] for k, a in p.arrays.items()}, z, l, v, zb, lb, vb)
+        assert g["ok"]
+        pr = oracle.probe(p, z, l, v, zb, lb, vb, sigma)
+        np.testing.assert_allclose(g["rz"], pr["natural"][:nz], atol=1e-11 * (1 + np.abs(pr["natural"]).max()))
+        pr = oracle.probe(p, z, l, v, zb, lb, vb, sigma, r=-pr["inner"], want_dx=True)
+        odz, odl, odv, ody = np.split(pr["dx"], [nz, nz + nl, nz + nl + nv])
+        for a_, b_ in ((g["dz"], odz), (g["dl"], odl), (g["dv"], odv)):
+            if b_.size:
+                assert np.abs(a_ - b_).max() <= tol * (1 + np.abs(b_).max()), (sigma, np.abs(a_ - b_).max())
+    s.close()
