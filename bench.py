@@ -342,7 +342,9 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
          "steps_in_flight": lanes, "kernel_ms": k_ms, "serial_value": batch / (k_ms * 1e-3),
          "mean_newton_iters": float(outs[0]["newton_iters"].mean()), "all_converged": ok,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "fbstab_dense_kernel",
+                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                      "kernel": "fbstab_dense_wave_kernel" if L[0]["s"].query()["threads"] == 64
+                      else "fbstab_dense_kernel",
                       "algorithmic_bytes_per_launch": DENSE_ALG_BYTES_PER_QP * batch},
          "launch": L[0]["s"].query()}
     for ln in L:

@@ -1,0 +1,603 @@
+// One-wavefront dense policy: ONE 64-lane wavefront owns one dense QP
+//   min 1/2 z'Hz + f'z  s.t. Gz = h, Az <= b      (fbstab/fbstab_dense.h:55-64)
+// with nz + nl <= 64, for EVERY phase of the solve, so that eight QPs are in
+// flight on a CU (two wavefronts per SIMD) and hide each other's latencies.
+// The four-wavefront policy of fb_dense.h keeps K, A and the iterates of a QP
+// in 80 KB of LDS: two QPs per CU, and three of its four wavefronts wait at a
+// barrier while the first one factors.  Here a QP holds ~19 KB of LDS:
+//
+//   * the KKT matrix  K = [H + sigma I + A'Gamma A  G'; G  -sigma I]
+//     (dense_cholesky_solver.cc:52-69) lives in REGISTERS, lane t holding row t
+//     of the full symmetric matrix (64 doubles);
+//   * A' Gamma A is accumulated on the matrix cores (v_mfma_f64_16x16x4, the ten
+//     16x16 tiles of the lower triangle), operands read from a transposed copy
+//     of A in global scratch (At[j + k nz]: every operand load and every A'x
+//     product is coalesced); the tiles reach the row layout through a 64 x 16
+//     staging panel in LDS, one column block at a time;
+//   * the pivoted LDL' (Eigen::LDLT's rule: largest |diagonal| of what is left,
+//     the first maximum wins; dense_cholesky_solver.cc:70-79) eliminates in
+//     place without swapping anything: the pivot row goes to LDS once, every
+//     lane reads its own entry of it (the multiplier column, by symmetry) and
+//     the row itself as 16-byte broadcasts.  The multipliers of step k go to a
+//     64 x 64 global scratch (row k, lane t: one coalesced store per pivot) from
+//     where both substitutions read them back, loads issued eight steps ahead;
+//   * right-hand side and solution of the substitutions stay in a register
+//     (lane t owns entry t), solved entries are handed round by v_readlane.
+//
+// Reference code answered to: DenseData products (dense_data.cc:12-41),
+// DenseCholeskySolver::Initialize / Solve (dense_cholesky_solver.cc:32-127),
+// FullFeasibility::CheckFeasibility (full_feasibility.cc:25-88).  Same
+// factorisation as Eigen's up to rounding (right-looking here, left-looking
+// there; the pivot order is the same rule).
+#pragma once
+
+#include <float.h>
+
+#include "fb_dense.h"
+#include "fb_row16.h"  // dpp_mov
+
+namespace fbk {
+
+#if !defined(FB_HOSTSIM)
+
+struct DenseWaveLayout {
+  static constexpr int kLd = 17;  // leading dimension of the staging panel (odd: rows hit different banks)
+  int nz, nl, nv, nk;
+  // LDS carve (offsets in doubles)
+  int o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz, o_rz, o_rl, o_wz, o_wl,
+      o_gam, o_rvm, o_rowbuf, o_stage, lds_doubles;
+  // global scratch of one workgroup (doubles): A' and the multipliers
+  long o_at, o_lg, ws_doubles;
+
+  __host__ __device__ void init(int nz_, int nl_, int nv_) {
+    nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
+    int s = 0;
+    o_z = s; s += nz;  o_l = s; s += nl;  o_v = s; s += nv;  o_y = s; s += nv;
+    o_zb = s; s += nz; o_lb = s; s += nl; o_vb = s; s += nv; o_yb = s; s += nv;
+    o_dz = s; s += nz; o_dl = s; s += nl; o_dv = s; s += nv; o_adz = s; s += nv;
+    o_rz = s; s += nz; o_rl = s; s += nl; o_wz = s; s += nz; o_wl = s; s += nl;
+    o_gam = s; s += nv; o_rvm = s; s += nv;
+    s = (s + 1) & ~1;
+    o_rowbuf = s; s += 64;
+    o_stage = s; s += 64 * kLd;
+    lds_doubles = (s + 1) & ~1;
+    o_at = 0;
+    o_lg = ((long)nv * nz + 15) & ~15L;
+    ws_doubles = o_lg + 64 * 64;
+  }
+  // nz + nl <= 64 and the iterate vectors fit a share of the LDS that leaves room
+  // for at least four workgroups per CU
+  __host__ __device__ bool fits() const { return nk <= 64 && nk >= 1 && (long)lds_doubles * 8 <= 40 * 1024; }
+};
+
+struct DenseWave {
+  typedef Ctx<64> C;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  static constexpr bool kFusedTrial = false;    // see fb_algorithm.h
+  static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat LDS vectors below
+  static constexpr int LD = DenseWaveLayout::kLd;
+  DenseWaveLayout lay;
+  DenseData D;
+  double *uz, *ul, *uv, *uy;
+  double *At, *Lg;  // global scratch: A' (At[j + k nz] = A[k][j]) and the multipliers Lg[64 k + t]
+  int nz, nl, nv;
+  lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
+  lds_ptr gam, rvm, rowbuf, stage;
+
+  FB_DEV void bind(const DenseWaveLayout& L_, const DenseData& D_, double* uz_, double* ul_, double* uv_,
+                   double* uy_, lds_ptr lds, double* ws) {
+    lay = L_; D = D_; uz = uz_; ul = ul_; uv = uv_; uy = uy_;
+    nz = lay.nz; nl = lay.nl; nv = lay.nv;
+    z = lds + lay.o_z; l = lds + lay.o_l; v = lds + lay.o_v; y = lds + lay.o_y;
+    zb = lds + lay.o_zb; lb = lds + lay.o_lb; vb = lds + lay.o_vb; yb = lds + lay.o_yb;
+    dz = lds + lay.o_dz; dl = lds + lay.o_dl; dv = lds + lay.o_dv; adz = lds + lay.o_adz;
+    rz = lds + lay.o_rz; rl = lds + lay.o_rl; wz = lds + lay.o_wz; wl = lds + lay.o_wl;
+    gam = lds + lay.o_gam; rvm = lds + lay.o_rvm;
+    rowbuf = lds + lay.o_rowbuf; stage = lds + lay.o_stage;
+    At = ws + lay.o_at;
+    Lg = ws + lay.o_lg;
+  }
+
+  // The wavefront's own global stores (At, Lg) become visible to its other lanes:
+  // one L1 serves the whole CU and is written through, what is needed is that the
+  // stores have left the wavefront (s_waitcnt vmcnt(0)).
+  static FB_DEV void global_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+
+  // sum_k M[i + k m] x[k], k < n: row i of a column-major matrix with m rows (lanes
+  // i, i+1, ... read consecutive words) times an LDS vector (broadcast reads).  Two
+  // wavefronts per SIMD do not hide a trip to L2: the loads go out U at a time.
+  template <int U = 16>
+  static FB_DEV double row_dot(const double* M, int m, int n, int i, lds_ptr x) {
+    const double* p = M + i;
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + U <= n; k += U) {
+      double a[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) a[u] = p[(long)(k + u) * m];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (u & 1) s1 = fma(a[u], x[k + u], s1);
+        else s0 = fma(a[u], x[k + u], s0);
+      }
+    }
+    if (k < n) {  // remainder: clamped loads, zero weights
+      double a[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) a[u] = p[(long)(k + u < n ? k + u : n - 1) * m];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const double w = k + u < n ? x[k + u < n ? k + u : n - 1] : 0.0;
+        if (u & 1) s1 = fma(a[u], w, s1);
+        else s0 = fma(a[u], w, s0);
+      }
+    }
+    return s0 + s1;
+  }
+  // sum_k M[k + j m] x[k], k < m: column j (only used for the small G, nl rows)
+  static FB_DEV double col_dot(const double* M, int m, int j, lds_ptr x) {
+    const double* col = M + (long)j * m;
+    double s = 0.0;
+    for (int k = 0; k < m; k++) s = fma(col[k], x[k], s);
+    return s;
+  }
+  FB_DEV double A_row_dot(int i, lds_ptr x) const { return row_dot(D.A, nv, nz, i, x); }   // (A x)_i
+  FB_DEV double A_col_dot(int j, lds_ptr x) const { return row_dot(At, nz, nv, j, x); }    // (A'x)_j
+
+  FB_DEV double forcing_norm(const C& c) const {  // dense_data.h:72-73
+    double s[1] = {0.0};
+    for (int i = c.tid; i < nz; i += 64) s[0] += D.f[i] * D.f[i];
+    for (int i = c.tid; i < nl; i += 64) s[0] += D.h[i] * D.h[i];
+    for (int i = c.tid; i < nv; i += 64) s[0] += D.b[i] * D.b[i];
+    c.sum(s);
+    return sqrt(s[0]);
+  }
+  FB_DEV int num_primal_dual() const { return nz + nl + nv; }
+  FB_DEV double bvec(int i) const { return D.b[i]; }
+
+  // x <- caller's guess, the transposed copy of A, y = b - A z (impl:334-347,
+  // full_variable.cc:47-53)
+  FB_DEV void load_guess(const C& c) const {
+    FB_WAVE_TIMER(9);
+    for (int i = c.tid; i < nz; i += 64) z[i] = uz[i];
+    for (int i = c.tid; i < nl; i += 64) l[i] = ul[i];
+    for (int i = c.tid; i < nv; i += 64) v[i] = uv[i];
+    for (int k0 = 0; k0 < nv; k0 += 64) {  // (ten columns' loads in flight, then their stores)
+      const int k = k0 + c.tid;
+      const int kc = k < nv ? k : nv - 1;
+      for (int j0 = 0; j0 < nz; j0 += 10) {
+        double a[10];
+#pragma unroll
+        for (int u = 0; u < 10; u++) a[u] = D.A[kc + (long)(j0 + u < nz ? j0 + u : nz - 1) * nv];
+#pragma unroll
+        for (int u = 0; u < 10; u++)
+          if (k < nv && j0 + u < nz) At[(j0 + u) + (long)k * nz] = a[u];
+      }
+    }
+    global_fence();
+    c.sync();
+    for (int i = c.tid; i < nv; i += 64) y[i] = D.b[i] - A_row_dot(i, z);
+    c.sync();
+  }
+
+  // rz = Hz + f + G'l + A'v ; rl = h - Gz (full_residual.cc:79-91)
+  FB_DEV void residual(const C& c) const {
+    FB_WAVE_TIMER(15);
+    const int i = c.tid;
+    if (i < nz) {
+      rz[i] = D.f[i] + row_dot(D.H, nz, nz, i, z) + col_dot(D.G, nl, i, l) + A_col_dot(i, v);
+    } else if (i < nz + nl) {
+      const int j = i - nz;
+      rl[j] = D.h[j] - row_dot(D.G, nl, nz, j, z);
+    }
+    c.sync();
+  }
+
+  FB_DEV int feasibility(const C& c, double tol) const {  // full_feasibility.cc:25-88
+    FB_WAVE_TIMER(16);
+    double mx[5] = {-1e300, 0.0, 0.0, 0.0, 0.0};
+    double sm[2] = {0.0, 0.0};
+    double ul_[1] = {0.0};
+    const int i = c.tid;
+    if (i < nz) {
+      mx[2] = fabs(row_dot(D.H, nz, nz, i, dz));
+      mx[3] = fabs(dz[i]);
+      mx[4] = fabs(A_col_dot(i, dv) + col_dot(D.G, nl, i, dl));
+      sm[0] = D.f[i] * dz[i];
+    } else if (i < nz + nl) {
+      const int j = i - nz;
+      mx[1] = fabs(row_dot(D.G, nl, nz, j, dz));
+      ul_[0] = fabs(dl[j]);
+      sm[1] = D.h[j] * dl[j];
+    }
+    for (int j = c.tid; j < nv; j += 64) {
+      mx[0] = fmax(mx[0], A_row_dot(j, dz));
+      ul_[0] = fmax(ul_[0], fabs(dv[j]));
+      sm[1] += D.b[j] * dv[j];
+    }
+    c.max(mx);
+    c.sum(sm);
+    c.max(ul_);
+    const double d1 = mx[0], d2 = mx[1], d3 = mx[2], w = mx[3], p1 = mx[4];
+    const double d4_ = sm[0], p2 = sm[1], u = ul_[0];
+    bool dual_feasible = true, primal_feasible = true;
+    if ((d1 <= w * tol) && (d2 <= tol * w) && (d3 <= tol * w) && (d4_ < 0) && (w > 1e-14))
+      dual_feasible = false;
+    if ((p1 <= tol * u) && (p2 < 0)) primal_feasible = false;
+    if (primal_feasible && dual_feasible) return kFeasible;
+    if (primal_feasible && !dual_feasible) return kDualInfeasible;
+    if (!primal_feasible && dual_feasible) return kPrimalInfeasible;
+    return kBothInfeasible;
+  }
+
+  static FB_DEV double lane_of(double x, int p) {  // x of lane p (p wavefront-uniform)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), p),
+                            __builtin_amdgcn_readlane(__double2loint(x), p));
+  }
+
+  // ---- K into registers -----------------------------------------------------------
+  // Kr[c] = K[t][c] for this lane's row t, dg = K[t][t].  E = H + sigma I + A'Gamma A
+  // is taken from its lower triangle (what the reference assembles and Eigen's LDLT
+  // reads), mirrored, so that the rows held here are exactly symmetric.
+  static constexpr int tile_of(int I, int J) { return I * (I + 1) / 2 + J; }  // I >= J
+  // (Lane id and sizes made opaque per call: everything below that depends on them
+  // only - 64 columns' worth of masks, addresses and even the H and G entries - is
+  // invariant over the whole solve, and the optimiser would otherwise hoist all of
+  // it out of the Newton loop and spill it: 1000 registers.)
+  FB_DEV void assemble(const C& c, double sigma, double (&Kr)[64], double* dg_out, double* atr_out) const {
+    int t = c.tid;
+    int nz = this->nz, nl = this->nl, nv = this->nv;
+    asm volatile("" : "+v"(t), "+s"(nz), "+s"(nl), "+s"(nv));
+    const int kq = t >> 4, ij = t & 15;
+    const int nt16 = (nz + 15) >> 4;
+    int col[4];
+#pragma unroll
+    for (int I = 0; I < 4; I++) col[I] = 16 * I + ij < nz ? 16 * I + ij : nz - 1;  // padded columns re-read the last one
+    // the accumulators start from H + sigma I (lower triangle; what lies above the
+    // diagonal or past nz is never used): lane l, register q <-> entry
+    // (16 I + l/16 + 4 q, 16 J + l%16) of tile (I, J)
+    d4 acc[10];
+#pragma unroll
+    for (int I = 0; I < 4; I++) {
+#pragma unroll
+      for (int J = 0; J <= I; J++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int r = 16 * I + kq + 4 * q;
+          const int rr = r < nz ? r : nz - 1;
+          double h = 0.0;
+          if (I < nt16) h = D.H[rr + (long)col[J] * nz];
+          if (I == J && kq + 4 * q == ij) h += sigma;
+          acc[tile_of(I, J)][q] = h;
+        }
+      }
+    }
+    // A operand of tile row I: lane l holds A[k0 + l/16][16 I + l%16]; B operand of
+    // tile column J: the same entry of block column J times Gamma (rows past nv: 0).
+    // KU steps' operands are requested together.  The same operands give A' (rv/mu)
+    // of the right-hand side (dense_cholesky_solver.cc:98-100): lane (kq, ij) sums
+    // the rows k = kq mod 4 of column 16 I + ij, the four partial sums meet below.
+    constexpr int KU = 5;
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < nv; k0 += 4 * KU) {
+      double a[KU][4], g[KU], rm[KU];
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        const int kk = k0 + 4 * u + kq;
+        const int kc = kk < nv ? kk : nv - 1;
+        const double* row = At + (long)kc * nz;
+#pragma unroll
+        for (int I = 0; I < 4; I++) a[u][I] = row[col[I]];
+        g[u] = kk < nv ? gam[kc] : 0.0;
+        rm[u] = kk < nv ? rvm[kc] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < KU; u++) {
+        double bb[4];
+#pragma unroll
+        for (int I = 0; I < 4; I++) {
+          bb[I] = g[u] * a[u][I];
+          part[I] = fma(a[u][I], rm[u], part[I]);
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I++) {
+          if (I < nt16) {
+#pragma unroll
+            for (int J = 0; J <= I; J++)
+              acc[tile_of(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][I], bb[J], acc[tile_of(I, J)], 0, 0, 0);
+          }
+        }
+      }
+    }
+    {
+      // (A' rv/mu)[t]: column t = 16 I + ij with I = t / 16 = kq of this lane
+#pragma unroll
+      for (int I = 0; I < 4; I++) {
+        part[I] += __shfl_xor(part[I], 16, 64);
+        part[I] += __shfl_xor(part[I], 32, 64);
+      }
+      *atr_out = kq == 0 ? part[0] : (kq == 1 ? part[1] : (kq == 2 ? part[2] : part[3]));
+    }
+    // D layout of a tile (R, C): lane l, register q hold E[16 R + l/16 + 4 q][16 C + l%16].
+    // Column block P of all 64 rows goes through the staging panel S[row][16]:
+    // tiles (R, P), R > P, as they are; the diagonal tile from its lower half, mirrored;
+    // the rows above it from the transposes of tiles (P, R), R < P.
+    lds_ptr S = stage;
+    double dgE = 0.0;
+#pragma unroll
+    for (int P = 0; P < 4; P++) {
+      if (P < nt16) {
+#pragma unroll
+        for (int R = 0; R < 4; R++) {
+          if (R > P) {
+            if (R < nt16) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) S[(16 * R + kq + 4 * q) * LD + ij] = acc[tile_of(R, P)][q];
+            }
+          } else if (R == P) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int r = kq + 4 * q;
+              const double e = acc[tile_of(P, P)][q];
+              if (r >= ij) S[(16 * P + r) * LD + ij] = e;
+              if (r > ij) S[(16 * P + ij) * LD + r] = e;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) S[(16 * R + ij) * LD + kq + 4 * q] = acc[tile_of(P, R)][q];
+          }
+        }
+        c.sync();
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) Kr[16 * P + cc] = S[t * LD + cc];
+        if ((t >> 4) == P) dgE = S[t * LD + (t & 15)];
+        c.sync();
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) Kr[16 * P + cc] = 0.0;
+      }
+    }
+    // G, G' and -sigma I round the E block (dense_cholesky_solver.cc:62-69).  One load
+    // per column, all of them issued before the first is used (clamped addresses, no
+    // branch in between: a branch per column made each load a round trip of its own);
+    // the lane's kind selects afterwards.
+    const int n = nz + nl;
+    const bool tz = t < nz, tg = t >= nz && t < n;
+    if (nl > 0) {  // (uniform)
+      const int q = tg ? t - nz : 0;
+      const int tt = tz ? t : 0;
+      const double* Gq = D.G + q;              // row q of G (lanes that hold a row of [G -sigma I])
+      const double* Gt = D.G + (long)tt * nl;  // column t of G (lanes that hold a row of E)
+#pragma unroll
+      for (int c0 = 0; c0 < 64; c0 += 16) {
+        double g[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int cidx = c0 + u;
+          const long off_q = (long)(cidx < nz ? cidx : 0) * nl;
+          const long off_t = cidx >= nz && cidx < n ? cidx - nz : 0;
+          const double* pq = Gq + off_q;
+          const double* pt = Gt + off_t;
+          g[u] = *(cidx < nz ? pq : pt);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int cidx = c0 + u;
+          const double e = tz ? Kr[cidx] : (tg ? g[u] : 0.0);                   // cidx < nz
+          const double r = tz ? g[u] : ((tg && cidx == t) ? -sigma : 0.0);       // nz <= cidx < n
+          Kr[cidx] = cidx < nz ? e : (cidx < n ? r : 0.0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cidx = 0; cidx < 64; cidx++) Kr[cidx] = (tz && cidx < nz) ? Kr[cidx] : 0.0;
+    }
+    *dg_out = tz ? dgE : (tg ? -sigma : 0.0);
+  }
+
+  // ---- pivoted LDL' on the register-held rows ---------------------------------------
+  // Nothing is swapped: eliminated rows and columns drop out of the pivot search, the
+  // elimination order is a list (lane k keeps perm[k], each row the step `ord` at
+  // which it went and its pivot).  A step: pivot search; every lane picks ITS entry
+  // of column p out of its own registers (= its entry of the pivot row, by symmetry)
+  // through a tree of scalar branches - the registers cannot be indexed at run time,
+  // and the alternative, the pivot lane alone writing its 64 values to LDS, keeps the
+  // LDS busy for 32 instructions that seven other wavefronts wait behind; the column
+  // goes to LDS with ONE store and comes back as the pivot row, kLdsCols columns as
+  // 16-byte broadcasts and the rest through v_readlane (the LDS and the vector pipe
+  // share the work).  Returns false where Eigen reports failure.
+  // out = a[p], p wavefront-uniform.  Real branches: the empty asm keeps the
+  // optimiser from turning the tree into selects of loads, i.e. into a copy of the
+  // array in scratch memory that every update then has to write through.
+  template <int LO, int HI>
+  static FB_DEV void pick(const double (&a)[64], int p, double& out) {
+    if constexpr (HI - LO == 1) {
+      out = a[LO];
+      asm volatile("" : "+v"(out));
+    } else {
+      constexpr int MID = (LO + HI) / 2;
+      if (p < MID) pick<LO, MID>(a, p, out);
+      else pick<MID, HI>(a, p, out);
+    }
+  }
+  // largest value over the wavefront, the same bits in every lane
+  static FB_DEV double wave_max(double v) {
+    v = fmax(v, dpp_mov<0x128>(v));  // row_ror:8
+    v = fmax(v, dpp_mov<0x124>(v));  // row_ror:4
+    v = fmax(v, dpp_mov<0x122>(v));  // row_ror:2
+    v = fmax(v, dpp_mov<0x121>(v));  // row_ror:1
+    const double r0 = lane_of(v, 0), r1 = lane_of(v, 16), r2 = lane_of(v, 32), r3 = lane_of(v, 48);
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+  }
+#ifndef FB_DW_LDS_COLS
+#define FB_DW_LDS_COLS 48
+#endif
+  static constexpr int kLdsCols = FB_DW_LDS_COLS;  // multiple of 8
+  FB_DEV bool factor(const C& c, double (&Kr)[64], double dg, int* ord_o, double* dpiv_o, int* permv_o) const {
+    int n = lay.nk, t = c.tid;
+    asm volatile("" : "+s"(n), "+v"(t));
+    bool alive = t < n;
+    int ord = 64, permv = 0;
+    double dpiv = 0.0;
+    bool found_zero_pivot = false;
+    for (int k = 0; k < n; k++) {
+      // largest |diagonal| of what is left; the first maximum wins (Eigen's maxCoeff)
+      const double mag = alive ? fabs(dg) : -1.0;
+      const double best = wave_max(mag);
+      const unsigned long long hit = __ballot(mag == best);
+      const int p = __builtin_ctzll(hit);
+      const double d = lane_of(dg, p);
+      if (t == k) permv = p;
+      const bool valid = fabs(d) > 0.0;
+      if (found_zero_pivot && valid) return false;
+      if (!valid) found_zero_pivot = true;
+      double colp;  // K[t][p] = K[p][t]
+      pick<0, 64>(Kr, p, colp);
+      if (t == p) {
+        alive = false;
+        ord = k;
+        dpiv = d;
+      }
+      rowbuf[t] = colp;
+      const double lm = (alive && valid) ? colp * (1.0 / d) : 0.0;
+      Lg[64 * k + t] = lm;
+      c.sync();
+      if (valid) {
+        const double nl_ = -lm;
+#pragma unroll
+        for (int j0 = 0; j0 < kLdsCols; j0 += 8) {
+          dbl2 sj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) sj[u] = *reinterpret_cast<FB_LDS const dbl2*>(rowbuf + j0 + 2 * u);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            Kr[j0 + 2 * u] = fma(nl_, sj[u][0], Kr[j0 + 2 * u]);
+            Kr[j0 + 2 * u + 1] = fma(nl_, sj[u][1], Kr[j0 + 2 * u + 1]);
+          }
+        }
+#pragma unroll
+        for (int j = kLdsCols; j < 64; j++) Kr[j] = fma(nl_, lane_of(colp, j), Kr[j]);
+        dg = fma(nl_, colp, dg);
+      }
+      c.sync();  // (the next column is stored behind these reads)
+    }
+    *ord_o = ord;
+    *dpiv_o = dpiv;
+    *permv_o = permv;
+    global_fence();  // the multipliers are read back by other lanes
+    return true;
+  }
+
+  // x <- K^{-1} x with the factors above (P' L^{-T} D^{+} L^{-1} P of
+  // dense_cholesky_solver.cc:112 with the permutation implicit in the elimination
+  // order).  Lane t owns entry t.  A multiplier is zero wherever its row was no
+  // longer (or not yet) part of the step, so neither sweep needs a predicate.
+  FB_DEV double substitute(int t, double x, int ord, double dpiv, int permv) const {
+    // (t arrives opaque: the 126 load addresses are invariant over the whole solve, and
+    // the optimiser would otherwise form them once per QP and keep them in scratch.)
+    // Both sweeps are chains of dependent steps whose multipliers do not depend on the
+    // chain: all of a sweep's loads go out before its first step (the matrix registers
+    // are free by now).  Steps past the problem's n run with zero multipliers (rows
+    // n.. of the scratch are zero from its allocation on; lanes n.. hold perm = 0).
+    const int n = lay.nk;
+    double lk[64];
+    // L y = b: step k hands the entry of the row eliminated at step k to all later rows
+#pragma unroll
+    for (int k = 0; k < 63; k++) lk[k] = Lg[64 * k + t];
+#pragma unroll
+    for (int k = 0; k < 63; k++) {
+      const int p = __builtin_amdgcn_readlane(permv, k);
+      x = fma(-lk[k], lane_of(x, p), x);
+    }
+    x = (t < n && fabs(dpiv) > DBL_MIN) ? x / dpiv : 0.0;  // pseudo-inverse of D
+    // L' w = y: the entry of the row eliminated at step k goes to the rows eliminated
+    // before it, each of which reads the multiplier it gave that row at its own step
+    const double* myrow = Lg + 64 * (ord < 64 ? ord : 0);
+#pragma unroll
+    for (int k = 63; k > 0; k--) {
+      const int p = __builtin_amdgcn_readlane(permv, k);
+      const double m = myrow[p];
+      lk[k] = (ord < k && k < n) ? m : 0.0;
+    }
+#pragma unroll
+    for (int k = 63; k > 0; k--) {
+      const int p = __builtin_amdgcn_readlane(permv, k);
+      x = fma(-lk[k], lane_of(x, p), x);
+    }
+    return x;
+  }
+
+  FB_DEV bool newton_step(const C& c, double sigma, double alpha) const {
+    FB_WAVE_LAP_DECL;
+    int t = c.tid;
+    asm volatile("" : "+v"(t));  // (see assemble)
+    const int n = lay.nk;
+    // PFB gradients (dense_cholesky_solver.cc:54-61)
+    for (int i = t; i < nv; i += 64) {
+      const double ys = y[i] + sigma * (v[i] - vb[i]);
+      double g0, g1;
+      pfb_gradient(ys, v[i], alpha, &g0, &g1);
+      const double mu = g1 + sigma * g0;
+      gam[i] = g0 / mu;
+      rvm[i] = -pfb(ys, v[i], alpha) / mu;
+    }
+    c.sync();
+    FB_WAVE_LAP(10);
+    double Kr[64], dg, atr;
+    assemble(c, sigma, Kr, &dg, &atr);
+    // eliminated right-hand side (dense_cholesky_solver.cc:98-104), entry t in lane t
+    double x = 0.0;
+    if (t < nz) x = -(rz[t] + sigma * (z[t] - zb[t])) - atr;
+    else if (t < n) x = rl[t - nz] + sigma * (l[t - nz] - lb[t - nz]);
+    FB_WAVE_LAP(11);
+    int ord, permv;
+    double dpiv;
+    if (!factor(c, Kr, dg, &ord, &dpiv, &permv)) return false;
+    FB_WAVE_LAP(12);
+    x = substitute(t, x, ord, dpiv, permv);
+    FB_WAVE_LAP(13);
+    if (t < nz) dz[t] = x;
+    else if (t < n) dl[t - nz] = x;
+    c.sync();
+    // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124)
+    for (int i = t; i < nv; i += 64) {
+      const double a = A_row_dot(i, dz);
+      adz[i] = a;
+      dv[i] = rvm[i] + gam[i] * a;
+    }
+    c.sync();
+    // W = (H dz + G'dl + A'dv, -G dz)
+    if (t < nz) wz[t] = row_dot(D.H, nz, nz, t, dz) + col_dot(D.G, nl, t, dl) + A_col_dot(t, dv);
+    else if (t < n) wl[t - nz] = -row_dot(D.G, nl, nz, t - nz, dz);
+    c.sync();
+    FB_WAVE_LAP(14);
+    return true;
+  }
+
+  FB_DEV void write_x(const C& c) const {
+    for (int i = c.tid; i < nz; i += 64) uz[i] = z[i];
+    for (int i = c.tid; i < nl; i += 64) ul[i] = l[i];
+    for (int i = c.tid; i < nv; i += 64) { uv[i] = v[i]; uy[i] = y[i]; }
+  }
+  FB_DEV void write_xbar(const C& c) const {
+    for (int i = c.tid; i < nz; i += 64) uz[i] = zb[i];
+    for (int i = c.tid; i < nl; i += 64) ul[i] = lb[i];
+    for (int i = c.tid; i < nv; i += 64) { uv[i] = vb[i]; uy[i] = yb[i]; }
+  }
+  FB_DEV void write_certificate(const C& c) const {
+    for (int i = c.tid; i < nz; i += 64) uz[i] = dz[i];
+    for (int i = c.tid; i < nl; i += 64) ul[i] = dl[i];
+    for (int i = c.tid; i < nv; i += 64) {
+      uv[i] = dv[i];
+      uy[i] = (y[i] - yb[i]) + bvec(i);
+    }
+  }
+};
+
+#endif  // !FB_HOSTSIM
+
+}  // namespace fbk

@@ -17,6 +17,7 @@
 #include "../../include/fbstab_hip.h"
 #include "fb_algorithm.h"
 #include "fb_dense.h"
+#include "fb_dense_wave.h"
 #include "fb_mpc.h"
 #include "fb_mpc_r16.h"
 
@@ -393,6 +394,46 @@ __global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_probe_kern
   newton_probe(p, ctx, opts, dbg);
 }
 
+// One wavefront per dense QP for every phase (fb_dense_wave.h; nz + nl <= 64): the KKT
+// matrix in registers, two wavefronts per SIMD.  scratch: one region of
+// lay.ws_doubles per workgroup (A' and the multipliers).  DBG: the Newton-step probe.
+template <bool DBG>
+__global__ __launch_bounds__(64, 2) void fbstab_dense_wave_kernel(DenseWaveLayout lay, DenseBatchArgs data,
+                                                                   VarBatchArgs x, fbstab_solver_out_t* out,
+                                                                   fbstab_options_t opts, int* counter, int batch,
+                                                                   double* scratch, double* dbg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  FB_WAVE_TIMER(28);  // total wave cycles (diagnostic builds)
+  lds_ptr lds = (lds_ptr)smem;
+  typedef DenseWave::C C;
+  C ctx;
+  ctx.tid = threadIdx.x;
+  ctx.red = lds;  // (unused: one wavefront reduces in registers)
+  double* ws = scratch + (long)blockIdx.x * lay.ws_doubles;
+  for (;;) {
+    const int q = DBG ? (int)blockIdx.x : next_qp<64>(counter, lds);
+    if (q >= batch) break;
+    DenseData D;
+    D.H = data.base[FBSTAB_DENSE_H] + q * data.stride[FBSTAB_DENSE_H];
+    D.f = data.base[FBSTAB_DENSE_f] + q * data.stride[FBSTAB_DENSE_f];
+    D.G = data.base[FBSTAB_DENSE_G] + q * data.stride[FBSTAB_DENSE_G];
+    D.h = data.base[FBSTAB_DENSE_h] + q * data.stride[FBSTAB_DENSE_h];
+    D.A = data.base[FBSTAB_DENSE_A] + q * data.stride[FBSTAB_DENSE_A];
+    D.b = data.base[FBSTAB_DENSE_b] + q * data.stride[FBSTAB_DENSE_b];
+    DenseWave p;
+    p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1], x.base[2] + q * x.stride[2],
+           x.base[3] + q * x.stride[3], lds, ws);
+    if constexpr (DBG) {
+      newton_probe(p, ctx, opts, dbg);
+      break;
+    } else {
+      Solver<DenseWave, C> solver(p, ctx, opts);
+      solver.solve(out + q);
+      ctx.sync();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 thread_local std::string g_error;
 
@@ -655,6 +696,10 @@ int launch_record(fbstab_mpc_solver* h, const void* kern, int grid, hipStream_t 
 }  // namespace
 struct fbstab_dense_solver : SolverBase {
   fbk::DenseLayout lay;
+  // one wavefront per QP with the KKT matrix in registers (fb_dense_wave.h): the
+  // kernel batches of nz + nl <= 64 run on; `lay` then only serves the traced solve
+  bool wave = false;
+  fbk::DenseWaveLayout wlay;
 };
 
 extern "C" {
@@ -1043,14 +1088,18 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   if (max_batch < 1) return fail(FBSTAB_HIP_ERR_ARGUMENT, "max_batch must be positive");
   fbstab_dense_solver* s = new (std::nothrow) fbstab_dense_solver();
   if (!s) return fail(FBSTAB_HIP_ERR_DEVICE, "out of host memory");
-  // Four wavefronts per QP; for nz + nl <= 64 the factorisation itself runs on the
-  // first of them with the KKT matrix in registers (fb_dense.h: ldlt_rows).
-  // FBSTAB_HIP_DENSE_THREADS=64 selects one wavefront per QP for everything
-  // (measured slower: the matrix-vector phases want the four of them).
+  // nz + nl <= 64: one wavefront per QP for every phase, the KKT matrix in registers,
+  // up to eight QPs per CU (fb_dense_wave.h).  Otherwise four wavefronts per QP with
+  // K in LDS or, beyond nz + nl ~ 140, in global scratch (fb_dense.h).
+  // FBSTAB_HIP_DENSE_THREADS=256 forces the four-wavefront kernel (comparisons);
+  // =64 its one-wavefront instance with K in LDS.
   s->threads = kDenseThreads;
+  s->wlay.init(nz, nl, nv);
+  s->wave = s->wlay.fits();
   {
     const char* th = getenv("FBSTAB_HIP_DENSE_THREADS");
-    if (th && atoi(th) == 64 && nz + nl <= 64) s->threads = 64;
+    if (th && atoi(th) == 256) s->wave = false;
+    if (th && atoi(th) == 64 && nz + nl <= 64) { s->threads = 64; s->wave = false; }
   }
   s->lay.init(nz, nl, nv, s->threads);
   if (s->threads == 64 && (s->lay.k_global || !s->lay.a_lds)) {  // does not fit that way
@@ -1058,17 +1107,26 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
     s->lay.init(nz, nl, nv, s->threads);
   }
   s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
+  if (s->wave) {
+    s->threads = 64;
+    s->lay.init(nz, nl, nv, kDenseThreads);  // (the traced solve's layout)
+    s->lds_bytes = s->wlay.lds_doubles * (int)sizeof(double);
+  }
   if (s->lds_bytes > kLdsLimitBytes) {
     delete s;
     return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "the iterate vectors do not fit the 160 KiB LDS budget");
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
-  const void* kern = s->threads == 64 ? reinterpret_cast<const void*>(fbstab_dense_kernel<64>)
+  const void* kern = s->wave ? reinterpret_cast<const void*>(fbstab_dense_wave_kernel<false>)
+                     : s->threads == 64 ? reinterpret_cast<const void*>(fbstab_dense_kernel<64>)
                      : s->lay.k_global
                          ? reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads, false, true>)
                          : reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads>);
   hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+  if (e == hipSuccess && s->wave)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fbstab_dense_wave_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
   int per_cu = 0;
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, s->threads, s->lds_bytes);
   hipDeviceProp_t prop;
@@ -1084,9 +1142,14 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   s->workgroups = prop.multiProcessorCount * per_cu;
   if (s->workgroups > max_batch) s->workgroups = max_batch;
   s->scratch_bytes = 0;
-  if (s->lay.k_global) {  // K of every resident workgroup (fb_dense.h)
+  if (s->wave)  // A' and the multipliers of every resident workgroup (fb_dense_wave.h)
+    s->scratch_bytes = (long long)sizeof(double) * s->wlay.ws_doubles * s->workgroups;
+  else if (s->lay.k_global)  // K of every resident workgroup (fb_dense.h)
     s->scratch_bytes = (long long)sizeof(double) * s->lay.k_doubles * s->workgroups;
+  if (s->scratch_bytes > 0) {
     e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
+    // (fb_dense_wave.h relies on the multiplier rows past nz + nl being zero)
+    if (e == hipSuccess && s->wave) e = hipMemset(s->scratch, 0, (size_t)s->scratch_bytes);
     if (e != hipSuccess) {
       s->release(); delete s;
       return fail(FBSTAB_HIP_ERR_DEVICE, std::string("scratch allocation: ") + hipGetErrorString(e));
@@ -1190,6 +1253,9 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
                                 hipFuncAttributeMaxDynamicSharedMemorySize, tlds));
     hipLaunchKernelGGL(kern, dim3(1), dim3(kDenseThreads), tlds, s, tl, a, v, d_out, h->opts,
                        h->counter, 1, TraceArg<true>{d_trace}, KScratchArg<false>());
+  } else if (h->wave) {
+    hipLaunchKernelGGL(fbstab_dense_wave_kernel<false>, dim3(grid), dim3(64), h->lds_bytes, s, h->wlay, a, v, d_out,
+                       h->opts, h->counter, batch, h->scratch, (double*)nullptr);
   } else if (h->threads == 64) {
     hipLaunchKernelGGL(fbstab_dense_kernel<64>, dim3(grid), dim3(64), h->lds_bytes, s, h->lay, a, v, d_out,
                        h->opts, h->counter, batch, TraceArg<false>(), KScratchArg<false>());
@@ -1251,7 +1317,7 @@ int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t h, const fbstab_dense_ba
 int fbstab_hip_dense_debug_newton(fbstab_dense_handle_t h, const fbstab_dense_batch_t* data,
                                   const fbstab_var_batch_t* x, double* io) {
   if (!h || !data || !x || !io) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null argument");
-  if (h->lay.k_global) return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "dense probe: K must fit the LDS");
+  if (!h->wave && h->lay.k_global) return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "dense probe: K must fit the LDS");
   HIP_TRY(hipSetDevice(h->device));
   int rc = h->ensure_staging();
   if (rc != FBSTAB_HIP_OK) return rc;
@@ -1278,7 +1344,10 @@ int fbstab_hip_dense_debug_newton(fbstab_dense_handle_t h, const fbstab_dense_ba
   HIP_TRY(hipMalloc(&d_io_buf.p, n_io * sizeof(double)));
   double* d_io = static_cast<double*>(d_io_buf.p);
   HIP_TRY(hipMemcpyAsync(d_io, io, sizeof(double) * (L.nz + L.nl + L.nv), hipMemcpyHostToDevice, s));
-  if (h->threads == 64) {
+  if (h->wave) {
+    hipLaunchKernelGGL(fbstab_dense_wave_kernel<true>, dim3(1), dim3(64), h->lds_bytes, s, h->wlay, a, v,
+                       (fbstab_solver_out_t*)nullptr, h->opts, h->counter, 1, h->scratch, d_io);
+  } else if (h->threads == 64) {
     auto kern = fbstab_dense_probe_kernel<64>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 h->lds_bytes));
