@@ -40,14 +40,27 @@ namespace fbk {
 
 #if !defined(FB_HOSTSIM)
 
+// Sub-phase cycles of the factorisation loop (diagnostic builds): summed in registers,
+// one atomic per factorisation (an atomic per lap would be most of what is measured).
+#if defined(FB_STAMP) || defined(FB_CLOCKSTAMP)
+#define FB_DW_LAPS_DECL long long dw_acc_[4] = {0, 0, 0, 0}; long long dw_t_ = __builtin_readcyclecounter()
+#define FB_DW_LAP(i) do { const long long n_ = __builtin_readcyclecounter(); dw_acc_[i] += n_ - dw_t_; dw_t_ = n_; } while (0)
+#define FB_DW_LAPS_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 4; i_++) atomicAdd(&g_stamps[(base) + i_], (unsigned long long)dw_acc_[i_]); } while (0)
+#else
+#define FB_DW_LAPS_DECL
+#define FB_DW_LAP(i)
+#define FB_DW_LAPS_FLUSH(base)
+#endif
+
 struct DenseWaveLayout {
   static constexpr int kLd = 17;  // leading dimension of the staging panel (odd: rows hit different banks)
   int nz, nl, nv, nk;
   // LDS carve (offsets in doubles)
   int o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz, o_rz, o_rl, o_wz, o_wl,
       o_gam, o_rvm, o_rowbuf, o_stage, lds_doubles;
-  // global scratch of one workgroup (doubles): A' and the multipliers
-  long o_at, o_lg, ws_doubles;
+  // global scratch of one workgroup (doubles): A', the multipliers, H in accumulator
+  // layout (40 x 64) and G' (Gt[64 q + t] = G[q][t])
+  long o_at, o_lg, o_hd, o_gt, ws_doubles;
 
   __host__ __device__ void init(int nz_, int nl_, int nv_) {
     nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
@@ -63,7 +76,9 @@ struct DenseWaveLayout {
     lds_doubles = (s + 1) & ~1;
     o_at = 0;
     o_lg = ((long)nv * nz + 15) & ~15L;
-    ws_doubles = o_lg + 64 * 64;
+    o_hd = o_lg + 64 * 64;
+    o_gt = o_hd + 40 * 64;
+    ws_doubles = o_gt + 64 * (long)(nl > 0 ? nl : 1);
   }
   // nz + nl <= 64 and the iterate vectors fit a share of the LDS that leaves room
   // for at least four workgroups per CU
@@ -80,7 +95,9 @@ struct DenseWave {
   DenseWaveLayout lay;
   DenseData D;
   double *uz, *ul, *uv, *uy;
-  double *At, *Lg;  // global scratch: A' (At[j + k nz] = A[k][j]) and the multipliers Lg[64 k + t]
+  // global scratch: A' (At[j + k nz] = A[k][j]), the multipliers Lg[64 k + t], the lower
+  // triangle of H as the MFMA accumulators hold it (Hd[64 (4 tile + q) + lane]) and G'
+  double *At, *Lg, *Hd, *Gt;
   int nz, nl, nv;
   lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
   lds_ptr gam, rvm, rowbuf, stage;
@@ -97,6 +114,8 @@ struct DenseWave {
     rowbuf = lds + lay.o_rowbuf; stage = lds + lay.o_stage;
     At = ws + lay.o_at;
     Lg = ws + lay.o_lg;
+    Hd = ws + lay.o_hd;
+    Gt = ws + lay.o_gt;
   }
 
   // The wavefront's own global stores (At, Lg) become visible to its other lanes:
@@ -178,6 +197,26 @@ struct DenseWave {
           if (k < nv && j0 + u < nz) At[(j0 + u) + (long)k * nz] = a[u];
       }
     }
+    {
+      // H as the accumulators of assemble() hold it: lane l, register q of tile (I, J)
+      // <-> entry (16 I + l/16 + 4 q, 16 J + l%16), rows and columns past nz clamped
+      // (never used).  Sixteen cache lines per load here, once per QP, instead of once
+      // per Newton iteration.
+      const int kq = c.tid >> 4, ij = c.tid & 15;
+#pragma unroll
+      for (int I = 0; I < 4; I++) {
+#pragma unroll
+        for (int J = 0; J <= I; J++) {
+          const int cj = 16 * J + ij < nz ? 16 * J + ij : nz - 1;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int r = 16 * I + kq + 4 * q;
+            Hd[64 * (4 * tile_of(I, J) + q) + c.tid] = D.H[(r < nz ? r : nz - 1) + (long)cj * nz];
+          }
+        }
+      }
+      for (int q = 0; q < nl; q++) Gt[64 * q + c.tid] = c.tid < nz ? D.G[q + (long)c.tid * nl] : 0.0;
+    }
     global_fence();
     c.sync();
     for (int i = c.tid; i < nv; i += 64) y[i] = D.b[i] - A_row_dot(i, z);
@@ -254,6 +293,7 @@ struct DenseWave {
     asm volatile("" : "+v"(t), "+s"(nz), "+s"(nl), "+s"(nv));
     const int kq = t >> 4, ij = t & 15;
     const int nt16 = (nz + 15) >> 4;
+    FB_DW_LAPS_DECL;
     int col[4];
 #pragma unroll
     for (int I = 0; I < 4; I++) col[I] = 16 * I + ij < nz ? 16 * I + ij : nz - 1;  // padded columns re-read the last one
@@ -267,10 +307,7 @@ struct DenseWave {
       for (int J = 0; J <= I; J++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int r = 16 * I + kq + 4 * q;
-          const int rr = r < nz ? r : nz - 1;
-          double h = 0.0;
-          if (I < nt16) h = D.H[rr + (long)col[J] * nz];
+          double h = Hd[64 * (4 * tile_of(I, J) + q) + t];
           if (I == J && kq + 4 * q == ij) h += sigma;
           acc[tile_of(I, J)][q] = h;
         }
@@ -281,6 +318,7 @@ struct DenseWave {
     // KU steps' operands are requested together.  The same operands give A' (rv/mu)
     // of the right-hand side (dense_cholesky_solver.cc:98-100): lane (kq, ij) sums
     // the rows k = kq mod 4 of column 16 I + ij, the four partial sums meet below.
+    FB_DW_LAP(0);
     constexpr int KU = 5;
     double part[4] = {0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < nv; k0 += 4 * KU) {
@@ -326,6 +364,7 @@ struct DenseWave {
     // Column block P of all 64 rows goes through the staging panel S[row][16]:
     // tiles (R, P), R > P, as they are; the diagonal tile from its lower half, mirrored;
     // the rows above it from the transposes of tiles (P, R), R < P.
+    FB_DW_LAP(1);
     lds_ptr S = stage;
     double dgE = 0.0;
 #pragma unroll
@@ -365,13 +404,14 @@ struct DenseWave {
     // per column, all of them issued before the first is used (clamped addresses, no
     // branch in between: a branch per column made each load a round trip of its own);
     // the lane's kind selects afterwards.
+    FB_DW_LAP(2);
     const int n = nz + nl;
     const bool tz = t < nz, tg = t >= nz && t < n;
     if (nl > 0) {  // (uniform)
       const int q = tg ? t - nz : 0;
       const int tt = tz ? t : 0;
       const double* Gq = D.G + q;              // row q of G (lanes that hold a row of [G -sigma I])
-      const double* Gt = D.G + (long)tt * nl;  // column t of G (lanes that hold a row of E)
+      const double* Gtt = Gt + tt;             // G'[t][.] (lanes that hold a row of E): Gt[64 q + t]
 #pragma unroll
       for (int c0 = 0; c0 < 64; c0 += 16) {
         double g[16];
@@ -379,9 +419,9 @@ struct DenseWave {
         for (int u = 0; u < 16; u++) {
           const int cidx = c0 + u;
           const long off_q = (long)(cidx < nz ? cidx : 0) * nl;
-          const long off_t = cidx >= nz && cidx < n ? cidx - nz : 0;
+          const long off_t = 64 * (long)(cidx >= nz && cidx < n ? cidx - nz : 0);
           const double* pq = Gq + off_q;
-          const double* pt = Gt + off_t;
+          const double* pt = Gtt + off_t;
           g[u] = *(cidx < nz ? pq : pt);
         }
 #pragma unroll
@@ -396,6 +436,8 @@ struct DenseWave {
 #pragma unroll
       for (int cidx = 0; cidx < 64; cidx++) Kr[cidx] = (tz && cidx < nz) ? Kr[cidx] : 0.0;
     }
+    FB_DW_LAP(3);
+    FB_DW_LAPS_FLUSH(19);
     *dg_out = tz ? dgE : (tg ? -sigma : 0.0);
   }
 
@@ -424,6 +466,15 @@ struct DenseWave {
       else pick<MID, HI>(a, p, out);
     }
   }
+  // sum over the wavefront, the same bits in every lane
+  static FB_DEV double wave_sum(double v) {
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    const double r0 = lane_of(v, 0), r1 = lane_of(v, 16), r2 = lane_of(v, 32), r3 = lane_of(v, 48);
+    return (r0 + r1) + (r2 + r3);
+  }
   // largest value over the wavefront, the same bits in every lane
   static FB_DEV double wave_max(double v) {
     v = fmax(v, dpp_mov<0x128>(v));  // row_ror:8
@@ -436,7 +487,11 @@ struct DenseWave {
 #ifndef FB_DW_LDS_COLS
 #define FB_DW_LDS_COLS 48
 #endif
-  static constexpr int kLdsCols = FB_DW_LDS_COLS;  // multiple of 8
+  static constexpr int kLdsCols = FB_DW_LDS_COLS;  // even
+#ifndef FB_DW_LDS_BATCH
+#define FB_DW_LDS_BATCH 24
+#endif
+  static constexpr int kLdsBatch = FB_DW_LDS_BATCH;  // columns per batch of LDS reads (even)
   FB_DEV bool factor(const C& c, double (&Kr)[64], double dg, int* ord_o, double* dpiv_o, int* permv_o) const {
     int n = lay.nk, t = c.tid;
     asm volatile("" : "+s"(n), "+v"(t));
@@ -444,9 +499,14 @@ struct DenseWave {
     int ord = 64, permv = 0;
     double dpiv = 0.0;
     bool found_zero_pivot = false;
+    FB_DW_LAPS_DECL;
     for (int k = 0; k < n; k++) {
       // largest |diagonal| of what is left; the first maximum wins (Eigen's maxCoeff)
-      const double mag = alive ? fabs(dg) : -1.0;
+      // (rows that are gone carry a NaN: v_max_f64 passes over it, it equals nothing,
+      // and all-ones is an inline constant - a -1.0 lived in a register the allocator
+      // spilled, and its reload in here waited for the multiplier store of the step
+      // before with every other vector memory operation)
+      const double mag = __hiloint2double(alive ? (__double2hiint(dg) & 0x7fffffff) : -1, alive ? __double2loint(dg) : -1);
       const double best = wave_max(mag);
       const unsigned long long hit = __ballot(mag == best);
       const int p = __builtin_ctzll(hit);
@@ -455,8 +515,10 @@ struct DenseWave {
       const bool valid = fabs(d) > 0.0;
       if (found_zero_pivot && valid) return false;
       if (!valid) found_zero_pivot = true;
+      FB_DW_LAP(0);
       double colp;  // K[t][p] = K[p][t]
       pick<0, 64>(Kr, p, colp);
+      FB_DW_LAP(1);
       if (t == p) {
         alive = false;
         ord = k;
@@ -466,25 +528,44 @@ struct DenseWave {
       const double lm = (alive && valid) ? colp * (1.0 / d) : 0.0;
       Lg[64 * k + t] = lm;
       c.sync();
+      FB_DW_LAP(2);
       if (valid) {
         const double nl_ = -lm;
+        // the row's LDS part is requested kLdsBatch columns at a time; the v_readlane
+        // columns run while the first batch is on its way
+        constexpr int NB = kLdsBatch / 2;
+        dbl2 sj[NB];
 #pragma unroll
-        for (int j0 = 0; j0 < kLdsCols; j0 += 8) {
-          dbl2 sj[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) sj[u] = *reinterpret_cast<FB_LDS const dbl2*>(rowbuf + j0 + 2 * u);
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            Kr[j0 + 2 * u] = fma(nl_, sj[u][0], Kr[j0 + 2 * u]);
-            Kr[j0 + 2 * u + 1] = fma(nl_, sj[u][1], Kr[j0 + 2 * u + 1]);
-          }
-        }
+        for (int u = 0; u < NB; u++)
+          if (2 * u < kLdsCols) sj[u] = *reinterpret_cast<FB_LDS const dbl2*>(rowbuf + 2 * u);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = kLdsCols; j < 64; j++) Kr[j] = fma(nl_, lane_of(colp, j), Kr[j]);
         dg = fma(nl_, colp, dg);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j0 = 0; j0 < kLdsCols; j0 += kLdsBatch) {
+#pragma unroll
+          for (int u = 0; u < NB; u++) {
+            if (j0 + 2 * u < kLdsCols) {
+              Kr[j0 + 2 * u] = fma(nl_, sj[u][0], Kr[j0 + 2 * u]);
+              Kr[j0 + 2 * u + 1] = fma(nl_, sj[u][1], Kr[j0 + 2 * u + 1]);
+            }
+          }
+          if (j0 + kLdsBatch < kLdsCols) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NB; u++)
+              if (j0 + kLdsBatch + 2 * u < kLdsCols)
+                sj[u] = *reinterpret_cast<FB_LDS const dbl2*>(rowbuf + j0 + kLdsBatch + 2 * u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
       c.sync();  // (the next column is stored behind these reads)
+      FB_DW_LAP(3);
     }
+    FB_DW_LAPS_FLUSH(0);
     *ord_o = ord;
     *dpiv_o = dpiv;
     *permv_o = permv;
@@ -500,34 +581,38 @@ struct DenseWave {
     // (t arrives opaque: the 126 load addresses are invariant over the whole solve, and
     // the optimiser would otherwise form them once per QP and keep them in scratch.)
     // Both sweeps are chains of dependent steps whose multipliers do not depend on the
-    // chain: all of a sweep's loads go out before its first step (the matrix registers
-    // are free by now).  Steps past the problem's n run with zero multipliers (rows
-    // n.. of the scratch are zero from its allocation on; lanes n.. hold perm = 0).
+    // chain: the loads go out before the first step (the matrix registers are free by
+    // now).  Steps past the problem's n run with zero multipliers (rows n.. of the
+    // scratch are zero from its allocation on; lanes n.. hold perm = 0).
     const int n = lay.nk;
     double lk[64];
+    FB_DW_LAPS_DECL;
     // L y = b: step k hands the entry of the row eliminated at step k to all later rows
 #pragma unroll
     for (int k = 0; k < 63; k++) lk[k] = Lg[64 * k + t];
+    FB_DW_LAP(0);
 #pragma unroll
     for (int k = 0; k < 63; k++) {
       const int p = __builtin_amdgcn_readlane(permv, k);
       x = fma(-lk[k], lane_of(x, p), x);
     }
+    FB_DW_LAP(1);
     x = (t < n && fabs(dpiv) > DBL_MIN) ? x / dpiv : 0.0;  // pseudo-inverse of D
-    // L' w = y: the entry of the row eliminated at step k goes to the rows eliminated
-    // before it, each of which reads the multiplier it gave that row at its own step
-    const double* myrow = Lg + 64 * (ord < 64 ? ord : 0);
+    // L' w = y, one row of L' per step: w(p_j) = y(p_j) - sum_t Lg[j][t] w(t) over the
+    // rows t eliminated after step j (the multipliers of all others are zero) - a sum
+    // over the wavefront per step, but row j of the multipliers is what lane t already
+    // read for the forward sweep.  (The column form - the solved entry handed to the
+    // rows eliminated before it - needs Lg[ord(t)][p_k], a different cache line in
+    // every lane: those 63 loads took five times as long as the rest of the solve.)
+    FB_DW_LAP(2);
 #pragma unroll
-    for (int k = 63; k > 0; k--) {
-      const int p = __builtin_amdgcn_readlane(permv, k);
-      const double m = myrow[p];
-      lk[k] = (ord < k && k < n) ? m : 0.0;
+    for (int j = 62; j >= 0; j--) {
+      const double s = wave_sum(lk[j] * x);
+      const int p = __builtin_amdgcn_readlane(permv, j);
+      x = t == p ? x - s : x;
     }
-#pragma unroll
-    for (int k = 63; k > 0; k--) {
-      const int p = __builtin_amdgcn_readlane(permv, k);
-      x = fma(-lk[k], lane_of(x, p), x);
-    }
+    FB_DW_LAP(3);
+    FB_DW_LAPS_FLUSH(4);
     return x;
   }
 
@@ -563,16 +648,55 @@ struct DenseWave {
     if (t < nz) dz[t] = x;
     else if (t < n) dl[t - nz] = x;
     c.sync();
-    // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124)
-    for (int i = t; i < nv; i += 64) {
-      const double a = A_row_dot(i, dz);
-      adz[i] = a;
-      dv[i] = rvm[i] + gam[i] * a;
+    // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124) and the
+    // dz part of W = (H dz + G'dl + A'dv, -G dz): the products with dz share one loop
+    // over its entries (rows t and t + 64 of A, row t of H or of G), the loads of ten
+    // entries - thirty loads - in flight together.  Rows past the end read row 0 and
+    // are dropped.
+    double hdz = 0.0;  // (H dz)_t, t < nz; (G dz)_(t - nz), nz <= t < n
+    if (nv <= 128) {
+      const bool r0 = t < nv, r1 = t + 64 < nv;
+      const double* a0 = D.A + (r0 ? t : 0);
+      const double* a1 = D.A + (r1 ? t + 64 : 0);
+      const double* hr = t < nz ? D.H + t : (nl > 0 ? D.G + (t < n ? t - nz : 0) : D.H);
+      const long hs = t < nz ? nz : (nl > 0 ? nl : nz);
+      double s0 = 0.0, s1 = 0.0;
+      for (int k0 = 0; k0 < nz; k0 += 10) {
+        double x0[10], x1[10], xh[10];
+#pragma unroll
+        for (int u = 0; u < 10; u++) {
+          const int k = k0 + u < nz ? k0 + u : nz - 1;
+          x0[u] = a0[(long)k * nv];
+          x1[u] = a1[(long)k * nv];
+          xh[u] = hr[(long)k * hs];
+        }
+#pragma unroll
+        for (int u = 0; u < 10; u++) {
+          const double d = k0 + u < nz ? dz[k0 + u < nz ? k0 + u : nz - 1] : 0.0;
+          s0 = fma(x0[u], d, s0);
+          s1 = fma(x1[u], d, s1);
+          hdz = fma(xh[u], d, hdz);
+        }
+      }
+      if (r0) { adz[t] = s0; dv[t] = rvm[t] + gam[t] * s0; }
+      if (r1) { adz[t + 64] = s1; dv[t + 64] = rvm[t + 64] + gam[t + 64] * s1; }
+    } else {
+      for (int i = t; i < nv; i += 64) {
+        const double a = A_row_dot(i, dz);
+        adz[i] = a;
+        dv[i] = rvm[i] + gam[i] * a;
+      }
+      if (t < nz) hdz = row_dot(D.H, nz, nz, t, dz);
+      else if (t < n) hdz = row_dot(D.G, nl, nz, t - nz, dz);
     }
     c.sync();
-    // W = (H dz + G'dl + A'dv, -G dz)
-    if (t < nz) wz[t] = row_dot(D.H, nz, nz, t, dz) + col_dot(D.G, nl, t, dl) + A_col_dot(t, dv);
-    else if (t < n) wl[t - nz] = -row_dot(D.G, nl, nz, t - nz, dz);
+    if (t < nz) {
+      double gdl = 0.0;  // (G'dl)_t from the transposed copy
+      for (int q = 0; q < nl; q++) gdl = fma(Gt[64 * q + t], dl[q], gdl);
+      wz[t] = hdz + gdl + row_dot<25>(At, nz, nv, t, dv);
+    } else if (t < n) {
+      wl[t - nz] = -hdz;
+    }
     c.sync();
     FB_WAVE_LAP(14);
     return true;
