@@ -287,7 +287,16 @@ struct DenseWave {
   // only - 64 columns' worth of masks, addresses and even the H and G entries - is
   // invariant over the whole solve, and the optimiser would otherwise hoist all of
   // it out of the Newton loop and spill it: 1000 registers.)
-  FB_DEV void assemble(const C& c, double sigma, double (&Kr)[64], double* dg_out, double* atr_out) const {
+  // H in accumulator layout (Hd), requested by the caller a phase ahead
+  FB_DEV void load_hd(int t, d4 (&hd)[10]) const {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) hd[i][q] = Hd[64 * (4 * i + q) + t];
+    }
+  }
+  FB_DEV void assemble(const C& c, const d4 (&hd)[10], double sigma, double (&Kr)[64], double* dg_out,
+                       double* atr_out) const {
     int t = c.tid;
     int nz = this->nz, nl = this->nl, nv = this->nv;
     asm volatile("" : "+v"(t), "+s"(nz), "+s"(nl), "+s"(nv));
@@ -307,7 +316,7 @@ struct DenseWave {
       for (int J = 0; J <= I; J++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          double h = Hd[64 * (4 * tile_of(I, J) + q) + t];
+          double h = hd[tile_of(I, J)][q];
           if (I == J && kq + 4 * q == ij) h += sigma;
           acc[tile_of(I, J)][q] = h;
         }
@@ -412,9 +421,8 @@ struct DenseWave {
       const int tt = tz ? t : 0;
       const double* Gq = D.G + q;              // row q of G (lanes that hold a row of [G -sigma I])
       const double* Gtt = Gt + tt;             // G'[t][.] (lanes that hold a row of E): Gt[64 q + t]
-#pragma unroll
-      for (int c0 = 0; c0 < 64; c0 += 16) {
-        double g[16];
+      auto load_g = [&](auto C0, double (&g)[16]) {
+        constexpr int c0 = decltype(C0)::value;
 #pragma unroll
         for (int u = 0; u < 16; u++) {
           const int cidx = c0 + u;
@@ -424,6 +432,9 @@ struct DenseWave {
           const double* pt = Gtt + off_t;
           g[u] = *(cidx < nz ? pq : pt);
         }
+      };
+      auto use_g = [&](auto C0, const double (&g)[16]) {
+        constexpr int c0 = decltype(C0)::value;
 #pragma unroll
         for (int u = 0; u < 16; u++) {
           const int cidx = c0 + u;
@@ -431,7 +442,17 @@ struct DenseWave {
           const double r = tz ? g[u] : ((tg && cidx == t) ? -sigma : 0.0);       // nz <= cidx < n
           Kr[cidx] = cidx < nz ? e : (cidx < n ? r : 0.0);
         }
-      }
+      };
+      // (two chunks of sixteen columns in flight)
+      double ga[16], gb[16];
+      load_g(std::integral_constant<int, 0>{}, ga);
+      load_g(std::integral_constant<int, 16>{}, gb);
+      use_g(std::integral_constant<int, 0>{}, ga);
+      load_g(std::integral_constant<int, 32>{}, ga);
+      use_g(std::integral_constant<int, 16>{}, gb);
+      load_g(std::integral_constant<int, 48>{}, gb);
+      use_g(std::integral_constant<int, 32>{}, ga);
+      use_g(std::integral_constant<int, 48>{}, gb);
     } else {
 #pragma unroll
       for (int cidx = 0; cidx < 64; cidx++) Kr[cidx] = (tz && cidx < nz) ? Kr[cidx] : 0.0;
@@ -621,6 +642,8 @@ struct DenseWave {
     int t = c.tid;
     asm volatile("" : "+v"(t));  // (see assemble)
     const int n = lay.nk;
+    d4 hd[10];
+    load_hd(t, hd);  // (on its way while the gradients are formed)
     // PFB gradients (dense_cholesky_solver.cc:54-61)
     for (int i = t; i < nv; i += 64) {
       const double ys = y[i] + sigma * (v[i] - vb[i]);
@@ -633,7 +656,7 @@ struct DenseWave {
     c.sync();
     FB_WAVE_LAP(10);
     double Kr[64], dg, atr;
-    assemble(c, sigma, Kr, &dg, &atr);
+    assemble(c, hd, sigma, Kr, &dg, &atr);
     // eliminated right-hand side (dense_cholesky_solver.cc:98-104), entry t in lane t
     double x = 0.0;
     if (t < nz) x = -(rz[t] + sigma * (z[t] - zb[t])) - atr;
@@ -661,22 +684,33 @@ struct DenseWave {
       const double* hr = t < nz ? D.H + t : (nl > 0 ? D.G + (t < n ? t - nz : 0) : D.H);
       const long hs = t < nz ? nz : (nl > 0 ? nl : nz);
       double s0 = 0.0, s1 = 0.0;
-      for (int k0 = 0; k0 < nz; k0 += 10) {
-        double x0[10], x1[10], xh[10];
+      struct Chunk { double x0[10], x1[10], xh[10]; };
+      auto load_chunk = [&](int k0, Chunk& ch) {
 #pragma unroll
         for (int u = 0; u < 10; u++) {
           const int k = k0 + u < nz ? k0 + u : nz - 1;
-          x0[u] = a0[(long)k * nv];
-          x1[u] = a1[(long)k * nv];
-          xh[u] = hr[(long)k * hs];
+          ch.x0[u] = a0[(long)k * nv];
+          ch.x1[u] = a1[(long)k * nv];
+          ch.xh[u] = hr[(long)k * hs];
         }
+      };
+      auto use_chunk = [&](int k0, const Chunk& ch) {
 #pragma unroll
         for (int u = 0; u < 10; u++) {
           const double d = k0 + u < nz ? dz[k0 + u < nz ? k0 + u : nz - 1] : 0.0;
-          s0 = fma(x0[u], d, s0);
-          s1 = fma(x1[u], d, s1);
-          hdz = fma(xh[u], d, hdz);
+          s0 = fma(ch.x0[u], d, s0);
+          s1 = fma(ch.x1[u], d, s1);
+          hdz = fma(ch.xh[u], d, hdz);
         }
+      };
+      // (the next ten entries' thirty loads go out before these ten are used)
+      Chunk ca, cb;
+      load_chunk(0, ca);
+      for (int k0 = 0; k0 < nz; k0 += 20) {
+        if (k0 + 10 < nz) load_chunk(k0 + 10, cb);
+        use_chunk(k0, ca);
+        if (k0 + 20 < nz) load_chunk(k0 + 20, ca);
+        if (k0 + 10 < nz) use_chunk(k0 + 10, cb);
       }
       if (r0) { adz[t] = s0; dv[t] = rvm[t] + gam[t] * s0; }
       if (r1) { adz[t + 64] = s1; dv[t + 64] = rvm[t + 64] + gam[t + 64] * s1; }

@@ -353,6 +353,34 @@ def test_dense_odd_shapes(hip, oracle, shape):
     assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(50, 10, 100), (7, 0, 9), (30, 20, 64), (64, 0, 128), (48, 16, 131)])
+def test_dense_one_wavefront_kernel_is_selected_and_agrees_with_the_four_wavefront_kernel(hip, oracle, monkeypatch, shape):
+    """nz + nl <= 64 runs one wavefront per QP with the KKT matrix in registers
+    (fb_dense_wave.h): up to eight workgroups of 64 threads per CU, A', the LDL'
+    multipliers, H and G' in a per-workgroup global scratch.  Same exit flags and
+    iteration counts as the four-wavefront kernel with K in LDS (fb_dense.h,
+    FBSTAB_HIP_DENSE_THREADS=256) and as the oracle; the two kernels factor with
+    different rounding (pivot column from the lane's own row against a pivot row
+    read back from LDS), so the solutions agree to the solver tolerance, not bitwise."""
+    nz, nl, nv = shape
+    p = fx.synthetic_dense_batch(40, nz, nl, nv, first_id=300 + nz)
+    o = default_options()
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=40)
+    q = s.query()
+    s.close()
+    assert q["threads"] == 64 and q["scratch_bytes"] > 0 and q["lds_bytes"] <= 40 * 1024, q
+    wave = _solve_dense_host(hip, p, o)
+    monkeypatch.setenv("FBSTAB_HIP_DENSE_THREADS", "256")
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=40)
+    assert s.query()["threads"] == 256
+    s.close()
+    four = _solve_dense_host(hip, p, o)
+    monkeypatch.delenv("FBSTAB_HIP_DENSE_THREADS")
+    cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(wave, cpu, o.abs_tol)
+    _assert_parity(wave, four, o.abs_tol)
+
+
 @pytest.mark.parametrize("shape", [(110, 20, 150), (150, 20, 220), (200, 0, 260)])
 def test_dense_kkt_matrix_larger_than_lds(hip, oracle, shape):
     """nz + nl beyond ~140: K = (nz+nl)^2 doubles no longer fits the 160 KiB LDS
