@@ -355,7 +355,9 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
 def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200):
     """BASELINE configs[4]: warm-started receding-horizon sweep, plant step
     x+ = A x + B u0, retirement of failed trajectories and the warm start all on
-    the device, one C call for the whole sweep (fbstab_hip_mpc_receding_sweep)."""
+    the device, one C call and ONE launch for the whole sweep
+    (fbstab_hip_mpc_receding_sweep): every 16-lane row advances its own trajectory
+    through all the steps, so no trajectory waits for the slowest solve of a step."""
     p = fx.synthetic_mpc_batch(trajectories)
     N, nx, nu, nc = p.sizes()
     A, Bm = fx.quadrotor_model()
@@ -372,9 +374,11 @@ def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200):
     res = {"config": "BASELINE configs[4]: 4096 closed-loop trajectories x 200 steps, N=30 nx=12 nu=4 nc=20, "
                      "warm start (unshifted), x+ = A x + B u0 on the device, failed trajectories retired to the origin",
            "value": trajectories * steps / dt, "unit": "QPs/sec", "wall_ms_per_step": 1e3 * dt / steps,
-           # solve time per step as HIP events see it: the median is the warm steady
-           # state; the mean carries the steps in which a trajectory runs to the
-           # iteration limit before it is retired (a batch waits for its slowest QP)
+           # one launch: the device time of the launch divided by the steps, the same
+           # figure for every step (the launch lasts as long as its slowest TRAJECTORY;
+           # with a launch per step - FBSTAB_HIP_SWEEP_PER_STEP=1, the round-2 start -
+           # every step waited for its slowest QP: 790 ms against 350 ms)
+           "launches": 1, "kernel_ms_total": float(r["kernel_ms"].sum()),
            "kernel_ms_first": float(r["kernel_ms"][0]), "kernel_ms_median": float(np.median(r["kernel_ms"])),
            "kernel_ms_mean": float(r["kernel_ms"].mean()), "kernel_ms_max_after_first": float(r["kernel_ms"][1:].max()),
            "kernel_ms_last": float(r["kernel_ms"][-1]), "wall_over_kernel_sum": dt * 1e3 / float(r["kernel_ms"].sum()),

@@ -450,7 +450,11 @@ struct Solver : TraceState<TRACE> {
   //
   template <class Queue>
   FB_DEV void solve_stream(Queue& qu, fbstab_solver_out_t* out_base) const {
-    enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5 };
+    // kPause: (queues that ask for it, qu.align_rows()) a row that has finished a QP
+    // waits here until no row of the wavefront stands before a Newton step, and the
+    // waiting rows then fetch together: their passes over a fresh QP run side by side
+    // again instead of one row at a time.
+    enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5, kPause = 6 };
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -458,9 +462,17 @@ struct Solver : TraceState<TRACE> {
     double Ei = 0.0, Eo = 0.0, Eo_top = 0.0, Ei0 = 0.0;
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
+    [[maybe_unused]] bool fetch_now = true;  // (align_rows) the wavefront has just released its waiting rows
     for (;;) {
-      while (phase != kNewton && phase != kDone) {
+      while (phase != kNewton && phase != kDone && phase != kPause) {
         if (phase == kFetch) {
+          if constexpr (Queue::kCanAlignRows) {
+            if (qu.align_rows() && !fetch_now) {
+              phase = kPause;
+              continue;
+            }
+            fetch_now = false;
+          }
           const int q = qu.fetch(p);
           if (q < 0) {
             phase = kDone;
@@ -566,9 +578,21 @@ struct Solver : TraceState<TRACE> {
           phase = kProxTop;
         }
       }
-      if (phase == kDone) break;
+      if constexpr (Queue::kCanAlignRows) {
+        // (every row is here: none leaves the loop before all are done)
+        if (__ballot(phase == kNewton) == 0ull) {
+          if (__ballot(phase == kPause) == 0ull) break;
+          if (phase == kPause) {
+            phase = kFetch;
+            fetch_now = true;
+          }
+          continue;
+        }
+      } else {
+        if (phase == kDone) break;
+      }
       // ---- one Newton step and its line search (impl:262-298), all rows together
-      {
+      if (!Queue::kCanAlignRows || phase == kNewton) {
       // The loop's scalars are not needed until the line search is over: they wait
       // in LDS meanwhile (the sweeps have no registers to spare; left to the
       // compiler they are spilled to scratch memory inside the passes).

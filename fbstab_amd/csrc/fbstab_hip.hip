@@ -170,6 +170,70 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
 // returns row-uniform values.  Nothing in here waits for another wavefront.
 constexpr size_t kQueueBytes = 8 * sizeof(int);
 
+// The receding-horizon sweep as ONE launch of a KEEP instance (fbstab_hip_mpc_receding_sweep):
+// a row then solves ITS trajectory `steps` times, advancing the plant in between, and
+// never waits for another trajectory - a batch launch per step lasts as long as its
+// slowest QP, and a trajectory that runs to the iteration limit before it is retired
+// holds up the other 4095 for a hundred solves' worth of time.  Lives in device memory;
+// the kernel gets the pointer through its (otherwise unused) probe argument.
+struct SweepArgs {
+  const double* A;  // simulation model x+ = A x + B u0 (ocp_generator.h:31-38), column-major
+  const double* B;
+  long long sA, sB;     // doubles between trajectories (0: one plant for all)
+  double* x0;           // the batch's initial states, advanced in place
+  long long sx0;
+  double* u_log;        // NULL or [steps][batch][nu]
+  unsigned long long* stats;  // [steps][4]
+  int steps, retire;
+  int nx, nu, nz, nl, nv;
+};
+
+// Closed-loop step of trajectory q after its solve number `step`, by the lanes of its
+// row (t = lane within the row, lpq = lanes per row): retirement, statistics, u0 and
+// x0 <- A x0 + B u0 - what fbstab_receding_plant_kernel does for a whole batch between
+// two launches.  Returns the updated `retired` flag.  A real call: inlined into the
+// solver loop its temporaries cost the sweeps 60 spilled registers.
+__device__ __noinline__ bool receding_plant_step(const SweepArgs* sweep, const VarBatchPtrs* x,
+                                                 const fbstab_solver_out_t* out, int batch, int q, int step, int t,
+                                                 int lpq, bool gone) {
+  const SweepArgs& a = *sweep;
+  // the solve's own stores (solution, SolverOut) are read back by other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int eflag = out[q].eflag, newton = out[q].newton_iters;
+  double* z = x->base[0] + q * x->stride[0];
+  if (a.retire && !gone && eflag != FBSTAB_SUCCESS) {
+    gone = true;
+    double* l = x->base[1] + q * x->stride[1];
+    double* v = x->base[2] + q * x->stride[2];
+    for (int i = t; i < a.nz; i += lpq) z[i] = 0.0;
+    for (int i = t; i < a.nl; i += lpq) l[i] = 0.0;
+    for (int i = t; i < a.nv; i += lpq) v[i] = 0.0;
+  }
+  if (t == 0) {
+    unsigned long long* st = a.stats + 4 * (long long)step;
+    atomicAdd(&st[0], (unsigned long long)newton);
+    atomicAdd(&st[1], (unsigned long long)(eflag == FBSTAB_SUCCESS ? 1 : 0));
+    atomicAdd(&st[2], (unsigned long long)(gone ? 1 : 0));
+    atomicMax(&st[3], (unsigned long long)newton);
+  }
+  if (a.u_log && t < a.nu) a.u_log[((long long)step * batch + q) * a.nu + t] = gone ? 0.0 : z[a.nx + t];
+  double* xs = a.x0 + q * a.sx0;
+  const double* Aq = a.A + q * a.sA;
+  const double* Bq = a.B + q * a.sB;
+  double acc = 0.0;  // (nx <= lanes of the row: one entry per lane)
+  if (t < a.nx) {
+    for (int c = 0; c < a.nx; c++) acc = fma(Aq[t + c * a.nx], xs[c], acc);
+    for (int j = 0; j < a.nu; j++) acc = fma(Bq[t + j * a.nx], gone ? 0.0 : z[a.nx + j], acc);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane has read x0
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (t < a.nx) xs[t] = gone ? 0.0 : acc;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return gone;
+}
+
 template <class P, bool KEEP>
 struct R16Queue {
   // Only launch-uniform values live in here (SGPRs): the sweeps have no registers
@@ -182,6 +246,10 @@ struct R16Queue {
   int batch, N;
   bool reuse;
   bool taken = false;  // (KEEP) this row has had its one QP
+  // (KEEP, sweep) solves of this row's trajectory finished so far; bit 30: retired
+  int swept = 0;
+  const SweepArgs* sweep = nullptr;
+  fbstab_solver_out_t* out = nullptr;
 
   static __device__ __forceinline__ int tid() { return threadIdx.x & (P::LPQ - 1); }
   static __device__ __forceinline__ int row() { return threadIdx.x / P::LPQ; }  // QP slot of the wavefront
@@ -200,11 +268,27 @@ struct R16Queue {
   }
   __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
 
+  // Sweep: the rows of a wavefront start every step of their trajectories together
+  // (Solver::solve_stream, kPause) - warm-started steps are mostly passes over the
+  // records, which four rows out of step would run one after the other.
+  static constexpr bool kCanAlignRows = KEEP;  // (the batch instances compile the plain loop)
+  __device__ __forceinline__ bool align_rows() const { return sweep != nullptr; }
   // Binds the policy to the next QP of the queue, in this row's own slot.
   __device__ __forceinline__ int fetch(P& pp) {
     int q = 0;
     if constexpr (KEEP) {
       q = home();
+      if (sweep) {
+        if (q >= batch) return -1;
+        const int done = swept & 0xffff;
+        bool gone = (swept & (1 << 30)) != 0;
+        if (done > 0) gone = receding_plant_step(sweep, x, out, batch, q, done - 1, tid(), P::LPQ, gone);
+        if (done >= sweep->steps) return -1;
+        swept = (done + 1) | (gone ? (1 << 30) : 0);
+        pp.bind(slot_ptr(home()), lds(), lpo(), data, x, q, N, tid());
+        pp.reuse = reuse || done > 0;
+        return q;
+      }
       if (taken) return -1;
       taken = true;
     } else {
@@ -241,6 +325,10 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
   qu.batch = batch;
   qu.N = N;
   qu.reuse = reuse != 0;
+  if constexpr (KEEP && !DBG) {
+    qu.sweep = reinterpret_cast<const SweepArgs*>(dbg);
+    qu.out = out;
+  }
   if constexpr (DBG) {
     if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
@@ -972,6 +1060,44 @@ int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t h, int batch, const fbstab
   for (int i = 0; i < 4; i++) { v.base[i] = x->base[i]; v.stride[i] = x->stride[i]; }
   const fbk::MpcLayout& L = h->lay;
   double* x0 = const_cast<double*>(data->base[FBSTAB_MPC_x0]);
+  // Record kernels: the whole sweep is ONE launch of the KEEP instance, every row
+  // looping over its own trajectory (SweepArgs; FBSTAB_HIP_SWEEP_PER_STEP=1 keeps the
+  // launch per step below, which the flat-vector kernel always uses).
+  const char* per_step = getenv("FBSTAB_HIP_SWEEP_PER_STEP");
+  if (h->rec && batch <= h->workgroups * h->qps_per_wg && steps < 0xffff && !(per_step && atoi(per_step) != 0)) {
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
+      if (!data->base[i]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer");
+    SweepArgs sa;
+    sa.A = plant->A; sa.B = plant->B; sa.sA = plant->stride_A; sa.sB = plant->stride_B;
+    sa.x0 = x0; sa.sx0 = data->stride[FBSTAB_MPC_x0];
+    sa.u_log = u_log; sa.stats = static_cast<unsigned long long*>(d_stats.p);
+    sa.steps = steps; sa.retire = retire;
+    sa.nx = L.nx; sa.nu = L.nu; sa.nz = L.nz; sa.nl = L.nl; sa.nv = L.nv;
+    DevBuf d_sa;
+    HIP_TRY(hipMalloc(&d_sa.p, sizeof(SweepArgs)));
+    HIP_TRY(hipMemcpyAsync(d_sa.p, &sa, sizeof(SweepArgs), hipMemcpyHostToDevice, s));
+    MpcBatchArgs a;
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { a.base[i] = data->base[i]; a.stride[i] = data->stride[i]; }
+    HIP_TRY(hipMemsetAsync(h->counter, 0, kQueueBytes, s));
+    HIP_TRY(hipEventRecord(h->ev0, s));
+    const RecordInstance& r = *h->rec;
+    rc = launch_record(h, h->exact ? r.solve_keep_exact : r.solve_keep, (batch + h->qps_per_wg - 1) / h->qps_per_wg, s,
+                       a, v, out, batch, static_cast<double*>(d_sa.p), false);
+    if (rc != FBSTAB_HIP_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    h->kept_batch = batch;
+    if (stats)
+      HIP_TRY(hipMemcpyAsync(stats, d_stats.p, sizeof(unsigned long long) * 4 * (size_t)steps, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (kernel_ms) {  // one launch: every step is charged its share
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      for (int k = 0; k < steps; k++) kernel_ms[k] = ms / (float)steps;
+    }
+    return FBSTAB_HIP_OK;
+  }
   const int flags = FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_ASYNC | FBSTAB_HIP_KEEP_MATRICES;
   h->kept_batch = -1;  // the first step builds the matrix copies
   for (int k = 0; k < steps; k++) {

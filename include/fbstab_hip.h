@@ -164,6 +164,11 @@ int fbstab_hip_mpc_solve_traced(fbstab_mpc_handle_t handle, const fbstab_mpc_bat
  *   stats:   NULL or HOST array [steps][4]: sum of Newton iterations, solves ended in
  *            SUCCESS, trajectories retired so far, largest Newton count of the step.
  *   kernel_ms: NULL or HOST array [steps]: device time of each step's solve.
+ * Shapes served by a record kernel run the whole sweep as ONE launch in which every
+ * trajectory advances at its own pace (no trajectory waits for the slowest solve of a
+ * step; same results per trajectory and per step); kernel_ms[k] is then the launch
+ * time / steps for every k.  Other shapes (or FBSTAB_HIP_SWEEP_PER_STEP=1) queue one
+ * solve launch and one plant launch per step.
  * Synchronous: returns when the sweep has finished. */
 typedef struct fbstab_receding_plant_t {
   const double* A;      /* nx x nx, column-major */

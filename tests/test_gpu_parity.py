@@ -814,6 +814,48 @@ def test_receding_sweep_on_the_device_matches_the_oracle_loop(hip, oracle):
     s.close()
 
 
+def test_receding_sweep_in_one_launch_equals_a_launch_per_step(hip, monkeypatch):
+    """The sweep as one launch of the record kernel's KEEP instance (every 16-lane row
+    runs its own trajectory through all the steps, the rows of a wavefront starting each
+    step together) against the sweep as one solve launch + one plant launch per step
+    (FBSTAB_HIP_SWEEP_PER_STEP=1): the work of a trajectory is the same sequence of
+    operations either way, so inputs, states, solutions and statistics are BITWISE
+    equal - including trajectories that are retired."""
+    import torch
+    T, S = 200, 15
+    p = fx.synthetic_mpc_batch(T, first_id=31000)
+    p.arrays["x0"][7, 6:9] = [2.5, -2.5, 2.5]
+    p.arrays["x0"][100, 3:6] = [40.0, -40.0, 40.0]
+    N, nx, nu, nc = p.sizes()
+    A, B = fx.quadrotor_model()
+    dev = torch.device("cuda:0")
+
+    def run():
+        s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=T)
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        r = s.RecedingSweep(data, z, l, v, y, A, B, S, retire=True, log_inputs=True)
+        res = dict(u=r["u"].cpu().numpy(), x0=data["x0"].cpu().numpy(), z=z.cpu().numpy(), v=v.cpu().numpy(),
+                   stats=r["stats"].copy(), out=hip_out(r["out"]), kms=r["kernel_ms"].copy())
+        s.close()
+        return res
+
+    hip_out = hip.out_to_numpy
+    one = run()
+    monkeypatch.setenv("FBSTAB_HIP_SWEEP_PER_STEP", "1")
+    per = run()
+    monkeypatch.delenv("FBSTAB_HIP_SWEEP_PER_STEP")
+    assert one["stats"]["retired_total"][-1] >= 1
+    assert len(set(one["kms"].tolist())) == 1 and len(set(per["kms"].tolist())) > 1   # one launch / many
+    for k in ("u", "x0", "z", "v"):
+        assert np.array_equal(one[k], per[k]), k
+    for k in one["stats"].dtype.names:
+        assert np.array_equal(one["stats"][k], per["stats"][k]), k
+    for k in ("eflag", "newton_iters", "prox_iters", "residual"):
+        assert np.array_equal(one["out"][k], per["out"][k]), k
+
+
 def test_config5_full_sweep_with_an_oracle_subset(hip, oracle):
     """BASELINE configs[4] at full size: 4096 trajectories x 200 steps on the device.
     The trajectories are independent, so the 64 of them with ids 0, 64, 128, ... are
