@@ -175,7 +175,7 @@ def main():
                 if timed:
                     ln.events.append((e0, e1))
                 if gather:
-                    sharding.gather_solutions(ln.x, ln.out, dst=0, record=ln.rec, gather_list=ln.grec)
+                    sharding.gather_solutions(ln.x, ln.out, dst=0, record=ln.rec, gather_list=ln.grec, stack=False)
 
         def fence():
             torch.cuda.synchronize()

@@ -33,7 +33,8 @@ def unpack_out(record):
     return np.frombuffer(tail.tobytes(), dtype=OUT_DTYPE).copy()
 
 
-def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[List] = None):
+def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[List] = None,
+                     stack: bool = True):
     """ONE gather of this rank's results to ``dst``: the solutions ``x``
     (``(B, nz+nl+2nv)`` float64) and the ``out`` records (``(B, 40)`` uint8
     SolverOut) travel side by side in one ``(B, nvar + 5)`` float64 record per QP.
@@ -41,7 +42,9 @@ def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[Li
     (then only the 40 bytes per QP of ``out`` are copied); ``gather_list``:
     optional preallocated receive buffers on ``dst``.  Returns ``(X, O)`` stacked in
     global instance order on ``dst`` (``O`` as uint8 ``(W*B, 40)``), ``(None,
-    None)`` elsewhere."""
+    None)`` elsewhere.  ``stack=False`` (a caller that keeps its own receive
+    buffers): no stacked copy is made on ``dst`` - at eight ranks that copy is
+    1.1 GB per batch - and ``(gather_list, None)`` is returned there."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -58,5 +61,7 @@ def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[Li
     dist.gather(record, gather_list, dst=dst)
     if rank != dst:
         return None, None
+    if not stack:
+        return gather_list, None
     full = torch.cat(gather_list, dim=0)
     return full[:, :nvar], full[:, nvar:].contiguous().view(torch.uint8).view(-1, 40)

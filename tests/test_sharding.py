@@ -36,8 +36,11 @@ def _worker(rank, world, port, per_rank, q):
     rec[:, :x.shape[1]] = x
     glist = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
     X2, O2 = sharding.gather_solutions(rec[:, :x.shape[1]], o, dst=0, record=rec, gather_list=glist)
+    # ... and without the stacked copy on rank 0 (bench.py: the receive buffers are kept)
+    G3, none = sharding.gather_solutions(rec[:, :x.shape[1]], o, dst=0, record=rec, gather_list=glist, stack=False)
+    assert none is None and (G3 is glist if rank == 0 else G3 is None)
     dist.gather = real_gather
-    assert len(calls) == 2, "one collective per batch"
+    assert len(calls) == 3, "one collective per batch"
     if rank == 0:
         assert torch.equal(X, X2) and torch.equal(O, O2)
         unpacked = np.concatenate([sharding.unpack_out(g) for g in glist])
