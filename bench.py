@@ -337,12 +337,25 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
     ok = all((o["eflag"] == 0).all() for o in outs)
     per_step = dt / steps
     ach = DENSE_ALG_BYTES_PER_QP * batch / per_step / 1e9
+    # HBM bytes per launch from the newest committed counter summary of the dense kernel
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; replayed, not measured in this run)
+    traffic, traffic_src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dense_wave_counters.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            traffic = t["derived"]["hbm_bytes_per_launch_raw"]
+            traffic_src = "profiles/" + os.path.basename(path) + " (replayed)"
+            break
+        except (OSError, ValueError, KeyError):
+            pass
     r = {"config": "BASELINE configs[1]: batched FBstabDense, batch=4096, nz=50 nl=10 nv=100, cold start",
          "value": batch * steps / dt, "unit": "QPs/sec", "ms_per_step": 1e3 * per_step, "steps": steps,
          "steps_in_flight": lanes, "kernel_ms": k_ms, "serial_value": batch / (k_ms * 1e-3),
          "mean_newton_iters": float(outs[0]["newton_iters"].mean()), "all_converged": ok,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                       "kernel": "fbstab_dense_wave_kernel" if L[0]["s"].query()["threads"] == 64
                       else "fbstab_dense_kernel",
                       "algorithmic_bytes_per_launch": DENSE_ALG_BYTES_PER_QP * batch},
