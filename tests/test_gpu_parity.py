@@ -381,6 +381,22 @@ def test_dense_one_wavefront_kernel_is_selected_and_agrees_with_the_four_wavefro
     _assert_parity(wave, four, o.abs_tol)
 
 
+def test_dense_many_constraints_fall_back_to_the_four_wavefront_kernel(hip, oracle):
+    """nz + nl <= 64 but so many inequality constraints that the iterate vectors do not
+    fit the one-wavefront kernel's share of the LDS (40 KB): the four-wavefront kernel
+    takes the problem (A read from global memory) and agrees with the oracle."""
+    nz, nl, nv = 20, 5, 700
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=12)
+    q = s.query()
+    s.close()
+    assert q["threads"] == 256, q
+    p = fx.synthetic_dense_batch(12, nz, nl, nv, first_id=4100)
+    o = default_options()
+    gpu = _solve_dense_host(hip, p, o)
+    cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+
+
 @pytest.mark.parametrize("shape", [(110, 20, 150), (150, 20, 220), (200, 0, 260)])
 def test_dense_kkt_matrix_larger_than_lds(hip, oracle, shape):
     """nz + nl beyond ~140: K = (nz+nl)^2 doubles no longer fits the 160 KiB LDS
