@@ -64,6 +64,9 @@ struct MpcR16 {
   // pair, two QPs per wavefront - fb_row16.h), QPs per wavefront
   static constexpr int LPQ = 16 * RQ, kQpPerWave = 64 / LPQ;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
+#ifndef FB_R16_ASM_IMAGES
+#define FB_R16_ASM_IMAGES 1
+#endif
   static constexpr bool kFusedTrial = true;
   static constexpr bool kOwnVectorOps = true;
   static constexpr int NS = NX + NU;
@@ -151,6 +154,145 @@ struct MpcR16 {
   // 24 spare doubles behind the images for the solver loop's parked scalars
   static constexpr int kLdsBase = ((kLdsDoubles + 31) & ~31) + 16;
   static constexpr int kLdsPerRow = kLdsBase - kLdsDoubles >= 24 ? kLdsBase : kLdsBase + 32;
+
+
+  // ---- the triangle images in LDS, hand-scheduled (instance <12,4,20>, one row per QP) ----
+  // Element (j, c) of a packed lower triangle sits at tri(j) + c of a linear image; lane r
+  // writes its column (elements (j, r), j >= r) or row (elements (r, c), c <= r) and
+  // reads them back the other way round.  Left to the compiler each of these predicated
+  // accesses is five to fifteen instructions (address select against a dump word, masks
+  // read back from spilled scalars with v_readlane, the LDS base fetched from an AGPR
+  // every time, a branch round every store) and the reads come back one at a time, each
+  // behind its own s_waitcnt because their registers are reused.  Here the predicate
+  // lives in EXEC: the columns are walked in the order in which the set of lanes that
+  // take part only shrinks, so ONE v_cmpx per element narrows EXEC and ONE ds
+  // instruction with an immediate offset does the access; all reads of a block are in
+  // flight together and waited for once.  EXEC is restored before the block ends.
+  static constexpr bool kAsmImages = FB_R16_ASM_IMAGES && RQ == 1 && NS == 16 && NX == 12;
+  static FB_DEV unsigned lds_addr(lds_ptr p) { return (unsigned)(unsigned long)p; }
+#define FB_IMG_WP(cc, off) "v_cmpx_le_i32_e32 vcc, " #cc ", %[ro]\n\tds_write_b64 %[rb], %[p" #cc "] offset:" #off "\n\t"
+#define FB_IMG_WX(j, off) "v_cmpx_ge_i32_e32 vcc, " #j ", %[ro]\n\tds_write_b64 %[rb], %[c" #j "] offset:" #off "\n\t"
+#define FB_IMG_RR(j, off) "v_cmpx_le_i32_e32 vcc, " #j ", %[ro]\n\tds_read_b64 %[r" #j "], %[rbr] offset:" #off "\n\t"
+#define FB_IMG_RC(j, off) "v_cmpx_ge_i32_e32 vcc, " #j ", %[ro]\n\tds_read_b64 %[c" #j "], %[rbc] offset:" #off "\n\t"
+#define FB_IMG_RS(s, off) "ds_read_b64 %[s" #s "], %[rbc] offset:" #off "\n\t"
+#define FB_IMG_RPB(cc, off) "ds_read_b64 %[p" #cc "], %[rbpc] offset:" #off "\n\t"
+#define FB_IMG_RPA(cc, off) "v_cmpx_le_i32_e32 vcc, " #cc ", %[ro]\n\tds_read_b64 %[p" #cc "], %[rbpr] offset:" #off "\n\t"
+  // Tr[kPl + tri(r) + cc] = Pv[cc] for cc <= r, lanes r < 12 (forward sweep)
+  static FB_DEV void img_write_pinv(lds_ptr row_r, int ro, const double (&Pv)[12]) {
+    unsigned long long sv;
+    const unsigned rb = lds_addr(row_r);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_i32_e32 vcc, 12, %[ro]\n\t"
+        FB_IMG_WP(0, 0) FB_IMG_WP(1, 8) FB_IMG_WP(2, 16) FB_IMG_WP(3, 24) FB_IMG_WP(4, 32) FB_IMG_WP(5, 40)
+        FB_IMG_WP(6, 48) FB_IMG_WP(7, 56) FB_IMG_WP(8, 64) FB_IMG_WP(9, 72) FB_IMG_WP(10, 80) FB_IMG_WP(11, 88)
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(sv)
+        : [rb] "v"(rb), [ro] "v"(ro), [p0] "v"(Pv[0]), [p1] "v"(Pv[1]), [p2] "v"(Pv[2]), [p3] "v"(Pv[3]),
+          [p4] "v"(Pv[4]), [p5] "v"(Pv[5]), [p6] "v"(Pv[6]), [p7] "v"(Pv[7]), [p8] "v"(Pv[8]), [p9] "v"(Pv[9]),
+          [p10] "v"(Pv[10]), [p11] "v"(Pv[11])
+        : "memory", "vcc");
+  }
+  // Tr[kXl + tri(j) + r] = XC[j] for j >= r (forward sweep); col_r = Tr + kXl + r
+  static FB_DEV void img_write_x(lds_ptr col_r, int ro, const double (&XC)[16]) {
+    unsigned long long sv;
+    const unsigned rb = lds_addr(col_r);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        FB_IMG_WX(15, 960) FB_IMG_WX(14, 840) FB_IMG_WX(13, 728) FB_IMG_WX(12, 624) FB_IMG_WX(11, 528)
+        FB_IMG_WX(10, 440) FB_IMG_WX(9, 360) FB_IMG_WX(8, 288) FB_IMG_WX(7, 224) FB_IMG_WX(6, 168) FB_IMG_WX(5, 120)
+        FB_IMG_WX(4, 80) FB_IMG_WX(3, 48) FB_IMG_WX(2, 24) FB_IMG_WX(1, 8) FB_IMG_WX(0, 0)
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(sv)
+        : [rb] "v"(rb), [ro] "v"(ro), [c0] "v"(XC[0]), [c1] "v"(XC[1]), [c2] "v"(XC[2]), [c3] "v"(XC[3]),
+          [c4] "v"(XC[4]), [c5] "v"(XC[5]), [c6] "v"(XC[6]), [c7] "v"(XC[7]), [c8] "v"(XC[8]), [c9] "v"(XC[9]),
+          [c10] "v"(XC[10]), [c11] "v"(XC[11]), [c12] "v"(XC[12]), [c13] "v"(XC[13]), [c14] "v"(XC[14]),
+          [c15] "v"(XC[15])
+        : "memory", "vcc");
+  }
+  // XR[j] = Tr[kXl + tri(r) + j] for j <= r, zero beyond (XR arrives zeroed), and the
+  // nine packed slots Xp[s] = Tr[kXl + 16 s + r] (forward sweep)
+  static FB_DEV void img_read_xrow_slots(lds_ptr row_r, lds_ptr col_r, int ro, double (&XR)[16], double (&Xp)[10]) {
+    unsigned long long sv;
+    const unsigned rbr = lds_addr(row_r), rbc = lds_addr(col_r);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        FB_IMG_RS(0, 0) FB_IMG_RS(1, 128) FB_IMG_RS(2, 256) FB_IMG_RS(3, 384) FB_IMG_RS(4, 512) FB_IMG_RS(5, 640)
+        FB_IMG_RS(6, 768) FB_IMG_RS(7, 896) FB_IMG_RS(8, 1024)
+        FB_IMG_RR(0, 0) FB_IMG_RR(1, 8) FB_IMG_RR(2, 16) FB_IMG_RR(3, 24) FB_IMG_RR(4, 32) FB_IMG_RR(5, 40)
+        FB_IMG_RR(6, 48) FB_IMG_RR(7, 56) FB_IMG_RR(8, 64) FB_IMG_RR(9, 72) FB_IMG_RR(10, 80) FB_IMG_RR(11, 88)
+        FB_IMG_RR(12, 96) FB_IMG_RR(13, 104) FB_IMG_RR(14, 112) FB_IMG_RR(15, 120)
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [sv] "=&s"(sv), [r0] "+v"(XR[0]), [r1] "+v"(XR[1]), [r2] "+v"(XR[2]), [r3] "+v"(XR[3]), [r4] "+v"(XR[4]),
+          [r5] "+v"(XR[5]), [r6] "+v"(XR[6]), [r7] "+v"(XR[7]), [r8] "+v"(XR[8]), [r9] "+v"(XR[9]),
+          [r10] "+v"(XR[10]), [r11] "+v"(XR[11]), [r12] "+v"(XR[12]), [r13] "+v"(XR[13]), [r14] "+v"(XR[14]),
+          [r15] "+v"(XR[15]), [s0] "=&v"(Xp[0]), [s1] "=&v"(Xp[1]), [s2] "=&v"(Xp[2]), [s3] "=&v"(Xp[3]),
+          [s4] "=&v"(Xp[4]), [s5] "=&v"(Xp[5]), [s6] "=&v"(Xp[6]), [s7] "=&v"(Xp[7]), [s8] "=&v"(Xp[8])
+        : [rbr] "v"(rbr), [rbc] "v"(rbc), [ro] "v"(ro)
+        : "memory", "vcc");
+  }
+  // Backward sweep: row r and column r of inv(Lc), row r of the symmetric inv(Pi), one
+  // block each, requested just before their products (all three at once are 88 registers
+  // that the sweep does not have: the allocator answered with a hundred AGPR copies).
+  // The destinations arrive zeroed.  XR[j] = Tr[kXl + tri(r) + j], j <= r.
+  static FB_DEV void img_read_xrow(lds_ptr xrow_r, int ro, double (&XR)[16]) {
+    unsigned long long sv;
+    const unsigned rbr = lds_addr(xrow_r);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        FB_IMG_RR(0, 0) FB_IMG_RR(1, 8) FB_IMG_RR(2, 16) FB_IMG_RR(3, 24) FB_IMG_RR(4, 32) FB_IMG_RR(5, 40)
+        FB_IMG_RR(6, 48) FB_IMG_RR(7, 56) FB_IMG_RR(8, 64) FB_IMG_RR(9, 72) FB_IMG_RR(10, 80) FB_IMG_RR(11, 88)
+        FB_IMG_RR(12, 96) FB_IMG_RR(13, 104) FB_IMG_RR(14, 112) FB_IMG_RR(15, 120)
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [sv] "=&s"(sv), [r0] "+v"(XR[0]), [r1] "+v"(XR[1]), [r2] "+v"(XR[2]), [r3] "+v"(XR[3]), [r4] "+v"(XR[4]),
+          [r5] "+v"(XR[5]), [r6] "+v"(XR[6]), [r7] "+v"(XR[7]), [r8] "+v"(XR[8]), [r9] "+v"(XR[9]),
+          [r10] "+v"(XR[10]), [r11] "+v"(XR[11]), [r12] "+v"(XR[12]), [r13] "+v"(XR[13]), [r14] "+v"(XR[14]),
+          [r15] "+v"(XR[15])
+        : [rbr] "v"(rbr), [ro] "v"(ro)
+        : "memory", "vcc");
+  }
+  // XC[j] = Tr[kXl + tri(j) + r], j >= r
+  static FB_DEV void img_read_xcol(lds_ptr xcol_r, int ro, double (&XC)[16]) {
+    unsigned long long sv;
+    const unsigned rbc = lds_addr(xcol_r);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        FB_IMG_RC(15, 960) FB_IMG_RC(14, 840) FB_IMG_RC(13, 728) FB_IMG_RC(12, 624) FB_IMG_RC(11, 528)
+        FB_IMG_RC(10, 440) FB_IMG_RC(9, 360) FB_IMG_RC(8, 288) FB_IMG_RC(7, 224) FB_IMG_RC(6, 168) FB_IMG_RC(5, 120)
+        FB_IMG_RC(4, 80) FB_IMG_RC(3, 48) FB_IMG_RC(2, 24) FB_IMG_RC(1, 8) FB_IMG_RC(0, 0)
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [sv] "=&s"(sv), [c0] "+v"(XC[0]), [c1] "+v"(XC[1]), [c2] "+v"(XC[2]), [c3] "+v"(XC[3]), [c4] "+v"(XC[4]),
+          [c5] "+v"(XC[5]), [c6] "+v"(XC[6]), [c7] "+v"(XC[7]), [c8] "+v"(XC[8]), [c9] "+v"(XC[9]),
+          [c10] "+v"(XC[10]), [c11] "+v"(XC[11]), [c12] "+v"(XC[12]), [c13] "+v"(XC[13]), [c14] "+v"(XC[14]),
+          [c15] "+v"(XC[15])
+        : [rbc] "v"(rbc), [ro] "v"(ro)
+        : "memory", "vcc");
+  }
+  // Pv[cc] = Tr[kPl + (cc <= r ? tri(r) + cc : tri(cc) + r)] on the lanes r < 12 (the
+  // second form is read first, the first over it where cc <= r: LDS operations of a
+  // wavefront complete in order)
+  static FB_DEV void img_read_pinv(lds_ptr prow_r, lds_ptr pcol_r, int ro, double (&Pv)[12]) {
+    unsigned long long sv;
+    const unsigned rbpr = lds_addr(prow_r), rbpc = lds_addr(pcol_r);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_i32_e32 vcc, 12, %[ro]\n\t"
+        FB_IMG_RPB(0, 0) FB_IMG_RPB(1, 8) FB_IMG_RPB(2, 24) FB_IMG_RPB(3, 48) FB_IMG_RPB(4, 80) FB_IMG_RPB(5, 120)
+        FB_IMG_RPB(6, 168) FB_IMG_RPB(7, 224) FB_IMG_RPB(8, 288) FB_IMG_RPB(9, 360) FB_IMG_RPB(10, 440)
+        FB_IMG_RPB(11, 528)
+        FB_IMG_RPA(0, 0) FB_IMG_RPA(1, 8) FB_IMG_RPA(2, 16) FB_IMG_RPA(3, 24) FB_IMG_RPA(4, 32) FB_IMG_RPA(5, 40)
+        FB_IMG_RPA(6, 48) FB_IMG_RPA(7, 56) FB_IMG_RPA(8, 64) FB_IMG_RPA(9, 72) FB_IMG_RPA(10, 80) FB_IMG_RPA(11, 88)
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [sv] "=&s"(sv), [p0] "+v"(Pv[0]), [p1] "+v"(Pv[1]), [p2] "+v"(Pv[2]), [p3] "+v"(Pv[3]), [p4] "+v"(Pv[4]),
+          [p5] "+v"(Pv[5]), [p6] "+v"(Pv[6]), [p7] "+v"(Pv[7]), [p8] "+v"(Pv[8]), [p9] "+v"(Pv[9]),
+          [p10] "+v"(Pv[10]), [p11] "+v"(Pv[11])
+        : [rbpr] "v"(rbpr), [rbpc] "v"(rbpc), [ro] "v"(ro)
+        : "memory", "vcc");
+  }
 
   // ---- state -------------------------------------------------------------------
   double* rec;   // this row's records, lane offset included
@@ -1159,10 +1301,14 @@ struct MpcR16 {
       const int tri_r = (ro * (ro + 1)) >> 1;
       {
         c.sync();  // the previous stage has read its images
-        sfor<0, NX>([&](auto Cc) {
-          constexpr int cc = decltype(Cc)::value;
-          Tr[(rx && cc <= ro) ? kPl + tri_r + cc : kDump] = Pinv[cc];
-        });
+        if constexpr (kAsmImages) {
+          img_write_pinv(Tr + kPl + tri_r, ro, Pinv);
+        } else {
+          sfor<0, NX>([&](auto Cc) {
+            constexpr int cc = decltype(Cc)::value;
+            Tr[(rx && cc <= ro) ? kPl + tri_r + cc : kDump] = Pinv[cc];
+          });
+        }
         c.sync();
         double Pp[nPs + 1];
         sfor<0, nPs>([&](auto S_) { Pp[decltype(S_)::value] = Tr[kPl + LPQ * decltype(S_)::value + r]; });
@@ -1187,7 +1333,14 @@ struct MpcR16 {
       // columns of inv(Lc) to the linear image of its lower triangle; rows (for t) and
       // the record's slots come back from it
       double XR[NS];
+      double Xp[nXs + 1];
       c.sync();
+      if constexpr (kAsmImages) {
+        img_write_x(Tr + kXl + ro, ro, XC);
+        c.sync();
+        sfor<0, NS>([&](auto J) { XR[decltype(J)::value] = 0.0; });
+        img_read_xrow_slots(Tr + kXl + tri_r, Tr + kXl + ro, ro, XR, Xp);
+      } else {
       sfor<0, NS>([&](auto J) {
         constexpr int j = decltype(J)::value;
         Tr[j >= ro ? kXl + tri(j) + r : kDump] = XC[j];
@@ -1198,8 +1351,8 @@ struct MpcR16 {
         const double v = Tr[kXl + tri_r + j];
         XR[j] = j <= ro ? v : 0.0;
       });
-      double Xp[nXs + 1];
       sfor<0, nXs>([&](auto S_) { Xp[decltype(S_)::value] = Tr[kXl + LPQ * decltype(S_)::value + r]; });
+      }
       if (LPQ * (nXs - 1) + r >= kXTri) Xp[nXs - 1] = 0.0;
       FB_SB();
       // t = inv(Lc) g
@@ -1311,6 +1464,7 @@ struct MpcR16 {
       c.sync();
       // column r and row r of inv(Lc), row r of inv(Pi)
       double XC[NS], XR[NS];
+      if constexpr (!kAsmImages) {
       sfor<0, NS>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const double vc = Tr[kXl + tri(j) + r], vr = Tr[kXl + tri_r + j];
@@ -1322,12 +1476,25 @@ struct MpcR16 {
         const double v = Tr[kPl + (cc <= ro ? tri_r + cc : tri(cc) + r)];
         Pinv[cc] = rx ? v : 0.0;
       });
+      }
       FB_SB();
       // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
+      if constexpr (kAsmImages) {
+        sfor<0, NS>([&](auto J) { XR[decltype(J)::value] = 0.0; });
+        img_read_xrow(Tr + kXl + tri_r, ro, XR);
+      }
       const double s = tcur - bc_dot<0, NS, RQ>(XR, u);
+      if constexpr (kAsmImages) {
+        sfor<0, NS>([&](auto J) { XC[decltype(J)::value] = 0.0; });
+        img_read_xcol(Tr + kXl + ro, ro, XC);
+      }
       const double dzu = bc_dot<0, NS, RQ>(XC, s);
       // dl = -inv(Pi)(theta + dx)
       const double tx = thcur + dzu;
+      if constexpr (kAsmImages) {
+        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
+        img_read_pinv(Tr + kPl + tri_r, Tr + kPl + ro, ro, Pinv);
+      }
       double dli = -bc_dot<0, NX, RQ>(Pinv, tx);
       if (!rx) dli = 0.0;
       FB_SB();
