@@ -167,7 +167,9 @@ struct MpcR16 {
   // lives in EXEC: the columns are walked in the order in which the set of lanes that
   // take part only shrinks, so ONE v_cmpx per element narrows EXEC and ONE ds
   // instruction with an immediate offset does the access; all reads of a block are in
-  // flight together and waited for once.  EXEC is restored before the block ends.
+  // flight together and waited for once.  EXEC is restored before the block ends, and
+  // five wait states follow (the compiler's hazard recognizer does not look inside the
+  // block: a DPP instruction of its own must not sit in the shadow of the last v_cmpx).
   static constexpr bool kAsmImages = FB_R16_ASM_IMAGES && RQ == 1 && NS == 16 && NX == 12;
   static FB_DEV unsigned lds_addr(lds_ptr p) { return (unsigned)(unsigned long)p; }
 #define FB_IMG_WP(cc, off) "v_cmpx_le_i32_e32 vcc, " #cc ", %[ro]\n\tds_write_b64 %[rb], %[p" #cc "] offset:" #off "\n\t"
@@ -186,7 +188,8 @@ struct MpcR16 {
         "v_cmpx_gt_i32_e32 vcc, 12, %[ro]\n\t"
         FB_IMG_WP(0, 0) FB_IMG_WP(1, 8) FB_IMG_WP(2, 16) FB_IMG_WP(3, 24) FB_IMG_WP(4, 32) FB_IMG_WP(5, 40)
         FB_IMG_WP(6, 48) FB_IMG_WP(7, 56) FB_IMG_WP(8, 64) FB_IMG_WP(9, 72) FB_IMG_WP(10, 80) FB_IMG_WP(11, 88)
-        "s_mov_b64 exec, %[sv]"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_nop 4"
         : [sv] "=&s"(sv)
         : [rb] "v"(rb), [ro] "v"(ro), [p0] "v"(Pv[0]), [p1] "v"(Pv[1]), [p2] "v"(Pv[2]), [p3] "v"(Pv[3]),
           [p4] "v"(Pv[4]), [p5] "v"(Pv[5]), [p6] "v"(Pv[6]), [p7] "v"(Pv[7]), [p8] "v"(Pv[8]), [p9] "v"(Pv[9]),
@@ -202,7 +205,8 @@ struct MpcR16 {
         FB_IMG_WX(15, 960) FB_IMG_WX(14, 840) FB_IMG_WX(13, 728) FB_IMG_WX(12, 624) FB_IMG_WX(11, 528)
         FB_IMG_WX(10, 440) FB_IMG_WX(9, 360) FB_IMG_WX(8, 288) FB_IMG_WX(7, 224) FB_IMG_WX(6, 168) FB_IMG_WX(5, 120)
         FB_IMG_WX(4, 80) FB_IMG_WX(3, 48) FB_IMG_WX(2, 24) FB_IMG_WX(1, 8) FB_IMG_WX(0, 0)
-        "s_mov_b64 exec, %[sv]"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_nop 4"
         : [sv] "=&s"(sv)
         : [rb] "v"(rb), [ro] "v"(ro), [c0] "v"(XC[0]), [c1] "v"(XC[1]), [c2] "v"(XC[2]), [c3] "v"(XC[3]),
           [c4] "v"(XC[4]), [c5] "v"(XC[5]), [c6] "v"(XC[6]), [c7] "v"(XC[7]), [c8] "v"(XC[8]), [c9] "v"(XC[9]),
@@ -223,7 +227,8 @@ struct MpcR16 {
         FB_IMG_RR(6, 48) FB_IMG_RR(7, 56) FB_IMG_RR(8, 64) FB_IMG_RR(9, 72) FB_IMG_RR(10, 80) FB_IMG_RR(11, 88)
         FB_IMG_RR(12, 96) FB_IMG_RR(13, 104) FB_IMG_RR(14, 112) FB_IMG_RR(15, 120)
         "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_nop 4"
         : [sv] "=&s"(sv), [r0] "+v"(XR[0]), [r1] "+v"(XR[1]), [r2] "+v"(XR[2]), [r3] "+v"(XR[3]), [r4] "+v"(XR[4]),
           [r5] "+v"(XR[5]), [r6] "+v"(XR[6]), [r7] "+v"(XR[7]), [r8] "+v"(XR[8]), [r9] "+v"(XR[9]),
           [r10] "+v"(XR[10]), [r11] "+v"(XR[11]), [r12] "+v"(XR[12]), [r13] "+v"(XR[13]), [r14] "+v"(XR[14]),
@@ -245,7 +250,8 @@ struct MpcR16 {
         FB_IMG_RR(6, 48) FB_IMG_RR(7, 56) FB_IMG_RR(8, 64) FB_IMG_RR(9, 72) FB_IMG_RR(10, 80) FB_IMG_RR(11, 88)
         FB_IMG_RR(12, 96) FB_IMG_RR(13, 104) FB_IMG_RR(14, 112) FB_IMG_RR(15, 120)
         "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_nop 4"
         : [sv] "=&s"(sv), [r0] "+v"(XR[0]), [r1] "+v"(XR[1]), [r2] "+v"(XR[2]), [r3] "+v"(XR[3]), [r4] "+v"(XR[4]),
           [r5] "+v"(XR[5]), [r6] "+v"(XR[6]), [r7] "+v"(XR[7]), [r8] "+v"(XR[8]), [r9] "+v"(XR[9]),
           [r10] "+v"(XR[10]), [r11] "+v"(XR[11]), [r12] "+v"(XR[12]), [r13] "+v"(XR[13]), [r14] "+v"(XR[14]),
@@ -263,7 +269,8 @@ struct MpcR16 {
         FB_IMG_RC(10, 440) FB_IMG_RC(9, 360) FB_IMG_RC(8, 288) FB_IMG_RC(7, 224) FB_IMG_RC(6, 168) FB_IMG_RC(5, 120)
         FB_IMG_RC(4, 80) FB_IMG_RC(3, 48) FB_IMG_RC(2, 24) FB_IMG_RC(1, 8) FB_IMG_RC(0, 0)
         "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_nop 4"
         : [sv] "=&s"(sv), [c0] "+v"(XC[0]), [c1] "+v"(XC[1]), [c2] "+v"(XC[2]), [c3] "+v"(XC[3]), [c4] "+v"(XC[4]),
           [c5] "+v"(XC[5]), [c6] "+v"(XC[6]), [c7] "+v"(XC[7]), [c8] "+v"(XC[8]), [c9] "+v"(XC[9]),
           [c10] "+v"(XC[10]), [c11] "+v"(XC[11]), [c12] "+v"(XC[12]), [c13] "+v"(XC[13]), [c14] "+v"(XC[14]),
@@ -286,7 +293,8 @@ struct MpcR16 {
         FB_IMG_RPA(0, 0) FB_IMG_RPA(1, 8) FB_IMG_RPA(2, 16) FB_IMG_RPA(3, 24) FB_IMG_RPA(4, 32) FB_IMG_RPA(5, 40)
         FB_IMG_RPA(6, 48) FB_IMG_RPA(7, 56) FB_IMG_RPA(8, 64) FB_IMG_RPA(9, 72) FB_IMG_RPA(10, 80) FB_IMG_RPA(11, 88)
         "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_nop 4"
         : [sv] "=&s"(sv), [p0] "+v"(Pv[0]), [p1] "+v"(Pv[1]), [p2] "+v"(Pv[2]), [p3] "+v"(Pv[3]), [p4] "+v"(Pv[4]),
           [p5] "+v"(Pv[5]), [p6] "+v"(Pv[6]), [p7] "+v"(Pv[7]), [p8] "+v"(Pv[8]), [p9] "+v"(Pv[9]),
           [p10] "+v"(Pv[10]), [p11] "+v"(Pv[11])
