@@ -751,6 +751,10 @@ RecordInstance r16_instance(const char* name) {
 const RecordInstance* record_instances(int* count) {
   static const RecordInstance table[] = {
       r16_instance<12, 4, 20>("fbstab_mpc_r16_kernel<12,4,20>"),
+      // the same stage width with up to two constraint rows per stage variable (two-sided
+      // bounds on all of x and u written as 32 rows); a third of its registers' worth of
+      // constraint slots more than the instance above, so that one stays the first choice
+      r16_instance<12, 4, 32>("fbstab_mpc_r16_kernel<12,4,32>"),
       // two 16-lane rows per QP: 16 < nx + nu <= 23 (the reference's copolymerization
       // reactor, nx = 18, nu = 5, nc = 10: fbstab/test/ocp_generator.cc:73-174)
       r16_instance<18, 5, 10, 2>("fbstab_mpc_r32_kernel<18,5,10>"),

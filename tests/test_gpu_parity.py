@@ -329,6 +329,31 @@ def test_random_time_varying_shapes(hip, oracle, shape):
     _assert_parity(gpu, cpu, o.abs_tol)
 
 
+def test_up_to_32_constraint_rows_per_stage_run_on_a_record_kernel(hip, oracle):
+    """Stage width 16 with 21..32 constraint rows (two-sided bounds on every stage
+    variable are 32) has a record instance of its own instead of falling to the
+    flat-vector kernel: selection, then parity on the boxed BASELINE plant and on random
+    time-varying problems with dense rows."""
+    for nc, want in ((20, "fbstab_mpc_r16_kernel<12,4,20>"), (21, "fbstab_mpc_r16_kernel<12,4,32>"),
+                     (32, "fbstab_mpc_r16_kernel<12,4,32>"), (33, "fbstab_mpc_kernel<64>")):
+        s = hip.FBstabMpcBatch(5, 12, 4, nc, max_batch=8)
+        assert s.kernel_name() == want, (nc, s.kernel_name())
+        s.close()
+    o = default_options()
+    p = fx.boxed_mpc_batch(192)
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+    assert (cpu[4]["newton_iters"] > 3).all()
+    for shape in ((9, 12, 4, 32), (6, 10, 3, 27), (4, 3, 1, 21)):
+        N, nx, nu, nc = shape
+        rng = np.random.default_rng(77 + nc)
+        p = _random_ltv_mpc(rng, 24, N, nx, nu, nc)
+        gpu = _solve_mpc_host(hip, p, o)
+        cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+        _assert_parity(gpu, cpu, o.abs_tol)
+
+
 def test_dense_synthetic_batch_parity(hip, oracle):
     for (nz, nl, nv, B) in ((20, 5, 40, 64), (50, 10, 100, 256)):
         p = fx.synthetic_dense_batch(B, nz, nl, nv)

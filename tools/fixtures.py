@@ -404,6 +404,28 @@ def synthetic_mpc_batch(batch: int, first_id: int = 0, seed: int = MASTER_SEED,
     return p
 
 
+def boxed_mpc_batch(batch: int, first_id: int = 0, seed: int = MASTER_SEED, N: int = 30) -> MpcProblem:
+    """The plant and initial states of ``synthetic_mpc_batch`` with two-sided bounds on
+    ALL sixteen stage variables, written as 32 single-entry rows per stage
+    (E x + L u + d <= 0): the shape of the ``<12,4,32>`` record instance."""
+    p = synthetic_mpc_batch(batch, first_id=first_id, seed=seed, N=N)
+    nx, nu = p.nx, p.nu
+    nc = 2 * (nx + nu)
+    xmax = np.array([6.0, 6.0, 6.0, 2.0, 2.0, 2.0, 0.35, 0.35, 0.35, 3.0, 3.0, 3.0])
+    umax = np.array([4.0, 2.0, 2.0, 1.0])
+    E = np.zeros((nc, nx)); L = np.zeros((nc, nu)); d = np.zeros(nc)
+    E[0:nx] = np.eye(nx); E[nx:2 * nx] = -np.eye(nx)
+    d[0:nx] = -xmax; d[nx:2 * nx] = -xmax
+    L[2 * nx:2 * nx + nu] = np.eye(nu); L[2 * nx + nu:] = -np.eye(nu)
+    d[2 * nx:2 * nx + nu] = -umax; d[2 * nx + nu:] = -umax
+    q = MpcProblem(N, nx, nu, nc)
+    q.arrays = dict(p.arrays)
+    rep = lambda m: np.ascontiguousarray(np.broadcast_to(np.tile(m.T.reshape(-1), N + 1), (batch, (N + 1) * m.size)))
+    q.arrays["E"], q.arrays["L"] = rep(E), rep(L)      # column-major images
+    q.arrays["d"] = np.ascontiguousarray(np.broadcast_to(np.tile(d, N + 1), (batch, (N + 1) * nc)))
+    return q
+
+
 def synthetic_mpc_ltv_batch(batch: int, first_id: int = 0, seed: int = MASTER_SEED,
                             N: int = 30) -> MpcProblem:
     """The same plant and initial states as ``synthetic_mpc_batch`` posed as a
