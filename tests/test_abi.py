@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def lib():
     from fbstab_amd import hip_api
     if not os.path.exists(hip_api.LIB_PATH):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fbstab_amd", "csrc")])
+        subprocess.check_call(["make", "-j6", "-C", os.path.join(ROOT, "fbstab_amd", "csrc")])
     return hip_api.load_library()
 
 

@@ -12,7 +12,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "facade_tests")
 def _build():
     lib = os.path.join(ROOT, "fbstab_amd", "libfbstab_hip.so")
     if not os.path.exists(lib):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "fbstab_amd", "csrc")])
+        subprocess.check_call(["make", "-j6", "-C", os.path.join(ROOT, "fbstab_amd", "csrc")])
     subprocess.check_call(
         ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
          "-o", EXE, os.path.join(ROOT, "tests", "cpp", "facade_tests.cc"),

@@ -271,48 +271,7 @@ def test_smaller_shapes_run_padded_on_the_record_kernel(hip, oracle, monkeypatch
         assert np.abs(a_ - b_).max() <= 1e-6 * (1 + np.abs(b_).max())
 
 
-def _random_ltv_mpc(rng, batch, N, nx, nu, nc):
-    """Random time-varying MPC QPs: a positive definite stage Hessian [Q S';S R],
-    dynamics near the identity, dense constraint rows with a strictly feasible
-    trajectory by construction, small linear terms."""
-    ns = nx + nu
-    a = {}
-    Q = np.zeros((batch, N + 1, nx * nx)); R = np.zeros((batch, N + 1, nu * nu)); S = np.zeros((batch, N + 1, nu * nx))
-    for b in range(batch):
-        for i in range(N + 1):
-            M = rng.standard_normal((ns, ns))
-            Hs = M.T @ M / ns + 0.5 * np.eye(ns)
-            Q[b, i] = Hs[:nx, :nx].T.reshape(-1)       # column-major images
-            R[b, i] = Hs[nx:, nx:].T.reshape(-1)
-            S[b, i] = Hs[nx:, :nx].T.reshape(-1)       # S is nu x nx
-    a["Q"], a["R"], a["S"] = Q.reshape(batch, -1), R.reshape(batch, -1), S.reshape(batch, -1)
-    a["q"] = 0.1 * rng.standard_normal((batch, (N + 1) * nx))
-    a["r"] = 0.1 * rng.standard_normal((batch, (N + 1) * nu))
-    A = np.eye(nx)[None, None] + 0.15 * rng.standard_normal((batch, N, nx, nx))
-    a["A"] = np.transpose(A, (0, 1, 3, 2)).reshape(batch, -1)
-    a["B"] = (0.5 * rng.standard_normal((batch, N, nu, nx))).reshape(batch, -1)   # (nx x nu) column-major
-    a["c"] = 0.05 * rng.standard_normal((batch, N * nx))
-    a["E"] = (rng.standard_normal((batch, N + 1, nx, nc)) * (rng.random((batch, N + 1, nx, nc)) < 0.4)).reshape(batch, -1)
-    a["L"] = (rng.standard_normal((batch, N + 1, nu, nc)) * (rng.random((batch, N + 1, nu, nc)) < 0.6)).reshape(batch, -1)
-    a["x0"] = 0.5 * rng.standard_normal((batch, nx))
-    # feasible by construction: d is set from a simulated trajectory with small
-    # random inputs, with a strictly positive slack
-    Bm = np.transpose(a["B"].reshape(batch, N, nu, nx), (0, 1, 3, 2))   # (batch, N, nx, nu)
-    Em = np.transpose(a["E"].reshape(batch, N + 1, nx, nc), (0, 1, 3, 2))
-    Lm = np.transpose(a["L"].reshape(batch, N + 1, nu, nc), (0, 1, 3, 2))
-    cm = a["c"].reshape(batch, N, nx)
-    d = np.zeros((batch, N + 1, nc))
-    for b in range(batch):
-        x = a["x0"][b].copy()
-        for i in range(N + 1):
-            u = 0.2 * rng.standard_normal(nu)
-            d[b, i] = -(Em[b, i] @ x + Lm[b, i] @ u) - (0.2 + 0.8 * rng.random(nc))
-            if i < N:
-                x = A[b, i] @ x + Bm[b, i] @ u + cm[b, i]
-    a["d"] = d.reshape(batch, -1)
-    p = fx.MpcProblem(N, nx, nu, nc)
-    p.arrays = {k: np.ascontiguousarray(v) for k, v in a.items()}
-    return p
+_random_ltv_mpc = fx.random_ltv_mpc
 
 
 @pytest.mark.parametrize("shape", [(5, 1, 1, 1), (7, 3, 2, 5), (12, 12, 4, 20), (9, 11, 3, 17), (4, 5, 4, 20),
@@ -1090,6 +1049,28 @@ def test_reactor_shape_runs_on_the_two_row_record_kernel(hip, oracle):
     p = fx.MpcProblem(N, nx, nu, nc)
     p.arrays = {k: np.ascontiguousarray(np.broadcast_to(a, (B, a.shape[1]))).copy() for k, a in one.arrays.items()}
     p.arrays["x0"] = p.arrays["x0"] * (1.0 + 0.3 * rng.standard_normal((B, nx)))
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+
+
+@pytest.mark.parametrize("shape,kernel", [((6, 20, 6, 16), "fbstab_mpc_r32_kernel<24,8,16>"),
+                                          ((5, 24, 8, 32), "fbstab_mpc_r32_kernel<24,8,32>"),
+                                          ((7, 13, 4, 25), "fbstab_mpc_r32_kernel<24,8,32>"),
+                                          ((4, 17, 1, 11), "fbstab_mpc_r32_kernel<24,8,16>"),
+                                          ((3, 25, 2, 4), "fbstab_mpc_kernel<64>"),
+                                          ((3, 10, 9, 4), "fbstab_mpc_kernel<64>")])
+def test_stage_widths_up_to_32_run_on_the_general_two_row_instances(hip, oracle, shape, kernel):
+    """Any nx <= 24, nu <= 8 with up to 32 constraint rows per stage has a record
+    instance (two QPs per wavefront); what is wider still runs on the flat-vector
+    kernel.  Selection, then parity on random time-varying problems."""
+    N, nx, nu, nc = shape
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=8)
+    assert s.kernel_name() == kernel, s.kernel_name()
+    s.close()
+    rng = np.random.default_rng(500 + 10 * nx + nc)
+    p = _random_ltv_mpc(rng, 16, N, nx, nu, nc)
     o = default_options()
     gpu = _solve_mpc_host(hip, p, o)
     cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())

@@ -471,6 +471,50 @@ def synthetic_mpc_ltv_batch(batch: int, first_id: int = 0, seed: int = MASTER_SE
     return p
 
 
+def random_ltv_mpc(rng, batch, N, nx, nu, nc):
+    """Random time-varying MPC QPs: a positive definite stage Hessian [Q S';S R],
+    dynamics near the identity, dense constraint rows with a strictly feasible
+    trajectory by construction, small linear terms."""
+    ns = nx + nu
+    a = {}
+    Q = np.zeros((batch, N + 1, nx * nx)); R = np.zeros((batch, N + 1, nu * nu)); S = np.zeros((batch, N + 1, nu * nx))
+    for b in range(batch):
+        for i in range(N + 1):
+            M = rng.standard_normal((ns, ns))
+            Hs = M.T @ M / ns + 0.5 * np.eye(ns)
+            Q[b, i] = Hs[:nx, :nx].T.reshape(-1)       # column-major images
+            R[b, i] = Hs[nx:, nx:].T.reshape(-1)
+            S[b, i] = Hs[nx:, :nx].T.reshape(-1)       # S is nu x nx
+    a["Q"], a["R"], a["S"] = Q.reshape(batch, -1), R.reshape(batch, -1), S.reshape(batch, -1)
+    a["q"] = 0.1 * rng.standard_normal((batch, (N + 1) * nx))
+    a["r"] = 0.1 * rng.standard_normal((batch, (N + 1) * nu))
+    A = np.eye(nx)[None, None] + 0.15 * rng.standard_normal((batch, N, nx, nx))
+    a["A"] = np.transpose(A, (0, 1, 3, 2)).reshape(batch, -1)
+    a["B"] = (0.5 * rng.standard_normal((batch, N, nu, nx))).reshape(batch, -1)   # (nx x nu) column-major
+    a["c"] = 0.05 * rng.standard_normal((batch, N * nx))
+    a["E"] = (rng.standard_normal((batch, N + 1, nx, nc)) * (rng.random((batch, N + 1, nx, nc)) < 0.4)).reshape(batch, -1)
+    a["L"] = (rng.standard_normal((batch, N + 1, nu, nc)) * (rng.random((batch, N + 1, nu, nc)) < 0.6)).reshape(batch, -1)
+    a["x0"] = 0.5 * rng.standard_normal((batch, nx))
+    # feasible by construction: d is set from a simulated trajectory with small
+    # random inputs, with a strictly positive slack
+    Bm = np.transpose(a["B"].reshape(batch, N, nu, nx), (0, 1, 3, 2))   # (batch, N, nx, nu)
+    Em = np.transpose(a["E"].reshape(batch, N + 1, nx, nc), (0, 1, 3, 2))
+    Lm = np.transpose(a["L"].reshape(batch, N + 1, nu, nc), (0, 1, 3, 2))
+    cm = a["c"].reshape(batch, N, nx)
+    d = np.zeros((batch, N + 1, nc))
+    for b in range(batch):
+        x = a["x0"][b].copy()
+        for i in range(N + 1):
+            u = 0.2 * rng.standard_normal(nu)
+            d[b, i] = -(Em[b, i] @ x + Lm[b, i] @ u) - (0.2 + 0.8 * rng.random(nc))
+            if i < N:
+                x = A[b, i] @ x + Bm[b, i] @ u + cm[b, i]
+    a["d"] = d.reshape(batch, -1)
+    p = MpcProblem(N, nx, nu, nc)
+    p.arrays = {k: np.ascontiguousarray(v) for k, v in a.items()}
+    return p
+
+
 def synthetic_dense_batch(batch: int, nz: int, nl: int, nv: int,
                           first_id: int = 0,
                           seed: int = MASTER_SEED) -> DenseProblem:

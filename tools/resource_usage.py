@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "fbstab_amd", "csrc", "fbstab_hip.hip")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
-       "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_ru.so", src] + sys.argv[1:]
+       "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage", "-DFB_SINGLE_TU", "-o", "/tmp/_ru.so", src] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
