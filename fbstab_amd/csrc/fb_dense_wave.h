@@ -505,6 +505,9 @@ struct DenseWave {
     const double r0 = lane_of(v, 0), r1 = lane_of(v, 16), r2 = lane_of(v, 32), r3 = lane_of(v, 48);
     return fmax(fmax(r0, r1), fmax(r2, r3));
   }
+#ifndef FB_DW_W_FROM_THE_SYSTEM
+#define FB_DW_W_FROM_THE_SYSTEM 1
+#endif
 #ifndef FB_DW_LDS_COLS
 #define FB_DW_LDS_COLS 48
 #endif
@@ -659,8 +662,9 @@ struct DenseWave {
     assemble(c, hd, sigma, Kr, &dg, &atr);
     // eliminated right-hand side (dense_cholesky_solver.cc:98-104), entry t in lane t
     double x = 0.0;
-    if (t < nz) x = -(rz[t] + sigma * (z[t] - zb[t])) - atr;
-    else if (t < n) x = rl[t - nz] + sigma * (l[t - nz] - lb[t - nz]);
+    double rhs0 = 0.0;  // this row's right-hand side of the full Newton system (before the elimination of dv)
+    if (t < nz) { rhs0 = -(rz[t] + sigma * (z[t] - zb[t])); x = rhs0 - atr; }
+    else if (t < n) { rhs0 = rl[t - nz] + sigma * (l[t - nz] - lb[t - nz]); x = rhs0; }
     FB_WAVE_LAP(11);
     int ord, permv;
     double dpiv;
@@ -670,19 +674,29 @@ struct DenseWave {
     FB_WAVE_LAP(13);
     if (t < nz) dz[t] = x;
     else if (t < n) dl[t - nz] = x;
+#if FB_DW_W_FROM_THE_SYSTEM
+    // W = (H dz + G'dl + A'dv, -G dz), the increment of the natural residual's (z, l)
+    // rows along the step (the line search evaluates its trial points from it), is what
+    // the rows of the Newton system just solved leave of their right-hand sides:
+    //   (H + sigma I) dz + G'dl + A'dv = rhs_z,   G dz - sigma dl = rhs_l
+    // - no pass over H, G' and A' (160 loads per lane and Newton step), at the price of
+    // the solve's own residual in W, which is of the size of the rounding error of the
+    // products it replaces.
+    if (t < nz) wz[t] = rhs0 - sigma * x;
+    else if (t < n) wl[t - nz] = -(rhs0 + sigma * x);
+#endif
     c.sync();
-    // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124) and the
-    // dz part of W = (H dz + G'dl + A'dv, -G dz): the products with dz share one loop
-    // over its entries (rows t and t + 64 of A, row t of H or of G), the loads of ten
-    // entries - thirty loads - in flight together.  Rows past the end read row 0 and
-    // are dropped.
-    double hdz = 0.0;  // (H dz)_t, t < nz; (G dz)_(t - nz), nz <= t < n
+    // dv = rv/mus + Gamma .* (A dz) (:114-121); adz = A dz (dy = b - A dz, :124): rows t
+    // and t + 64 of A against dz (and, for the explicit W, row t of H or of G in the same
+    // loop), the loads of ten entries in flight together.  Rows past the end read row 0
+    // and are dropped.
+    [[maybe_unused]] double hdz = 0.0;  // (H dz)_t, t < nz; (G dz)_(t - nz), nz <= t < n
     if (nv <= 128) {
       const bool r0 = t < nv, r1 = t + 64 < nv;
       const double* a0 = D.A + (r0 ? t : 0);
       const double* a1 = D.A + (r1 ? t + 64 : 0);
-      const double* hr = t < nz ? D.H + t : (nl > 0 ? D.G + (t < n ? t - nz : 0) : D.H);
-      const long hs = t < nz ? nz : (nl > 0 ? nl : nz);
+      [[maybe_unused]] const double* hr = t < nz ? D.H + t : (nl > 0 ? D.G + (t < n ? t - nz : 0) : D.H);
+      [[maybe_unused]] const long hs = t < nz ? nz : (nl > 0 ? nl : nz);
       double s0 = 0.0, s1 = 0.0;
       struct Chunk { double x0[10], x1[10], xh[10]; };
       auto load_chunk = [&](int k0, Chunk& ch) {
@@ -691,7 +705,9 @@ struct DenseWave {
           const int k = k0 + u < nz ? k0 + u : nz - 1;
           ch.x0[u] = a0[(long)k * nv];
           ch.x1[u] = a1[(long)k * nv];
+#if !FB_DW_W_FROM_THE_SYSTEM
           ch.xh[u] = hr[(long)k * hs];
+#endif
         }
       };
       auto use_chunk = [&](int k0, const Chunk& ch) {
@@ -700,7 +716,9 @@ struct DenseWave {
           const double d = k0 + u < nz ? dz[k0 + u < nz ? k0 + u : nz - 1] : 0.0;
           s0 = fma(ch.x0[u], d, s0);
           s1 = fma(ch.x1[u], d, s1);
+#if !FB_DW_W_FROM_THE_SYSTEM
           hdz = fma(ch.xh[u], d, hdz);
+#endif
         }
       };
       // (the next ten entries' thirty loads go out before these ten are used)
@@ -720,10 +738,13 @@ struct DenseWave {
         adz[i] = a;
         dv[i] = rvm[i] + gam[i] * a;
       }
+#if !FB_DW_W_FROM_THE_SYSTEM
       if (t < nz) hdz = row_dot(D.H, nz, nz, t, dz);
       else if (t < n) hdz = row_dot(D.G, nl, nz, t - nz, dz);
+#endif
     }
     c.sync();
+#if !FB_DW_W_FROM_THE_SYSTEM
     if (t < nz) {
       double gdl = 0.0;  // (G'dl)_t from the transposed copy
       for (int q = 0; q < nl; q++) gdl = fma(Gt[64 * q + t], dl[q], gdl);
@@ -732,6 +753,7 @@ struct DenseWave {
       wl[t - nz] = -hdz;
     }
     c.sync();
+#endif
     FB_WAVE_LAP(14);
     return true;
   }
