@@ -244,6 +244,14 @@ def main():
         torch.cuda.empty_cache()
         blocks["dense"] = bench_dense(torch, dev, fx, hip_api)
         blocks["receding"] = bench_receding(torch, dev, fx, hip_api)
+    if dist is not None and args.extras != 0 and (world > 1 or os.environ.get("FBSTAB_BENCH_SHARDED_SWEEP") == "1"):
+        # N > 1: configs[4] sharded by trajectory (every rank takes part: one gather at
+        # the end).  (The environment variable rehearses this branch with one rank.)
+        data = None
+        torch.cuda.empty_cache()
+        rec_blk = bench_receding(torch, dev, fx, hip_api, dist=dist, rank=rank, world=world)
+        if rank == 0:
+            blocks["receding"] = rec_blk
     gpu_t1 = time.time()
 
     if rank == 0:
@@ -365,28 +373,48 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
     return r
 
 
-def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200):
+def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200, dist=None, rank=0, world=1):
     """BASELINE configs[4]: warm-started receding-horizon sweep, plant step
     x+ = A x + B u0, retirement of failed trajectories and the warm start all on
     the device, one C call and ONE launch for the whole sweep
     (fbstab_hip_mpc_receding_sweep): every 16-lane row advances its own trajectory
-    through all the steps, so no trajectory waits for the slowest solve of a step."""
-    p = fx.synthetic_mpc_batch(trajectories)
+    through all the steps, so no trajectory waits for the slowest solve of a step.
+    Under torch.distributed every rank sweeps its own block of `trajectories`
+    (global ids rank * trajectories ...; nothing is exchanged while the sweep runs) and
+    the applied inputs go to rank 0 in ONE gather at the end (sharding.gather_input_log);
+    the time is the slowest rank's, barrier to barrier, gather included."""
+    p = fx.synthetic_mpc_batch(trajectories, first_id=rank * trajectories)
     N, nx, nu, nc = p.sizes()
     A, Bm = fx.quadrotor_model()
-    s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=trajectories)
+    s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=trajectories, device=dev.index or 0)
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
     mk = lambda n: torch.zeros((trajectories, n), dtype=torch.float64, device=dev)
     z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+    glist = None
+    if dist is not None and rank == 0:
+        glist = [torch.empty((steps, trajectories, nu), dtype=torch.float64, device=dev) for _ in range(world)]
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
-    r = s.RecedingSweep(data, z, l, v, y, A, Bm, steps, retire=True)
+    r = s.RecedingSweep(data, z, l, v, y, A, Bm, steps, retire=True, log_inputs=dist is not None)
+    if dist is not None:
+        from fbstab_amd import sharding
+        sharding.gather_input_log(r["u"], dst=0, gather_list=glist)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     st = r["stats"]
-    res = {"config": "BASELINE configs[4]: 4096 closed-loop trajectories x 200 steps, N=30 nx=12 nu=4 nc=20, "
-                     "warm start (unshifted), x+ = A x + B u0 on the device, failed trajectories retired to the origin",
-           "value": trajectories * steps / dt, "unit": "QPs/sec", "wall_ms_per_step": 1e3 * dt / steps,
+    res = {"config": f"BASELINE configs[4]: {world} x 4096 closed-loop trajectories x 200 steps, N=30 nx=12 nu=4 nc=20, "
+                     "warm start (unshifted), x+ = A x + B u0 on the device, failed trajectories retired to the origin"
+                     + ("; one gather of the applied inputs to rank 0 at the end" if dist is not None else ""),
+           "value": world * trajectories * steps / dt, "unit": "QPs/sec", "wall_ms_per_step": 1e3 * dt / steps,
+           "n_gpus": world, "scaling": "weak",
            # one launch: the device time of the launch divided by the steps, the same
            # figure for every step (the launch lasts as long as its slowest TRAJECTORY;
            # with a launch per step - FBSTAB_HIP_SWEEP_PER_STEP=1, the round-2 start -

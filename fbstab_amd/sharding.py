@@ -65,3 +65,23 @@ def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[Li
         return gather_list, None
     full = torch.cat(gather_list, dim=0)
     return full[:, :nvar], full[:, nvar:].contiguous().view(torch.uint8).view(-1, 40)
+
+
+def gather_input_log(u_log, dst: int = 0, gather_list: Optional[List] = None):
+    """The receding-horizon sweep (BASELINE configs[4]) over several ranks: every rank
+    sweeps its own block of trajectories with no exchange at all - a trajectory's next
+    QP depends on nothing but its own last solution - and the applied inputs
+    ``u_log`` (``(steps, B, nu)`` float64, 32 bytes per trajectory and step) travel to
+    ``dst`` in ONE gather when the sweep is over.  Returns the list of per-rank logs
+    on ``dst`` (rank g's block = global trajectories ``[g*B, (g+1)*B)``), ``None``
+    elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if rank == dst:
+        gather_list = gather_list or [torch.empty_like(u_log) for _ in range(world)]
+    else:
+        gather_list = None
+    dist.gather(u_log.contiguous(), gather_list, dst=dst)
+    return gather_list

@@ -74,3 +74,70 @@ def test_shard_and_gather_equals_single_process(oracle):
     assert sharding.shard_range(1, 2, 8192) == (8192, 16384)
     with pytest.raises(ValueError):
         sharding.shard_range(2, 2, 1)
+
+
+def _oracle_sweep(p, steps):
+    """Closed loop of tools/fixtures' plant with the oracle as the solver (warm start
+    unshifted, as the device sweep): the applied inputs, (steps, B, nu)."""
+    from tools import fixtures as fx
+    from fbstab_amd.receding_horizon import closed_loop
+    from oracle.oracle_py import Oracle
+    orc = Oracle(False)
+    A, Bm = fx.quadrotor_model()
+    B = p.batch
+
+    def solve(x0, z, l, v):
+        p.arrays["x0"] = np.ascontiguousarray(x0)
+        return orc.solve_mpc(p, x0guess=(z, l, v))
+
+    log = closed_loop(solve, p.arrays["x0"].copy(), np.zeros((B, p.nz)), np.zeros((B, p.nl)), np.zeros((B, p.nv)),
+                      A, Bm, p.nx, p.nu, steps)
+    return np.stack([r["u0"] for r in log])
+
+
+def _sweep_worker(rank, world, port, per_rank, steps, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from tools import fixtures as fx
+    from fbstab_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, last = sharding.shard_range(rank, world, per_rank)
+    u = torch.from_numpy(_oracle_sweep(fx.synthetic_mpc_batch(last - first, first_id=first, N=8), steps))
+    calls = []
+    real_gather = dist.gather
+    dist.gather = lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1]
+    logs = sharding.gather_input_log(u, dst=0)
+    dist.gather = real_gather
+    assert len(calls) == 1, "one collective per sweep"
+    if rank == 0:
+        q.put(torch.cat(logs, dim=1).numpy())
+    else:
+        assert logs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_receding_sweep_equals_single_process():
+    """BASELINE configs[4] over W ranks: trajectories are sharded by global id, every
+    rank sweeps its block with no exchange, ONE gather of the input log at the end -
+    bit-identical to sweeping all trajectories in one process."""
+    import torch.multiprocessing as mp
+    from tools import fixtures as fx
+    world, per_rank, steps = 2, 3, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, per_rank, steps, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    U = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    want = _oracle_sweep(fx.synthetic_mpc_batch(world * per_rank, N=8), steps)
+    assert U.shape == (steps, world * per_rank, 4)
+    assert np.array_equal(U, want)
+    assert np.abs(want).max() > 0.1
