@@ -856,6 +856,55 @@ def test_receding_sweep_in_one_launch_equals_a_launch_per_step(hip, monkeypatch)
         assert np.array_equal(one["out"][k], per["out"][k]), k
 
 
+@pytest.mark.parametrize("problem,N,kernel", [("SpacecraftRelativeMotion", 12, "fbstab_mpc_r16_kernel<12,4,20>"),
+                                              ("CopolymerizationReactor", 16, "fbstab_mpc_r32_kernel<18,5,10>")])
+def test_receding_sweep_on_padded_and_two_row_instances(hip, oracle, monkeypatch, problem, N, kernel):
+    """The one-launch sweep on a zero-padded shape (nx = 6, nu = 3 on the <12,4,20>
+    instance) and on a two-rows-per-QP instance (the reactor: the plant step then runs on
+    32 lanes per trajectory), with the generator's own simulation model: bitwise equal
+    to a launch per step, and the applied inputs match the oracle's closed loop."""
+    import torch
+    gen = fx.OcpGenerator()
+    getattr(gen, problem)(N)
+    one = gen.GetFBstabInput()
+    sim = gen.GetSimulationInputs()
+    A, B = np.asarray(sim["A"], dtype=np.float64), np.asarray(sim["B"], dtype=np.float64)
+    Nn, nx, nu, nc = one.sizes()
+    T, S = 12, 5
+    p = fx.MpcProblem(Nn, nx, nu, nc)
+    p.arrays = {k: np.repeat(v, T, axis=0) for k, v in one.arrays.items()}
+    p.arrays["x0"] = np.ascontiguousarray(p.arrays["x0"] * (1.0 + 0.02 * np.arange(T)[:, None]))
+    dev = torch.device("cuda:0")
+
+    def run():
+        s = hip.FBstabMpcBatch(Nn, nx, nu, nc, max_batch=T)
+        assert s.kernel_name() == kernel, s.kernel_name()
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        mk = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        r = s.RecedingSweep(data, z, l, v, y, A, B, S, retire=False, log_inputs=True)
+        res = dict(u=r["u"].cpu().numpy(), x0=data["x0"].cpu().numpy(), z=z.cpu().numpy(),
+                   stats=r["stats"].copy(), out=hip.out_to_numpy(r["out"]))
+        s.close()
+        return res
+
+    one_launch = run()
+    monkeypatch.setenv("FBSTAB_HIP_SWEEP_PER_STEP", "1")
+    per_step = run()
+    monkeypatch.delenv("FBSTAB_HIP_SWEEP_PER_STEP")
+    for k in ("u", "x0", "z"):
+        assert np.array_equal(one_launch[k], per_step[k]), k
+    for k in one_launch["stats"].dtype.names:
+        assert np.array_equal(one_launch["stats"][k], per_step["stats"][k]), k
+    for k in ("eflag", "newton_iters", "prox_iters", "residual"):
+        assert np.array_equal(one_launch["out"][k], per_step["out"][k]), k
+    ref, x_end = _oracle_closed_loop(oracle, p, A, B, S, retire=False)
+    for k in range(S):
+        us = 1.0 + np.abs(ref[k]["u0"]).max()
+        assert np.abs(one_launch["u"][k] - ref[k]["u0"]).max() <= 1e-6 * us, (problem, k)
+    assert np.abs(one_launch["x0"] - x_end).max() <= 1e-6 * (1.0 + np.abs(x_end).max())
+
+
 def test_config5_full_sweep_with_an_oracle_subset(hip, oracle):
     """BASELINE configs[4] at full size: 4096 trajectories x 200 steps on the device.
     The trajectories are independent, so the 64 of them with ids 0, 64, 128, ... are
