@@ -463,6 +463,8 @@ struct Solver : TraceState<TRACE> {
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
     [[maybe_unused]] bool fetch_now = true;  // (align_rows) the wavefront has just released its waiting rows
+    // line-search trial passes run by all rows of the wavefront for one of them at a time
+    constexpr bool kCoop = P::kCoopTrials && !Queue::kCanAlignRows;
     for (;;) {
       while (phase != kNewton && phase != kDone && phase != kPause) {
         if (phase == kFetch) {
@@ -577,6 +579,115 @@ struct Solver : TraceState<TRACE> {
           open_prox(sigma, &Ek, &Ei0);
           phase = kProxTop;
         }
+      }
+      if constexpr (kCoop) {
+        // ---- one Newton step, then the line search with COOPERATIVE trial passes: the
+        // rows stay in the loop until the last one of the wavefront is done, and every
+        // trial pass of a row is run by all rows (P::norms_at_multi_coop).  Same
+        // statements per QP as below; a row's scalars wait in its save area while the
+        // sweeps run, the rows without a step included (nothing of theirs may stay in
+        // registers across a Newton step: the sweeps have none to spare).
+        if (__ballot(phase != kDone) == 0ull) break;
+        {
+          auto sv = qu.save_area();
+          sv[0] = combo_tol; sv[1] = Ek; sv[2] = E0; sv[3] = rk_last; sv[4] = inner_tol; sv[5] = dx_norm;
+          sv[6] = Eo_top; sv[7] = Ei0; sv[8] = merit[0]; sv[9] = merit[1]; sv[10] = merit[2]; sv[11] = merit[3];
+          sv[12] = Eo;
+          sv[13] = __hiloint2double(newton, prox);
+          sv[14] = __hiloint2double(k, inner_i);
+          sv[15] = __longlong_as_double((long long)(out - out_base));
+          sv[16] = Ei;
+          sv[17] = __hiloint2double(phase, 0);
+        }
+        bool searching = false, taken = false;
+        double t = 1.0, cm = 0.0, m0 = 0.0, Et = 0.0, Eot = 0.0;
+        int fails = 0;  // failed sufficient-decrease tests so far
+        if (phase == kNewton) {
+          double ti2, to2;
+          const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2);
+          auto sv = qu.save_area();
+          if (!stepped) {
+            out = out_base + __double_as_longlong(sv[15]);
+            p.flush(c);
+            p.write_x(c);
+            finish(out, FBSTAB_DIVERGENCE, sv[3], __double2hiint(sv[13]), __double2loint(sv[13]), sv[2]);
+            sv[17] = __hiloint2double(kFetch, 0);
+          } else {
+            taken = true;
+            cm = 0.5 * sv[16] * sv[16];
+            m0 = cm;
+            if (o.nonmonotone_linesearch) {
+              for (int m = 8; m < 12; m++) m0 = sv[m] > m0 ? sv[m] : m0;
+            }
+            Et = sqrt(ti2);
+            Eot = sqrt(to2);
+            // trial 0 (t = 1) came with the Newton step (impl:283-297)
+            if (o.max_linesearch_iters > 0 && !(0.5 * Et * Et <= m0 - 2.0 * t * o.eta * cm)) {
+              t *= o.beta;
+              fails = 1;
+              searching = true;
+            }
+          }
+        }
+        constexpr int KT = FB_LS_KT;
+        for (;;) {
+          unsigned long long need = __ballot(searching);
+          if (need == 0ull) break;
+          double Em[KT], Eom[KT];
+#pragma unroll
+          for (int m = 0; m < KT; m++) Em[m] = Eom[m] = 0.0;
+          while (need != 0ull) {
+            const int owner = __builtin_ctzll(need);
+            double Ec[KT], Eoc[KT];
+            p.template norms_at_multi_coop<KT>(owner, t, o.beta, sigma, o.alpha, Ec, Eoc);
+            const bool mine = ((threadIdx.x ^ owner) & 63 & ~(C::nt - 1)) == 0;
+#pragma unroll
+            for (int m = 0; m < KT; m++) {
+              Em[m] = mine ? Ec[m] : Em[m];
+              Eom[m] = mine ? Eoc[m] : Eom[m];
+            }
+            need &= ~(((C::nt == 64) ? ~0ull : ((1ull << C::nt) - 1ull)) << (owner & ~(C::nt - 1)));
+          }
+#pragma unroll
+          for (int m = 0; m < KT; m++) {
+            if (searching) {
+              Et = Em[m];
+              Eot = Eom[m];
+              // (the trial after the last allowed test is taken as it is, impl:283-297)
+              if (fails >= o.max_linesearch_iters || 0.5 * Et * Et <= m0 - 2.0 * t * o.eta * cm) {
+                searching = false;
+              } else {
+                t *= o.beta;
+                fails++;
+              }
+            }
+          }
+        }
+        {
+          auto sv = qu.save_area();
+          combo_tol = sv[0]; Ek = sv[1]; E0 = sv[2]; rk_last = sv[3]; inner_tol = sv[4]; dx_norm = sv[5];
+          Eo_top = sv[6]; Ei0 = sv[7];
+          merit[0] = sv[8]; merit[1] = sv[9]; merit[2] = sv[10]; merit[3] = sv[11];  // ([4] is only ever written)
+          Eo = sv[12];
+          newton = __double2hiint(sv[13]);
+          prox = __double2loint(sv[13]);
+          k = __double2hiint(sv[14]);
+          inner_i = __double2loint(sv[14]);
+          out = out_base + __double_as_longlong(sv[15]);
+          Ei = sv[16];
+          phase = __double2hiint(sv[17]);
+          if (taken) {
+            // merit FIFO (impl:276-278), the step and its norms
+            merit[4] = sv[11]; merit[3] = sv[10]; merit[2] = sv[9]; merit[1] = sv[8]; merit[0] = cm;
+            p.pend_t = t;
+            Ei = Et;
+            Eo = Eot;
+            newton++;
+            inner_i++;
+            phase = kInnerTop;
+          }
+        }
+        continue;
       }
       if constexpr (Queue::kCanAlignRows) {
         // (every row is here: none leaves the loop before all are done)

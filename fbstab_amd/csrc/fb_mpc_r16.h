@@ -769,6 +769,116 @@ struct MpcR16 {
     });
   }
 
+  // The same pass for ONE QP of the wavefront (the one whose lane `owner` is), run by ALL
+  // its rows: row q takes the stages q, q + QW, q + 2 QW, ... - the rows that need a
+  // line-search pass at a given moment are usually one or two of the four, and the
+  // others' lanes would only wait.  Every lane calls this (wave-uniform control flow);
+  // every lane gets the owner's norms.  The sums over the stages are formed per row and
+  // then over the rows: same terms as norms_at_multi(), different order of summation.
+  // No step is pending here (the Newton step's forward sweep applied it).
+  // The pass proper is a real call (trial_pass_coop, not inlined): it takes nothing but
+  // scalars, so the policy object stays in registers; inlined into the solver loop the
+  // exact <12,4,32> instance came out of the compiler finishing every QP at its first
+  // convergence test (any other change of the surrounding code made it right again - the
+  // cause was not found; tests/test_gpu_parity.py runs every instance, exact and padded).
+#ifndef FB_R16_COOP_TRIALS
+#define FB_R16_COOP_TRIALS 1
+#endif
+  static constexpr bool kCoopTrials = FB_R16_COOP_TRIALS != 0;
+  static FB_DEV double lane_value(double x, int lane) {  // x of lane `lane` (wave-uniform index)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
+                            __builtin_amdgcn_readlane(__double2loint(x), lane));
+  }
+  template <int K>
+  struct TrialNorms {
+    double ei[K], eo[K];
+  };
+  // R0: the owner's record base with this lane's offset within ITS row (2 * r)
+  template <int K>
+  static __device__ __attribute__((noinline)) TrialNorms<K> trial_pass_coop(const double* R0, int N_, double t0,
+                                                                            double beta, double sigma, double alpha) {
+    constexpr int QW = kQpPerWave;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPQ, r = lane & (LPQ - 1);
+    double tt[K], s[2 * K];
+    tt[0] = t0;
+    sfor<1, K>([&](auto Kk) { tt[decltype(Kk)::value] = tt[decltype(Kk)::value - 1] * beta; });
+    sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
+    const bool rx = r < NX;
+    auto stage_ptr = [&](int i) { return R0 + (long)(i < N_ ? i : N_) * kRec; };
+    TrialIn in;
+    double wln_in;  // WLN of the stage below (stage 0: unused)
+    load_trial(stage_ptr(q), in);
+    wln_in = ld(stage_ptr(q > 0 ? q - 1 : 0), sWLN);
+    for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
+      const TrialIn cu = in;
+      const double wlp = wln_in;
+      load_trial(stage_ptr(i + QW), in);
+      wln_in = ld(stage_ptr(i + QW - 1), sWLN);
+      const bool live = i <= N_;
+      const double wl = wl_of_stage(i, rx, cu.dw[0], wlp);
+      sfor<0, K>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        const double rzt = fma(tt[k], cu.dw[1], cu.zr[1]);
+        const double rzi = rzt + sigma * (fma(tt[k], cu.dw[0], cu.zr[0]) - cu.bb[0]);
+        const double rlt = fma(tt[k], wl, cu.lr[1]);
+        const double rli = rlt + sigma * (fma(tt[k], cu.dwl[0], cu.lr[0]) - cu.bb[1]);
+        double a = s[k], b = s[K + k];
+        a = fma(rzi, rzi, a);
+        a = fma(rli, rli, a);
+        b = fma(rzt, rzt, b);
+        b = fma(rlt, rlt, b);
+        s[k] = live ? a : s[k];
+        s[K + k] = live ? b : s[K + k];
+      });
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        sfor<0, K>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          const double vi = fma(tt[k], cu.da[sl][0], cu.vy[sl][0]);
+          const double yi = fma(-tt[k], cu.da[sl][1], cu.vy[sl][1]);
+          const double ys = yi + sigma * (vi - cu.vb[sl]);
+          const double ph = pfb(ys, vi, alpha);
+          const double pn = pnr(yi, vi, alpha);
+          s[k] = live ? fma(ph, ph, s[k]) : s[k];
+          s[K + k] = live ? fma(pn, pn, s[K + k]) : s[K + k];
+        });
+      });
+    }
+    TrialNorms<K> out;
+    sfor<0, 2 * K>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      const double rs = qp_reduce<RQ, OpSum16>(s[k]);  // the row's (row pair's) stages
+      double tot = lane_value(rs, 0);
+      sfor<1, QW>([&](auto Q_) { tot += lane_value(rs, LPQ * decltype(Q_)::value); });
+      if constexpr (k < K) out.ei[k] = sqrt(tot);
+      else out.eo[k - K] = sqrt(tot);
+    });
+    return out;
+  }
+  template <int K>
+  FB_DEV void norms_at_multi_coop(int owner, double t0, double beta, double sigma, double alpha,
+                                  double (&Ei)[K], double (&Eo)[K]) const {
+    FB_WAVE_COUNT(24);
+    FB_WAVE_TIMER(23);
+    // (the owner's records were written by the owner's lanes: their stores are complete
+    // before another row's lanes read them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the owner's record base (lane 0 of its row: rec carries 2 * tid) and horizon
+    const int own0 = owner & ~(LPQ - 1);
+    const unsigned long long rb = (unsigned long long)rec;
+    const unsigned long long rbo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rb >> 32), own0) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)rb, own0);
+    const double* const R0 = reinterpret_cast<const double*>(rbo) + 2 * (threadIdx.x & (LPQ - 1));
+    const TrialNorms<K> n = trial_pass_coop<K>(R0, __builtin_amdgcn_readlane(N, own0), lane_value(t0, own0), beta,
+                                               sigma, alpha);
+    sfor<0, K>([&](auto Kk) {
+      Ei[decltype(Kk)::value] = n.ei[decltype(Kk)::value];
+      Eo[decltype(Kk)::value] = n.eo[decltype(Kk)::value];
+    });
+  }
+
   // x <- x + t dx, (rz, rl) <- (rz, rl) + t W for the pending step (impl:298,
   // full_variable.cc:55-65).
   FB_DEV void flush(const C& c) {
