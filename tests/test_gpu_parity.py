@@ -1108,6 +1108,7 @@ def test_reactor_shape_runs_on_the_two_row_record_kernel(hip, oracle):
                                           ((5, 24, 8, 32), "fbstab_mpc_r32_kernel<24,8,32>"),
                                           ((7, 13, 4, 25), "fbstab_mpc_r32_kernel<24,8,32>"),
                                           ((4, 17, 1, 11), "fbstab_mpc_r32_kernel<24,8,16>"),
+                                          ((4, 24, 8, 16), "fbstab_mpc_r32_kernel<24,8,16>"),
                                           ((3, 25, 2, 4), "fbstab_mpc_kernel<64>"),
                                           ((3, 10, 9, 4), "fbstab_mpc_kernel<64>")])
 def test_stage_widths_up_to_32_run_on_the_general_two_row_instances(hip, oracle, shape, kernel):
