@@ -533,6 +533,24 @@ def test_warm_start_and_iteration_limits(hip, oracle):
     np.testing.assert_allclose(g[4]["residual"], c[4]["residual"], rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("max_ls", [1, 2, 5, 9])
+def test_line_search_trial_limits_on_the_record_kernel(hip, oracle, max_ls):
+    """max_linesearch_iters below, at and between multiples of the four step lengths a
+    trial pass evaluates: the step taken after the last allowed sufficient-decrease test
+    is the reference's (impl:283-297: the trial after the last test is accepted as it is),
+    so exit flags, proximal and Newton counts follow the oracle's under the same option."""
+    p = fx.synthetic_mpc_batch(96, first_id=52000)
+    o = default_options(max_linesearch_iters=max_ls)
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    assert np.array_equal(gpu[4]["eflag"], cpu[4]["eflag"])
+    dn = np.abs(gpu[4]["newton_iters"].astype(int) - cpu[4]["newton_iters"].astype(int))
+    assert (dn == 0).mean() >= 0.97 and dn.max() <= 4, ((dn != 0).sum(), dn.max())
+    ok = cpu[4]["eflag"] == 0
+    scale = 1.0 + np.abs(cpu[0]).max(axis=1, keepdims=True)
+    assert (np.abs(gpu[0] - cpu[0])[ok] <= 10 * o.abs_tol * scale[ok]).all()
+
+
 def test_reliable_options_and_no_feasibility_check(hip, oracle):
     p = fx.synthetic_dense_batch(32, 20, 5, 40, first_id=9)
     for o in (reliable_options(), default_options(check_feasibility=0),
