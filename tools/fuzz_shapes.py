@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer tool: random MPC shapes over every record instance (and the flat-vector
+kernel) against the oracle: exit flags, proximal counts equal; Newton counts equal on
+all but a few.  argv: number of shapes [seed]."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fbstab_amd import hip_api
+from tools import fixtures as fx
+from oracle.oracle_py import Oracle, default_options
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+orc = Oracle(False)
+bad = 0
+for it in range(n):
+    nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
+    B = int(rng.integers(1, 14))
+    o = default_options()
+    if rng.random() < 0.3:
+        o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
+    p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    h = hip_api.Options()
+    for name, _ in h._fields_:
+        setattr(h, name, getattr(o, name))
+    s.UpdateOptions(h)
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    kn = s.kernel_name(); s.close()
+    c = orc.solve_mpc(p, opts=o, nthreads=orc.num_threads())
+    oc = c[4]
+    dn = np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
+    okf = np.array_equal(out["eflag"], oc["eflag"]) and np.array_equal(out["prox_iters"], oc["prox_iters"])
+    good = oc["eflag"] == 0
+    dz = float(np.abs(z - c[0])[good].max()) if good.any() else 0.0
+    flag = "" if (okf and dn.max() <= 2 and dz < 1e-4) else "  <-- CHECK"
+    bad += flag != ""
+    print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e}{flag}")
+print("shapes to check:", bad)
