@@ -1,0 +1,236 @@
+"""GPU tests: the reference's hand-calculated COMPONENT goldens through the HIP
+Newton-step probes (fbstab_hip_mpc_debug_newton / fbstab_hip_dense_debug_newton),
+and seeded random-shape subsets of tools/fuzz_shapes.py / tools/fuzz_dense.py that
+reach every MPC kernel instance and every dense kernel.
+
+The goldens are the reference's own (tests/golden/reference_kats.json, transcribed
+from fbstab/components/test/mpc_component_unit_tests.h:99-461 and
+dense_unit_tests.h:100-213); tests/test_oracle.py pins the oracle with them on the
+CPU, this file puts the same numbers to the device path."""
+import numpy as np
+import pytest
+
+from tools import fixtures as fx
+from oracle.oracle_py import default_options
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from fbstab_amd import hip_api
+    assert hip_api.load_library().fbstab_hip_device_count() >= 1
+    return hip_api
+
+
+def _opts(hip, o):
+    h = hip.Options()
+    for name, _ in h._fields_:
+        setattr(h, name, getattr(o, name))
+    return h
+
+
+def _pfb_gradient(ys, v, alpha, sigma):
+    """(gamma, mus) of riccati_linear_solver.cc:346-365 / :91-99, in numpy."""
+    r = np.sqrt(ys * ys + v * v)
+    d = alpha * (1.0 - 1.0 / np.sqrt(2.0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = np.where(r < 1e-13, d, alpha * (1.0 - ys / r))
+        m = np.where(r < 1e-13, d, alpha * (1.0 - v / r))
+    both = (r >= 1e-13) & (ys > 0) & (v > 0)
+    g = g + np.where(both, (1.0 - alpha) * v, 0.0)
+    m = m + np.where(both, (1.0 - alpha) * ys, 0.0)
+    return g, m + sigma * g
+
+
+def _pfb(a, b, alpha):
+    return alpha * (a + b - np.sqrt(a * a + b * b)) + (1.0 - alpha) * np.maximum(a, 0) * np.maximum(b, 0)
+
+
+@pytest.mark.parametrize("kernel", ["r16", "generic"])
+def test_mpc_component_goldens_through_the_hip_probe(hip, kats, monkeypatch, kernel):
+    """mpc_component_unit_tests.h:99-461 on the record kernel (padded <12,4,20>
+    instance) and on the flat-vector kernel: the products gemvH/GT/AT/G and the
+    constants f, h behind the natural residual, A z, the InnerResidual golden
+    (1e-14 in the reference; 1e-12 here for rv, which is recovered from the step),
+    and the Newton system's residual, block by block."""
+    monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kernel == "generic" else "0")
+    c = kats["mpc_components"]
+    p = H.mpc_component_fixture(c)
+    data = {k: a[0] for k, a in p.arrays.items()}
+    s = hip.FBstabMpcBatch(*p.sizes(), max_batch=1)
+    if kernel == "r16":
+        assert s.kernel_name() == "fbstab_mpc_r16_kernel<12,4,20>"
+    Hm, f, G, h, A, b = H.mpc_explicit(p)
+    ramp = lambda n: np.arange(1, n + 1, dtype=np.float64)
+    exp = lambda op: np.asarray(c[op]["expected"], dtype=np.float64)
+    alpha = 0.95
+
+    # ---- gemvH + f + gemvGT + gemvAT and h - gemvG at the ramp vectors (:99-192)
+    s.UpdateOptions(hip.DefaultOptions(sigma0=1.0, sigma_max=100.0, alpha=alpha))
+    z, l, v = ramp(p.nz), ramp(p.nl), ramp(p.nv)
+    g = s.debug_newton(data, z, l, v, z, l, v)
+    assert g["ok"]
+    np.testing.assert_allclose(g["rz"], exp("gemvH") + f + exp("gemvGT") + exp("gemvAT"), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(g["rl"], h - exp("gemvG"), rtol=0, atol=1e-12)
+    # gemvA golden through the step: adz = A dz, and y = b - A z enters dv
+    np.testing.assert_allclose(exp("gemvA"), A @ z, rtol=0, atol=0)
+    np.testing.assert_allclose(g["adz"], A @ g["dz"], rtol=0, atol=1e-12 * (1 + np.abs(g["dz"]).max()))
+
+    # ---- InnerResidual golden: x.Fill(2), xbar.Fill(-2), sigma = 1 (:316-355)
+    gi = c["inner_residual"]
+    fill = lambda n, a: np.full(n, float(a))
+    z, l, v = fill(p.nz, 2), fill(p.nl, 2), fill(p.nv, 2)
+    zb, lb, vb = fill(p.nz, -2), fill(p.nl, -2), fill(p.nv, -2)
+    g = s.debug_newton(data, z, l, v, zb, lb, vb)
+    assert g["ok"]
+    np.testing.assert_allclose(g["rz"] + 1.0 * (z - zb), gi["rz"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(g["rl"] + 1.0 * (l - lb), gi["rl"], rtol=0, atol=1e-13)
+    # rv = phi(y + sigma (v - vbar), v): the third block row of the Newton system,
+    # -gamma (A dz) + mus dv = -rv, gives it back from the device's step
+    y = b - A @ z
+    gam, mus = _pfb_gradient(y + 1.0 * (v - vb), v, alpha, 1.0)
+    np.testing.assert_allclose(gam * g["adz"] - mus * g["dv"], gi["rv"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(_pfb(y + (v - vb), v, alpha), gi["rv"], rtol=0, atol=1e-13)
+
+    # ---- the Riccati golden's point: x = (1,2,4), xbar = (2,1,3), sigma = 1 (:386-461):
+    # every block of V dx - r vanishes (r = -inner residual here), W = (H dz + G'dl + A'dv, -G dz)
+    z, l, v = fill(p.nz, 1), fill(p.nl, 2), fill(p.nv, 4)
+    zb, lb, vb = fill(p.nz, 2), fill(p.nl, 1), fill(p.nv, 3)
+    g = s.debug_newton(data, z, l, v, zb, lb, vb)
+    assert g["ok"]
+    y = b - A @ z
+    gam, mus = _pfb_gradient(y + (v - vb), v, alpha, 1.0)
+    rz = -(g["rz"] + (z - zb))
+    rl = -(g["rl"] + (l - lb))
+    rv = -_pfb(y + (v - vb), v, alpha)
+    e1 = Hm @ g["dz"] + g["dz"] + G.T @ g["dl"] + A.T @ g["dv"] - rz
+    e2 = -G @ g["dz"] + g["dl"] - rl
+    e3 = -gam * (A @ g["dz"]) + mus * g["dv"] - rv
+    for e in (e1, e2, e3):
+        assert np.abs(e).max() <= 1e-12, np.abs(e).max()
+    np.testing.assert_allclose(g["wz"], Hm @ g["dz"] + G.T @ g["dl"] + A.T @ g["dv"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(g["wl"], -G @ g["dz"], rtol=0, atol=1e-12)
+    s.close()
+
+
+@pytest.mark.parametrize("threads", ["64", "256"])
+def test_dense_component_goldens_through_the_hip_probe(hip, kats, monkeypatch, threads):
+    """dense_unit_tests.h:100-213 on the one-wavefront and the four-wavefront dense
+    kernels: NaturalResidual and InnerResidual goldens, rv through the step, and the
+    linear solver's residual (1e-12 in the reference)."""
+    monkeypatch.setenv("FBSTAB_HIP_DENSE_THREADS", threads)
+    c = kats["dense_components"]
+    p = H.dense_from_kat(dict(H=c["H"], f=c["f"], A=c["A"], b=c["b"]))
+    data = {k: a[0] for k, a in p.arrays.items()}
+    Hm, f, G, h, A, b = H.dense_explicit(p)
+    gi, gn, gl = c["inner_residual"], c["natural_residual"], c["linear_solver"]
+    sigma, alpha = gi["sigma"], 0.95
+    s = hip.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=1)
+    assert s.query()["threads"] == int(threads)
+    s.UpdateOptions(hip.DefaultOptions(sigma0=sigma, sigma_max=100.0, alpha=alpha))
+    e = np.zeros(0)
+    z, v = np.asarray(gi["x_z"], float), np.asarray(gi["x_v"], float)
+    zb, vb = np.asarray(gi["xbar_z"], float), np.asarray(gi["xbar_v"], float)
+    g = s.debug_newton(data, z, e, v, zb, e, vb)
+    assert g["ok"]
+    np.testing.assert_allclose(g["rz"], gn["rz"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(g["rz"] + sigma * (z - zb), gi["rz"], rtol=0, atol=1e-13)
+    y = b - A @ z
+    np.testing.assert_allclose(np.minimum(y, v), gn["rv"], rtol=0, atol=1e-14)
+    gam, mus = _pfb_gradient(y + sigma * (v - vb), v, alpha, sigma)
+    np.testing.assert_allclose(gam * (A @ g["dz"]) - mus * g["dv"], gi["rv"], rtol=0, atol=1e-12)
+    # linear solver (:169-208): both block rows of the eliminated-free system vanish
+    rz = -(g["rz"] + sigma * (z - zb))
+    rv = -_pfb(y + sigma * (v - vb), v, alpha)
+    e1 = Hm @ g["dz"] + sigma * g["dz"] + A.T @ g["dv"] - rz
+    e3 = -gam * (A @ g["dz"]) + mus * g["dv"] - rv
+    assert np.sqrt(e1 @ e1 + e3 @ e3) <= gl["tol"]
+    s.close()
+
+
+# ---- seeded random shapes over every MPC instance ---------------------------------
+# (N, nx, nu, nc) -> the kernel fbstab_hip_mpc_create must pick (fbstab_hip.hip:
+# record_instance_for); four shapes per instance, exact and padded.
+_MPC_SHAPES = [
+    ((6, 12, 4, 20), "fbstab_mpc_r16_kernel<12,4,20>"), ((9, 5, 2, 7), "fbstab_mpc_r16_kernel<12,4,20>"),
+    ((3, 12, 1, 17), "fbstab_mpc_r16_kernel<12,4,20>"), ((11, 1, 4, 1), "fbstab_mpc_r16_kernel<12,4,20>"),
+    ((5, 12, 4, 32), "fbstab_mpc_r16_kernel<12,4,32>"), ((8, 7, 3, 21), "fbstab_mpc_r16_kernel<12,4,32>"),
+    ((2, 11, 4, 27), "fbstab_mpc_r16_kernel<12,4,32>"), ((12, 3, 1, 30), "fbstab_mpc_r16_kernel<12,4,32>"),
+    ((7, 18, 5, 10), "fbstab_mpc_r32_kernel<18,5,10>"), ((4, 13, 2, 6), "fbstab_mpc_r32_kernel<18,5,10>"),
+    ((10, 16, 5, 9), "fbstab_mpc_r32_kernel<18,5,10>"), ((3, 12, 5, 3), "fbstab_mpc_r32_kernel<18,5,10>"),
+    ((5, 24, 8, 16), "fbstab_mpc_r32_kernel<24,8,16>"), ((6, 20, 6, 16), "fbstab_mpc_r32_kernel<24,8,16>"),
+    ((9, 19, 2, 12), "fbstab_mpc_r32_kernel<24,8,16>"), ((2, 14, 7, 11), "fbstab_mpc_r32_kernel<24,8,16>"),
+    ((4, 24, 8, 32), "fbstab_mpc_r32_kernel<24,8,32>"), ((7, 20, 6, 30), "fbstab_mpc_r32_kernel<24,8,32>"),
+    ((3, 22, 3, 17), "fbstab_mpc_r32_kernel<24,8,32>"), ((8, 13, 8, 25), "fbstab_mpc_r32_kernel<24,8,32>"),
+    ((4, 26, 3, 9), "fbstab_mpc_kernel<64>"), ((3, 10, 9, 12), "fbstab_mpc_kernel<64>"),
+    ((5, 8, 2, 33), "fbstab_mpc_kernel<64>"), ((2, 25, 9, 5), "fbstab_mpc_kernel<64>"),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(_MPC_SHAPES)))
+def test_random_shapes_on_every_mpc_instance(hip, oracle, idx):
+    """tools/fuzz_shapes.py, a fixed subset: random time-varying problems (dense
+    constraint rows, S != 0) of shapes chosen to land on each of the five record
+    instances and on the flat-vector kernel, a third of them with a restricted line
+    search.  Exit flags and proximal counts equal the oracle's; Newton counts differ
+    by at most 2; solutions within the parity tolerance."""
+    (N, nx, nu, nc), kern = _MPC_SHAPES[idx]
+    rng = np.random.default_rng(7000 + idx)
+    B = int(rng.integers(2, 12))
+    o = default_options()
+    if idx % 3 == 2:
+        o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
+    p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    assert s.kernel_name() == kern, s.kernel_name()
+    s.UpdateOptions(_opts(hip, o))
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    s.close()
+    c = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    oc = c[4]
+    assert np.array_equal(out["eflag"], oc["eflag"])
+    assert np.array_equal(out["prox_iters"], oc["prox_iters"])
+    dn = np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
+    assert dn.max() <= 2, dn
+    good = oc["eflag"] == 0
+    if good.any():
+        scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+        assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
+
+
+# (nz, nl, nv) -> threads per QP of the kernel that must run it (one wavefront for
+# nz + nl <= 64, four beyond; the K-in-global-memory layout above ~140)
+_DENSE_SHAPES = [
+    ((1, 0, 1), 64), ((7, 3, 40), 64), ((50, 10, 100), 64), ((33, 0, 9), 64), ((60, 4, 131), 64), ((20, 5, 40), 64),
+    ((64, 1, 30), 256), ((90, 12, 77), 256), ((120, 20, 60), 256), ((70, 0, 200), 256),
+    ((150, 10, 90), 256), ((159, 24, 239), 256),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(_DENSE_SHAPES)))
+def test_random_shapes_on_every_dense_kernel(hip, oracle, idx):
+    """tools/fuzz_dense.py, a fixed subset over the one-wavefront kernel, the
+    four-wavefront kernel and its K-in-global-memory instance."""
+    (nz, nl, nv), threads = _DENSE_SHAPES[idx]
+    rng = np.random.default_rng(8000 + idx)
+    B = int(rng.integers(1, 9))
+    o = default_options()
+    p = fx.synthetic_dense_batch(B, nz, nl, nv, first_id=int(rng.integers(0, 1 << 20)))
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=B)
+    assert s.query()["threads"] == threads
+    z = np.zeros((B, nz)); l = np.zeros((B, nl)); v = np.zeros((B, nv)); y = np.zeros((B, nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    s.close()
+    c = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+    oc = c[4]
+    assert np.array_equal(out["eflag"], oc["eflag"])
+    assert np.array_equal(out["prox_iters"], oc["prox_iters"])
+    dn = np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
+    assert dn.max() <= 2, dn
+    good = oc["eflag"] == 0
+    if good.any():
+        scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+        assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()

@@ -545,7 +545,7 @@ def test_line_search_trial_limits_on_the_record_kernel(hip, oracle, max_ls):
     cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
     assert np.array_equal(gpu[4]["eflag"], cpu[4]["eflag"])
     dn = np.abs(gpu[4]["newton_iters"].astype(int) - cpu[4]["newton_iters"].astype(int))
-    assert (dn == 0).mean() >= 0.97 and dn.max() <= 4, ((dn != 0).sum(), dn.max())
+    assert (dn == 0).mean() >= 0.99 and dn.max() <= 2, ((dn != 0).sum(), dn.max())
     ok = cpu[4]["eflag"] == 0
     scale = 1.0 + np.abs(cpu[0]).max(axis=1, keepdims=True)
     assert (np.abs(gpu[0] - cpu[0])[ok] <= 10 * o.abs_tol * scale[ok]).all()
@@ -1073,7 +1073,7 @@ def test_config4_all_eight_shards(hip, oracle):
         oc = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())[4]
         assert np.array_equal(og["eflag"], oc["eflag"]), shard
         dn = np.abs(og["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
-        assert (dn == 0).mean() >= 0.99 and dn.max() <= 4, (shard, (dn != 0).sum(), dn.max())
+        assert (dn == 0).mean() >= 0.99 and dn.max() <= 2, (shard, (dn != 0).sum(), dn.max())
         tot_g += int(og["newton_iters"].sum())
         tot_c += int(oc["newton_iters"].sum())
         limit_g += (shard * B + np.nonzero(og["eflag"] == 2)[0]).tolist()

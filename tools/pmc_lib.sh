@@ -1,0 +1,30 @@
+#!/bin/bash
+# Developer tool (GPU box): traffic and SQ counter passes over ONE launch of the MPC
+# kernel of a build variant.  usage: tools/pmc_lib.sh <outdir> <lib.so> [batch]
+# Each pass is its own process, --pmc with --kernel-trace only, wrapped in timeout.
+R=$PWD; OUT=$R/$1; export FBSTAB_HIP_LIB=$R/$2; B=${3:-8192}; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+ "SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES" \
+ "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
+ "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCC_HIT TCC_MISS TCC_REQ" ; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $set --kernel-trace -d $OUT/p$i -o p -- python3 $R/tools/variant_bench.py $B 1 > $OUT/p$i.log 2>&1
+  echo "pass $i rc=$?"
+done
+cd $R
+for j in $(seq 1 $i); do python3 tools/rocpd_summary.py pmc $OUT/p$j/p_results.db _kernel > $OUT/p$j.json 2>/dev/null; rm -rf $OUT/p$j; done
+python3 - <<PY
+import json,glob
+tot={}
+for f in sorted(glob.glob("$OUT/p*.json")):
+    try: rows=json.load(open(f))
+    except Exception as e: print(f,"unreadable"); continue
+    last=max(r["dispatch_id"] for r in rows) if rows else None
+    for r in rows:
+        if r["dispatch_id"]==last: tot[r["counter"]]=r["value"]; tot.setdefault("duration_ms",[]).append(r["duration_ns"]/1e6)
+tot["duration_ms"]=sorted(set(tot.get("duration_ms",[])))
+json.dump(tot, open("$OUT/summary.json","w"), indent=1)
+print(json.dumps(tot))
+PY
