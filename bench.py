@@ -66,6 +66,9 @@ def cpu_baseline(sample_qps: int):
     t_1 = time.perf_counter() - t0
     return {
         "value": sample_qps / t_omp, "unit": "QPs/sec", "cores": cores, "kind": "port",
+        # what the box actually grants the process: `cores` threads may share fewer CPUs
+        "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": cgroup_cpu_quota(),
+        "os_cpu_count": os.cpu_count(),
         "sample": f"{sample_qps} QPs of the same synthetic MPC workload (ids 0..{sample_qps - 1}), "
                   f"OpenMP schedule(dynamic) over the batch, {t_omp:.1f} s; "
                   f"single thread: {n1} QPs in {t_1:.1f} s",
@@ -74,22 +77,46 @@ def cpu_baseline(sample_qps: int):
     }
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the cgroup grants (cpu.max quota / period), or None."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                t = f.read().split()
+            if path.endswith("cpu.max"):
+                return None if t[0] == "max" else float(t[0]) / float(t[1])
+            q = float(t[0])
+            if q <= 0:
+                return None
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                return q / float(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            pass
+    return None
+
+
 def stored_traffic(batch: int):
     """HBM bytes per launch of the record kernel from the newest committed
     rocprofv3 --pmc summary for this batch size (FETCH_SIZE and WRITE_SIZE in
     separate passes; bench.py cannot run the profiler on itself, so the figure is
-    REPLAYED from profiles/, not measured in this run).  Returns (bytes, source)."""
+    REPLAYED from profiles/, not measured in this run).  Returns a dict:
+    corrected bytes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies the
+    16-byte-per-lane reads of the records at half their bytes on gfx950, so the read
+    side is doubled; WRITE_SIZE is exact), the raw counter sum, the regime the
+    counters were taken in, and the source file."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if t.get("batch") == batch:
-                return t["hbm_bytes_per_launch_raw"], "profiles/" + os.path.basename(path) + " (replayed; build " + \
-                    str(t.get("build", "unrecorded")) + ")"
+                return {"corrected": t["hbm_bytes_per_launch_fetch_doubled"], "raw": t["hbm_bytes_per_launch_raw"],
+                        "regime": t.get("regime", "one launch at a time (rocprofv3 --pmc over tools/variant_bench.py)"),
+                        "source": "profiles/" + os.path.basename(path) + " (replayed; build " +
+                                  str(t.get("build", "unrecorded")) + ")"}
         except (OSError, ValueError, KeyError):
             pass
-    return None, None
+    return None
 
 
 def main():
@@ -260,7 +287,8 @@ def main():
         per_step_s = elapsed / args.steps
         achieved = ALG_BYTES_PER_QP * B * world / per_step_s / 1e9 / world  # per GPU
         k_ms = head["kernel_ms"]
-        traffic, traffic_src = stored_traffic(B)
+        tr = stored_traffic(B)
+        traffic = tr["corrected"] if tr else None
         rec = {
             "metric": "QPs/sec (batched MPC N=30 nx=12 nu=4 nc=20)",
             "value": total_qps, "unit": "QPs/sec", "n_gpus": world, "steps": args.steps,
@@ -278,7 +306,13 @@ def main():
             # is the named extra
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         # corrected counter bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), the raw
+                         # sum beside it, their ratio to the algorithmic bytes and the regime the
+                         # counters were taken in (the profiler serialises dispatches)
+                         "traffic": traffic, "traffic_raw": tr["raw"] if tr else None,
+                         "traffic_ratio": (traffic / (ALG_BYTES_PER_QP * B)) if traffic else None,
+                         "traffic_regime": tr["regime"] if tr else None,
+                         "traffic_source": tr["source"] if tr else None,
                          "traffic_per_step_GBps": (traffic / per_step_s / 1e9) if traffic else None,
                          "kernel": head["kernel"], "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B,
@@ -347,14 +381,16 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
     ach = DENSE_ALG_BYTES_PER_QP * batch / per_step / 1e9
     # HBM bytes per launch from the newest committed counter summary of the dense kernel
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; replayed, not measured in this run)
-    traffic, traffic_src = None, None
+    traffic, traffic_raw, traffic_src = None, None, None
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dense_wave_counters.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
-            traffic = t["derived"]["hbm_bytes_per_launch_raw"]
-            traffic_src = "profiles/" + os.path.basename(path) + " (replayed)"
+            traffic_raw = t["derived"]["hbm_bytes_per_launch_raw"]
+            # corrected: the read side doubled (16-byte-per-lane reads, MI355X_MICROARCH.md HBM section)
+            traffic = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
+            traffic_src = "profiles/" + os.path.basename(path) + " (replayed; one launch at a time under rocprofv3 --pmc)"
             break
         except (OSError, ValueError, KeyError):
             pass
@@ -363,7 +399,9 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
          "steps_in_flight": lanes, "kernel_ms": k_ms, "serial_value": batch / (k_ms * 1e-3),
          "mean_newton_iters": float(outs[0]["newton_iters"].mean()), "all_converged": ok,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
+                      "traffic_ratio": (traffic / (DENSE_ALG_BYTES_PER_QP * batch)) if traffic else None,
+                      "traffic_source": traffic_src,
                       "kernel": "fbstab_dense_wave_kernel" if L[0]["s"].query()["threads"] == 64
                       else "fbstab_dense_kernel",
                       "algorithmic_bytes_per_launch": DENSE_ALG_BYTES_PER_QP * batch},

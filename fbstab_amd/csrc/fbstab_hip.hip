@@ -18,6 +18,7 @@
 #include "fb_algorithm.h"
 #include "fb_dense.h"
 #include "fb_dense_wave.h"
+#include "fb_final_norms.h"
 #include "fb_mpc.h"
 #include "fb_mpc_r16.h"
 #include "fb_record_kernel.h"
@@ -333,6 +334,13 @@ struct SolverBase {
     if (!d_out_only) HIP_TRY(hipMalloc(&d_out_only, sizeof(fbstab_solver_out_t) * (size_t)max_batch));
     return FBSTAB_HIP_OK;
   }
+  double* d_norms = nullptr;  // fbstab_hip_*_solve_batch_final: device side of the norms returned to the host
+  int ensure_norms() {
+    if (!d_norms) HIP_TRY(hipMalloc(&d_norms, sizeof(double) * 4 * (size_t)max_batch));
+    return FBSTAB_HIP_OK;
+  }
+  // workspace of the traced flat-vector MPC solve (kept from call to call)
+  double* trace_ws = nullptr;
 
   int release() {
     (void)hipSetDevice(device);
@@ -342,6 +350,8 @@ struct SolverBase {
       if (d_var[i]) (void)hipFree(d_var[i]);
     if (d_out) (void)hipFree(d_out);
     if (d_out_only) (void)hipFree(d_out_only);
+    if (d_norms) (void)hipFree(d_norms);
+    if (trace_ws) (void)hipFree(trace_ws);
     if (scratch) (void)hipFree(scratch);
     if (counter) (void)hipFree(counter);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -664,9 +674,11 @@ int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t h, fbstab_options_t* o) {
 
 // solve_batch; with d_trace != nullptr the ONE QP of the call runs on the traced
 // instance of the flat-vector kernel instead (fbstab_hip_mpc_solve_traced).
+// norms != nullptr: the component norms of the summary block follow the solve
+// (fbstab_hip_mpc_solve_batch_final); they live where `out` lives.
 static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
                           const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
-                          void* stream, double* d_trace) {
+                          void* stream, double* d_trace, double* norms = nullptr) {
   int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
   if (rc != FBSTAB_HIP_OK) return rc;
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
@@ -718,7 +730,6 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
   int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  DevBuf tmp_ws;
   if (d_trace) {
     const int lds = h->lay.lds_doubles * (int)sizeof(double);
     if (h->lay.nx > kMpcThreads || lds > kLdsLimitBytes)
@@ -726,9 +737,9 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     auto kern = fbstab_mpc_kernel<kMpcThreads, false, true>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipMalloc(&tmp_ws.p, sizeof(double) * (size_t)h->lay.ws_doubles));
+    if (!h->trace_ws) HIP_TRY(hipMalloc(&h->trace_ws, sizeof(double) * (size_t)h->lay.ws_doubles));
     hipLaunchKernelGGL(kern, dim3(1), dim3(kMpcThreads), lds, s, h->lay, a, v, d_out, h->opts,
-                       static_cast<double*>(tmp_ws.p), h->counter, 1, d_trace);
+                       h->trace_ws, h->counter, 1, d_trace);
   } else if (h->rec) {
     // FBSTAB_HIP_KEEP_MATRICES: one QP per slot, slot = QP index
     const bool keep = (flags & FBSTAB_HIP_KEEP_MATRICES) && dev_ptrs && batch <= h->workgroups * h->qps_per_wg;
@@ -746,6 +757,23 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
+  const bool norms_host = norms && (!dev_ptrs || out_host);
+  if (norms) {
+    double* dn = norms;
+    if (norms_host) {
+      rc = h->ensure_norms();
+      if (rc != FBSTAB_HIP_OK) return rc;
+      dn = h->d_norms;
+    }
+    MpcNormArgs na;
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { na.base[i] = a.base[i]; na.stride[i] = a.stride[i]; }
+    for (int i = 0; i < 4; i++) { na.x[i] = v.base[i]; na.xstride[i] = v.stride[i]; }
+    na.N = h->lay.N; na.nx = h->lay.nx; na.nu = h->lay.nu; na.nc = h->lay.nc;
+    hipLaunchKernelGGL(fbstab_mpc_final_norms_kernel, dim3(batch), dim3(64), 0, s, na, h->opts, dn, batch);
+    HIP_TRY(hipGetLastError());
+    if (norms_host)
+      HIP_TRY(hipMemcpyAsync(norms, dn, sizeof(double) * 4 * (size_t)batch, hipMemcpyDeviceToHost, s));
+  }
   if (!dev_ptrs) {
     for (int i = 0; i < 4; i++) {
       rc = h->download(x->base[i], x->stride[i] ? x->stride[i] : h->var_len[i], h->var_len[i], batch,
@@ -765,6 +793,13 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     HIP_TRY(hipStreamSynchronize(s));
   }
   return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_mpc_solve_batch_final(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
+                                     const fbstab_var_batch_t* x, fbstab_solver_out_t* out, double* norms,
+                                     int flags, void* stream) {
+  if (!norms) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null norms pointer");
+  return mpc_solve_impl(h, batch, data, x, out, flags, stream, nullptr, norms);
 }
 
 int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_batch_t* data,
@@ -1067,7 +1102,7 @@ int fbstab_hip_dense_get_options(fbstab_dense_handle_t h, fbstab_options_t* o) {
 
 static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_dense_batch_t* data,
                             const fbstab_var_batch_t* x, fbstab_solver_out_t* out, int flags,
-                            void* stream, double* d_trace) {
+                            void* stream, double* d_trace, double* norms = nullptr) {
   int rc = check_common(h, batch, data, x, out, h ? h->max_batch : 0);
   if (rc != FBSTAB_HIP_OK) return rc;
   for (int i = 0; i < FBSTAB_DENSE_NARR; i++)
@@ -1155,6 +1190,23 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
   h->timed = true;
+  const bool norms_host = norms && (!dev_ptrs || out_host);
+  if (norms) {
+    double* dn = norms;
+    if (norms_host) {
+      rc = h->ensure_norms();
+      if (rc != FBSTAB_HIP_OK) return rc;
+      dn = h->d_norms;
+    }
+    DenseNormArgs na;
+    for (int i = 0; i < FBSTAB_DENSE_NARR; i++) { na.base[i] = a.base[i]; na.stride[i] = a.stride[i]; }
+    for (int i = 0; i < 4; i++) { na.x[i] = v.base[i]; na.xstride[i] = v.stride[i]; }
+    na.nz = h->lay.nz; na.nl = h->lay.nl; na.nv = h->lay.nv;
+    hipLaunchKernelGGL(fbstab_dense_final_norms_kernel, dim3(batch), dim3(64), 0, s, na, h->opts, dn, batch);
+    HIP_TRY(hipGetLastError());
+    if (norms_host)
+      HIP_TRY(hipMemcpyAsync(norms, dn, sizeof(double) * 4 * (size_t)batch, hipMemcpyDeviceToHost, s));
+  }
   if (!dev_ptrs) {
     for (int i = 0; i < 4; i++) {
       rc = h->download(x->base[i], x->stride[i] ? x->stride[i] : h->var_len[i], h->var_len[i], batch,
@@ -1174,6 +1226,13 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
     HIP_TRY(hipStreamSynchronize(s));
   }
   return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_dense_solve_batch_final(fbstab_dense_handle_t h, int batch, const fbstab_dense_batch_t* data,
+                                       const fbstab_var_batch_t* x, fbstab_solver_out_t* out, double* norms,
+                                       int flags, void* stream) {
+  if (!norms) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null norms pointer");
+  return dense_solve_impl(h, batch, data, x, out, flags, stream, nullptr, norms);
 }
 
 int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t h, int batch,

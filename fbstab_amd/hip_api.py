@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
         getattr(lib, f"fbstab_hip_{kind}_get_options").argtypes = [C.c_void_p, C.c_void_p]
         getattr(lib, f"fbstab_hip_{kind}_solve_batch").argtypes = [
             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        getattr(lib, f"fbstab_hip_{kind}_solve_batch_final").argtypes = [
+            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         getattr(lib, f"fbstab_hip_{kind}_query").argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         getattr(lib, f"fbstab_hip_{kind}_solve_traced").argtypes = [
@@ -132,12 +134,13 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = (
     "fbstab_hip_last_error", "fbstab_hip_device_count",
     "fbstab_hip_mpc_create", "fbstab_hip_mpc_destroy", "fbstab_hip_mpc_set_options",
-    "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch",
+    "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch", "fbstab_hip_mpc_solve_batch_final",
     "fbstab_hip_mpc_solve_traced", "fbstab_hip_mpc_receding_sweep",
     "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_kernel_name",
     "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
-    "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_traced",
+    "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_batch_final",
+    "fbstab_hip_dense_solve_traced",
     "fbstab_hip_dense_debug_newton", "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
 
 
@@ -208,7 +211,7 @@ class _SolverBase:
                     threads=th.value)
 
     def _solve(self, batch_struct, names: Sequence[str], lens: Sequence[int], arrays,
-               var_lens, z, l, v, y, out, stream, async_, keep_matrices=False):
+               var_lens, z, l, v, y, out, stream, async_, keep_matrices=False, norms=False):
         dev_flags = []
         B = None
         for i, (k, n) in enumerate(zip(names, lens)):
@@ -250,6 +253,19 @@ class _SolverBase:
                 out = np.zeros(B, dtype=OUT_DTYPE)
             out_ptr = out.ctypes.data
             flags = HOST_POINTERS
+        if norms:
+            # fbstab_hip_*_solve_batch_final: (B, 4) |rz| |rl| |rv| tolerance, living where out lives
+            if on_dev:
+                nrm = torch.zeros((B, 4), dtype=torch.float64, device=z.device)
+                nptr = nrm.data_ptr()
+            else:
+                nrm = np.zeros((B, 4))
+                nptr = nrm.ctypes.data
+            rc = getattr(self._lib, f"fbstab_hip_{self._kind}_solve_batch_final")(
+                self._h, B, C.byref(batch_struct), C.byref(vb), out_ptr, C.c_void_p(nptr), flags,
+                C.c_void_p(stream) if stream else None)
+            _check(self._lib, rc)
+            return out, nrm
         rc = getattr(self._lib, f"fbstab_hip_{self._kind}_solve_batch")(
             self._h, B, C.byref(batch_struct), C.byref(vb), out_ptr, flags,
             C.c_void_p(stream) if stream else None)
@@ -324,6 +340,13 @@ class FBstabMpcBatch(_SolverBase):
         return self._solve(_MpcBatch(), MPC_SEQ, self.seq_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
                            stream, async_, keep_matrices)
+
+    def SolveFinal(self, data, z, l, v, y, out=None, stream: int = 0, async_: bool = False):
+        """Solve followed by the numbers of the reference's Display::FINAL summary
+        (fbstab_hip_mpc_solve_batch_final): returns ``(out, norms)``, norms ``(batch, 4)``
+        = |rz|, |rl|, |rv|, tolerance at the returned point."""
+        return self._solve(_MpcBatch(), MPC_SEQ, self.seq_len, data,
+                           (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out, stream, async_, norms=True)
 
     def SolveTraced(self, data, z, l, v, y, capacity: int = 4096):
         """One QP (``(1, n)`` numpy arrays) with the reference's per-iteration
@@ -425,6 +448,11 @@ class FBstabDenseBatch(_SolverBase):
         return self._solve(_DenseBatch(), DENSE_ARR, self.arr_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
                            stream, async_)
+
+    def SolveFinal(self, data, z, l, v, y, out=None, stream: int = 0, async_: bool = False):
+        """As FBstabMpcBatch.SolveFinal (fbstab_hip_dense_solve_batch_final)."""
+        return self._solve(_DenseBatch(), DENSE_ARR, self.arr_len, data,
+                           (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out, stream, async_, norms=True)
 
     def debug_newton(self, data, z, l, v, zb, lb, vb):
         """Tests only: one Newton step of the dense device path at (x, xbar, sigma0,

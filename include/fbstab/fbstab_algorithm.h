@@ -112,11 +112,12 @@ inline SolverOut FromC(const fbstab_solver_out_t& c) {
 
 // The display of the reference (fbstab_algorithm-impl.h:411-541).
 //
-// Every level above OFF prints the component norms |rz| |rl| |rv| of the residual
-// (FINAL in its summary block, impl:493-541 - the reference's DEFAULT level), which
-// SolverOut does not carry: Solve() then runs fbstab_hip_*_solve_traced and
-// PrintTrace() formats the records it returns, line for line as the reference
-// prints them.  Display::OFF takes the batch kernels.
+// Every level above OFF prints the component norms |rz| |rl| |rv| of the residual,
+// which SolverOut does not carry.  Display::FINAL - the reference's DEFAULT level, its
+// summary block only (impl:493-541) - runs the batch kernels like Display::OFF and
+// takes the three norms from fbstab_hip_*_solve_batch_final; ITER and ITER_DETAILED run
+// fbstab_hip_*_solve_traced and PrintTrace() formats the records it returns, line for
+// line as the reference prints them.
 inline const char* ExitMessage(ExitFlag e) {
   switch (e) {
     case ExitFlag::SUCCESS: return " Success\n";
@@ -141,6 +142,17 @@ void PrintSummaryHead(const SolverOut& s, const AlgorithmParameters& p, const Ou
   os.Print(buff);
   snprintf(buff, 100, "Newton iterations: %d out of %d\n", s.newton_iters, p.max_newton_iters);
   os.Print(buff);
+}
+
+// Whether the residual blocks the reference prints in its summary belong to the point
+// the solve returned: SUCCESS (rk_ evaluated at x(k), impl:162-170) and the Newton
+// iteration limit (rk_ re-evaluated at the returned point, impl:188-199).  The
+// infeasibility exits return the certificate while rk_ still belongs to x(k)
+// (impl:204-212), and at the proximal iteration limit rk_ is one iteration old
+// (impl:219-223).
+inline bool FinalNormsAtReturnedPoint(const fbstab_solver_out_t& c, const AlgorithmParameters& p) {
+  return c.eflag == FBSTAB_SUCCESS ||
+         (c.eflag == FBSTAB_MAXITERATIONS && c.newton_iters >= p.max_newton_iters);
 }
 
 // Number of records one solve can produce: two per proximal iteration, one per
@@ -201,6 +213,21 @@ void PrintTrace(const fbstab_trace_record_t* rec, int n, const SolverOut& s,
         break;
     }
   }
+}
+
+// The summary block (impl:493-541) from the four numbers of fbstab_hip_*_solve_batch_final.
+template <class OutStream>
+void PrintFinalBlock(const double (&norms)[4], const SolverOut& s, const AlgorithmParameters& p,
+                     const OutStream& os) {
+  fbstab_trace_record_t r;
+  r.kind = FBSTAB_TRACE_FINAL;
+  r.i0 = static_cast<double>(static_cast<int>(s.eflag));
+  r.i1 = 0.0;
+  for (int k = 0; k < 4; k++) r.v[k] = norms[k];
+  r.v[4] = 0.0;
+  AlgorithmParameters q = p;
+  q.display_level = Display::FINAL;
+  PrintTrace(&r, 1, s, q, os);
 }
 
 }  // namespace detail

@@ -115,7 +115,7 @@ class FBstabMpc {
   // VariableRef exist so that a caller's buffers are used without copies
   // (fbstab_mpc.h:90-150); here those buffers may be DEVICE memory: after
   // SetMemory(Memory::DEVICE) Solve hands the pointers to the kernel as they are
-  // (no staging copies; display levels above OFF need host memory).
+  // (no staging copies; the iteration displays ITER / ITER_DETAILED need host memory).
   enum class Memory { HOST, DEVICE };
   void SetMemory(Memory m) { memory_ = m; }
 
@@ -140,12 +140,42 @@ class FBstabMpc {
     v.stride[0] = nz_; v.stride[1] = nl_; v.stride[2] = nv_; v.stride[3] = nv_;
     fbstab_solver_out_t out;
     if (memory_ == Memory::DEVICE) {
-      if (opts_.display_level != Display::OFF)
-        throw std::runtime_error("In FBstabMpc::Solve: device-resident data is solved with Display::OFF.");
-      if (fbstab_hip_mpc_solve_batch(h_, 1, &b, &v, &out, FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_OUT_ON_HOST,
-                                     nullptr) != FBSTAB_HIP_OK)
+      if (opts_.display_level > Display::FINAL)
+        throw std::runtime_error("In FBstabMpc::Solve: the iteration displays need host-resident data.");
+      const int fl = FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_OUT_ON_HOST;
+      if (opts_.display_level == Display::OFF) {
+        if (fbstab_hip_mpc_solve_batch(h_, 1, &b, &v, &out, fl, nullptr) != FBSTAB_HIP_OK)
+          throw std::runtime_error(std::string("In FBstabMpc::Solve: ") + fbstab_hip_last_error());
+        return detail::FromC(out);
+      }
+      // (FINAL on device-resident data: the summary's residual blocks are always those of the
+      // returned point - for an infeasibility certificate or at the proximal iteration limit the
+      // reference prints the residual of an earlier iterate, which would need a second solve)
+      double nrm[4];
+      if (fbstab_hip_mpc_solve_batch_final(h_, 1, &b, &v, &out, nrm, fl, nullptr) != FBSTAB_HIP_OK)
         throw std::runtime_error(std::string("In FBstabMpc::Solve: ") + fbstab_hip_last_error());
-      return detail::FromC(out);
+      SolverOut st = detail::FromC(out);
+      detail::PrintFinalBlock(nrm, st, opts_, os);
+      return st;
+    }
+    if (opts_.display_level == Display::FINAL) {
+      // the reference's default level: the batch kernels, then the summary block.  The guess
+      // is kept for the exits whose printed residual belongs to an earlier iterate.
+      std::vector<double> gz(x->z.data(), x->z.data() + nz_), gl(x->l.data(), x->l.data() + nl_),
+          gv(x->v.data(), x->v.data() + nv_);
+      double nrm[4];
+      if (fbstab_hip_mpc_solve_batch_final(h_, 1, &b, &v, &out, nrm, FBSTAB_HIP_HOST_POINTERS, nullptr) !=
+          FBSTAB_HIP_OK)
+        throw std::runtime_error(std::string("In FBstabMpc::Solve: ") + fbstab_hip_last_error());
+      if (detail::FinalNormsAtReturnedPoint(out, opts_) || out.eflag == FBSTAB_DIVERGENCE ||
+          out.eflag == FBSTAB_SATURATE_ERROR) {
+        SolverOut st = detail::FromC(out);
+        detail::PrintFinalBlock(nrm, st, opts_, os);
+        return st;
+      }
+      for (int i = 0; i < nz_; i++) x->z.data()[i] = gz[i];
+      for (int i = 0; i < nl_; i++) x->l.data()[i] = gl[i];
+      for (int i = 0; i < nv_; i++) x->v.data()[i] = gv[i];
     }
     if (opts_.display_level >= Display::FINAL) {
       // every display level prints component norms (|rz| |rl| |rv|, impl:411-541):

@@ -14,6 +14,10 @@
  *   fbstab_hip_mpc_solve_batch          FBstabMpc::Solve(qp, &x), fbstab_mpc.h:181-195
  *                                       (batch == 1 with host pointers is exactly one
  *                                       reference Solve call)
+ *   fbstab_hip_mpc_solve_batch_final    the same Solve at Display::FINAL, the reference's default
+ *                                       level: the batch kernels, then the |rz| |rl| |rv| and
+ *                                       tolerance of the summary block PrintFinal prints
+ *                                       (fbstab_algorithm-impl.h:493-541)
  *   fbstab_hip_mpc_solve_traced         the same Solve with Display::ITER / ITER_DETAILED:
  *                                       the numbers of PrintIterLine, PrintDetailedHeader/
  *                                       Line/Footer and PrintFinal
@@ -131,6 +135,21 @@ int fbstab_hip_mpc_get_options(fbstab_mpc_handle_t handle, fbstab_options_t* opt
 int fbstab_hip_mpc_solve_batch(fbstab_mpc_handle_t handle, int batch,
                                const fbstab_mpc_batch_t* data, const fbstab_var_batch_t* x,
                                fbstab_solver_out_t* out, int flags, void* stream);
+/* fbstab_hip_mpc_solve_batch followed, on the same stream, by the numbers of the
+ * summary block the reference prints at Display::FINAL (PrintFinal,
+ * fbstab_algorithm-impl.h:493-541): norms[4 q .. 4 q + 3] = {|rz|, |rl|, |rv|} of the
+ * penalised natural residual (full_residual.cc:99-109) at the point QP q returned, and
+ * the stopping tolerance abs_tol + rel_tol (1 + ||(f, h, b)||) (impl:137).  `norms` lives
+ * where `out` lives (host for host-pointer calls and with FBSTAB_HIP_OUT_ON_HOST, device
+ * otherwise).  Same kernels, same iteration counts as solve_batch.  For SUCCESS and the
+ * Newton-iteration limit these are the numbers the reference prints (its rk_ is evaluated
+ * at the returned point, impl:162-170, :188-199); for infeasibility exits (impl:204-212:
+ * the certificate is returned, rk_ belongs to x(k)) and the proximal-iteration limit
+ * (impl:219-223: rk_ is one iteration old) the reference prints a residual of a point the
+ * solve does not return - callers that need that text use solve_traced. */
+int fbstab_hip_mpc_solve_batch_final(fbstab_mpc_handle_t handle, int batch,
+                                     const fbstab_mpc_batch_t* data, const fbstab_var_batch_t* x,
+                                     fbstab_solver_out_t* out, double* norms, int flags, void* stream);
 /* ONE QP given by host pointers, solved synchronously, with the per-iteration
  * display of the reference returned as data: every line the reference's
  * Display::ITER and ITER_DETAILED levels would print during this solve
@@ -215,6 +234,10 @@ int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t handle, int batch,
                                  const fbstab_dense_batch_t* data,
                                  const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
                                  int flags, void* stream);
+/* As fbstab_hip_mpc_solve_batch_final (FBstabDense::Solve at Display::FINAL). */
+int fbstab_hip_dense_solve_batch_final(fbstab_dense_handle_t handle, int batch,
+                                       const fbstab_dense_batch_t* data, const fbstab_var_batch_t* x,
+                                       fbstab_solver_out_t* out, double* norms, int flags, void* stream);
 int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t handle, const fbstab_dense_batch_t* data,
                                   const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
                                   fbstab_trace_record_t* trace, int capacity, int* count);

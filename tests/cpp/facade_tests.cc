@@ -296,6 +296,19 @@ static void MapTypedRefsAndVector4() {
   }
 }
 
+// A stream of the user's own (tools/output_stream.h:15-37) collecting the display.
+class StringOutput : public OutputStream<StringOutput> {
+ public:
+  explicit StringOutput(std::string* s) : s_(s) {}
+
+ protected:
+  void PrintImplementation(const char* message) const { s_->append(message); }
+  friend class OutputStream<StringOutput>;
+
+ private:
+  std::string* s_;
+};
+
 // ProblemDataRef / VariableRef over DEVICE memory: Solve passes the pointers on
 // as they are (FBstabMpc::SetMemory, FBSTAB_HIP_DEVICE_POINTERS | OUT_ON_HOST).
 struct DeviceArray {
@@ -305,6 +318,9 @@ struct DeviceArray {
   }
   DeviceArray(const double* h, size_t n_) : DeviceArray(std::vector<double>(h, h + n_)) {}
   ~DeviceArray() { if (p) (void)hipFree(p); }
+  void upload(const std::vector<double>& h) {
+    if (p && n) (void)hipMemcpy(p, h.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+  }
   std::vector<double> host() const {
     std::vector<double> h(n);
     if (n) (void)hipMemcpy(h.data(), p, sizeof(double) * n, hipMemcpyDeviceToHost);
@@ -350,9 +366,21 @@ static void DeviceResidentRefs() {
   const std::vector<double> zd = z.host(), vd = v.host();
   for (int i = 0; i < nz; i++) EXPECT_TRUE(zd[i] == xh.z(i));
   for (int i = 0; i < nv; i++) EXPECT_TRUE(vd[i] == xh.v(i));
-  // display needs host memory
+  // Display::FINAL, the reference's default level, runs the same kernel on the device
+  // buffers (summary block from fbstab_hip_mpc_solve_batch_final); the iteration
+  // displays need host memory
   FBstabMpc::Options o = MpcOpts();
   o.display_level = Display::FINAL;
+  solver.UpdateOptions(o);
+  z.upload(std::vector<double>(nz, 0.0)); l.upload(std::vector<double>(nl, 0.0)); v.upload(std::vector<double>(nv, 0.0));
+  std::string text;
+  StringOutput os(&text);
+  SolverOut outf = solver.Solve(ref, &x, os);
+  EXPECT_TRUE(outf.eflag == ExitFlag::SUCCESS && outf.newton_iters == 9 && outf.prox_iters == 4);
+  EXPECT_TRUE(text.find("Exit code: Success") != std::string::npos && text.find("|rz|") != std::string::npos);
+  const std::vector<double> zf = z.host();
+  for (int i = 0; i < nz; i++) EXPECT_TRUE(zf[i] == xh.z(i));
+  o.display_level = Display::ITER;
   solver.UpdateOptions(o);
   EXPECT_THROW(solver.Solve(ref, &x));
 }
@@ -374,19 +402,6 @@ static void ErrorBehaviour() {
   AlgorithmParameters raw;
   EXPECT_TRUE(raw.beta == 0.7 && raw.max_newton_iters == 500);  // header initialisers differ
 }
-
-// A stream of the user's own (tools/output_stream.h:15-37) collecting the display.
-class StringOutput : public OutputStream<StringOutput> {
- public:
-  explicit StringOutput(std::string* s) : s_(s) {}
-
- protected:
-  void PrintImplementation(const char* message) const { s_->append(message); }
-  friend class OutputStream<StringOutput>;
-
- private:
-  std::string* s_;
-};
 
 // `facade_tests display`: FeasibleQP and DoubleIntegrator(2) at Display::FINAL (the
 // reference's default level), ITER and ITER_DETAILED (default options), text between
@@ -427,6 +442,22 @@ static int DisplayMode() {
       printf("===BEGIN mpc DoubleIntegrator %d===\n%s===END===\n", static_cast<int>(levels[k]), text.c_str());
       EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
     }
+  }
+  {
+    // an infeasibility exit at the default level: the reference's summary shows the residual
+    // of x(k), not of the certificate it returns (impl:204-212) - the facade's second solve
+    FBstabDense::ProblemData data(2, 0, 5);
+    data.H = {1, 0, 0, 0};
+    data.f = {1, -1};
+    data.A = {1, 1, 1, 0, 0, 1, -1, 0, 0, -1};
+    data.b = {0, 3, 3, -1, -1};
+    FBstabDense::Variable x0(2, 0, 5);
+    FBstabDense solver(2, 0, 5);  // default options: Display::FINAL
+    std::string text;
+    StringOutput os(&text);
+    SolverOut out = solver.Solve(data, &x0, os);
+    printf("===BEGIN dense InfeasibleQP 1===\n%s===END===\n", text.c_str());
+    EXPECT_TRUE(out.eflag == ExitFlag::PRIMAL_INFEASIBLE);
   }
   return g_fail ? 1 : 0;
 }

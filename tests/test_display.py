@@ -154,3 +154,58 @@ def test_traced_solve_argument_errors():
         s.SolveTraced(a, z, l, v, y, capacity=0)
     out, rec = s.SolveTraced(a, z, l, v, y, capacity=3)  # truncated, not overrun
     assert len(rec) == 3 and out["eflag"][0] == 0
+
+
+@pytest.mark.gpu
+def test_final_summary_numbers_from_the_batch_kernels(oracle, kats, display_golden):
+    """Display::FINAL, the reference's default level (impl:493-541), through
+    fbstab_hip_*_solve_batch_final: the batch kernels solve (same iteration counts as
+    solve_batch), a small kernel evaluates |rz| |rl| |rv| and the tolerance at the
+    returned point.  For the known-answer problems that end in SUCCESS these are the
+    numbers of the reference's summary block (the FINAL record of the oracle's trace,
+    whose text tests above pin to the reference's own output); on the BASELINE
+    workloads the three blocks add up to SolverOut::residual for every QP."""
+    from fbstab_amd import hip_api
+    from tools import fixtures as fx
+    done = set()
+    for case in display_golden:
+        key = (case["kind"], case["index"])
+        if key in done or case["eflag"] != 0:
+            continue
+        done.add(key)
+        p = _problem(kats, case)
+        ref = oracle.solve_display(p, opts=default_options())
+        a = {k: np.ascontiguousarray(v[:1]) for k, v in p.arrays.items()}
+        z, l, v, y = (np.zeros((1, n)) for n in (p.nz, p.nl, p.nv, p.nv))
+        s = (hip_api.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=1) if case["kind"] == "dense"
+             else hip_api.FBstabMpcBatch(*p.sizes(), max_batch=1))
+        out, nrm = s.SolveFinal(a, z, l, v, y)
+        s.close()
+        assert (out["eflag"][0], out["newton_iters"][0], out["prox_iters"][0]) == (
+            case["eflag"], case["newton_iters"], case["prox_iters"]), case["name"]
+        fin = ref[6][-1]
+        assert fin[0] == 5  # FBSTAB_TRACE_FINAL
+        _records_agree(np.concatenate([fin[:3], nrm[0], [0.0]])[None, :], fin[None, :], case["name"])
+        assert nrm[0, 3] == pytest.approx(fin[6], rel=1e-12)
+    # batches on the record kernel and the one-wavefront dense kernel, device memory
+    import torch
+    dev = torch.device("cuda:0")
+    for kind, p in (("mpc", fx.synthetic_mpc_batch(96, first_id=300)), ("dense", fx.synthetic_dense_batch(96, 50, 10, 100))):
+        s = (hip_api.FBstabMpcBatch(*p.sizes(), max_batch=96) if kind == "mpc"
+             else hip_api.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=96))
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        mk = lambda n: torch.zeros((96, n), dtype=torch.float64, device=dev)
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        out, nrm = s.SolveFinal(data, z, l, v, y)
+        out = hip_api.out_to_numpy(out)
+        nrm = nrm.cpu().numpy()
+        z2, l2, v2, y2 = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        out2 = hip_api.out_to_numpy(s.Solve(data, z2, l2, v2, y2))
+        s.close()
+        assert (out["eflag"] == 0).all() and np.array_equal(out["newton_iters"], out2["newton_iters"])
+        assert torch.equal(z, z2) and torch.equal(v, v2)
+        tot = np.sqrt((nrm[:, :3] ** 2).sum(axis=1))
+        # the kernel's own residual is carried through the Newton steps of the last
+        # subproblem's successor evaluation; the pass evaluates it afresh: rounding apart
+        np.testing.assert_allclose(tot, out["residual"], rtol=1e-6, atol=1e-9)
+        assert (nrm[:, 3] >= 1e-6).all() and (tot <= nrm[:, 3]).all()

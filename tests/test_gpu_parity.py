@@ -469,7 +469,7 @@ def test_keep_matrices_flag_changes_nothing_but_time(hip):
     also after an unflagged call in between and after a change of the matrices
     that is announced by dropping the flag once."""
     import torch
-    from fbstab_amd import receding_horizon as rh
+    from tests import closed_loop as rh
     T, S = 96, 5
     p = fx.synthetic_mpc_batch(T, first_id=31000)
     N, nx, nu, nc = p.sizes()
@@ -680,7 +680,7 @@ def test_closed_loop_with_the_generator_simulation_inputs(hip, oracle, problem, 
     loop x+ = A x + B u0* from its x0 and from seven perturbed copies, eight MPC
     steps, warm-started unshifted, device path against the oracle run in the same
     loop: equal exit flags, inputs applied equal to 1e-6 of the input scale."""
-    from fbstab_amd import receding_horizon as rh
+    from tests import closed_loop as rh
     gen = fx.OcpGenerator()
     getattr(gen, problem)(N)
     one = gen.GetFBstabInput()
@@ -725,7 +725,7 @@ def test_receding_horizon_sweep_matches_oracle(hip, oracle):
     rounding of its tolerance: at most one proximal / two Newton iterations on
     at most 2% of the 240 solves."""
     import torch
-    from fbstab_amd import receding_horizon as rh
+    from tests import closed_loop as rh
     T, S = 24, 10
     p = fx.synthetic_mpc_batch(T, first_id=4000)
     N, nx, nu, nc = p.sizes()

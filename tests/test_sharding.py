@@ -80,7 +80,7 @@ def _oracle_sweep(p, steps):
     """Closed loop of tools/fixtures' plant with the oracle as the solver (warm start
     unshifted, as the device sweep): the applied inputs, (steps, B, nu)."""
     from tools import fixtures as fx
-    from fbstab_amd.receding_horizon import closed_loop
+    from tests.closed_loop import closed_loop
     from oracle.oracle_py import Oracle
     orc = Oracle(False)
     A, Bm = fx.quadrotor_model()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: BASELINE config 5 in short form on one GPU - T closed-loop
 trajectories x S warm-started MPC steps (N=30, nx=12, nu=4, nc=20), problem
-data resident on the device, only x0 changing (fbstab_amd/receding_horizon.py).
+data resident on the device, only x0 changing (tests/closed_loop.py).
 argv: trajectories steps [retire] [keep]
 
 With "retire", a trajectory whose QP did not return SUCCESS (the closed loop
@@ -17,7 +17,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from fbstab_amd import hip_api, receding_horizon as rh  # noqa: E402
+from fbstab_amd import hip_api  # noqa: E402
+from tests import closed_loop as rh  # noqa: E402
 from tools import fixtures as fx  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
