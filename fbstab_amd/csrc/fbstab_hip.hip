@@ -832,6 +832,16 @@ int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t h, int batch, const fbstab
     return fail(FBSTAB_HIP_ERR_ARGUMENT, "plant matrices and a non-negative step count are required");
   if (h->lay.nx > 64 || h->lay.nu > 8)
     return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "receding sweep: nx <= 64 and nu <= 8");
+  for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
+    if (!data->base[i]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer");
+  for (int i = 0; i < 4; i++)
+    if (!x->base[i]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer");
+  // x0 is advanced in place, one state per trajectory: a shared x0 would be written by all of them
+  if (batch > 1 && data->stride[FBSTAB_MPC_x0] < h->lay.nx)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "receding sweep: every trajectory needs its own x0 (stride >= nx)");
+  for (int i = 0; i < 4; i++)
+    if (batch > 1 && x->stride[i] < h->var_len[i])
+      return fail(FBSTAB_HIP_ERR_ARGUMENT, "variable stride smaller than the vector length");
   if (batch == 0 || steps == 0) return FBSTAB_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -1320,3 +1330,5 @@ int fbstab_hip_dense_query(fbstab_dense_handle_t h, long long* scratch_bytes, in
 }
 
 }  // extern "C"
+
+#include "fb_shard.h"

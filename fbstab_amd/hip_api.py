@@ -125,6 +125,13 @@ def load_library() -> C.CDLL:
     lib.fbstab_hip_mpc_receding_sweep.argtypes = [
         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fbstab_hip_shard_group_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    lib.fbstab_hip_shard_group_destroy.argtypes = [C.c_void_p]
+    lib.fbstab_hip_shard_group_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    for name in ("fbstab_hip_mpc_solve_batch_sharded", "fbstab_hip_dense_solve_batch_sharded"):
+        getattr(lib, name).argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]
+    lib.fbstab_hip_mpc_receding_sweep_sharded.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                          C.c_void_p, C.c_void_p]
     lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
     lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
     _lib = lib
@@ -141,7 +148,10 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
     "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_batch_final",
     "fbstab_hip_dense_solve_traced",
-    "fbstab_hip_dense_debug_newton", "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query")
+    "fbstab_hip_dense_debug_newton", "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query",
+    "fbstab_hip_shard_group_create", "fbstab_hip_shard_group_destroy", "fbstab_hip_shard_group_stats",
+    "fbstab_hip_mpc_solve_batch_sharded", "fbstab_hip_mpc_receding_sweep_sharded",
+    "fbstab_hip_dense_solve_batch_sharded")
 
 
 class FBstabHipError(RuntimeError):
@@ -495,3 +505,101 @@ class FBstabDenseBatch(_SolverBase):
         display returned as records (fbstab_hip_dense_solve_traced)."""
         return _solve_traced(self, _DenseBatch(), DENSE_ARR, self.arr_len, data,
                              (self.nz, self.nl, self.nv, self.nv), z, l, v, y, capacity)
+
+
+class ShardGroup:
+    """fbstab_hip_shard_group_*: the GPUs of one node driven by ONE process; shard d of a
+    batch lives on ``devices[d]`` and is solved by ``solvers[d]`` (a solver created on
+    that device); the results are gathered to ``devices[root]`` in one RCCL operation
+    (fbstab_hip_*_solve_batch_sharded).  Arrays are torch CUDA tensors."""
+
+    def __init__(self, devices: Sequence[int]):
+        self._lib = load_library()
+        self._g = C.c_void_p()
+        self.devices = list(devices)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        _check(self._lib, self._lib.fbstab_hip_shard_group_create(len(self.devices), arr, C.byref(self._g)))
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self._lib.fbstab_hip_shard_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self) -> Dict[str, int]:
+        a, b = C.c_longlong(), C.c_longlong()
+        _check(self._lib, self._lib.fbstab_hip_shard_group_stats(self._g, C.byref(a), C.byref(b)))
+        return dict(gathers=a.value, rccl_ops=b.value)
+
+    def _shards(self, solvers, names, lens, data, xs, outs):
+        n = len(self.devices)
+        assert len(solvers) == len(data) == len(xs) == len(outs) == n
+        kind = solvers[0]._kind
+        bs = ((_MpcBatch if kind == "mpc" else _DenseBatch) * n)()
+        vs = (_VarBatch * n)()
+        counts = (C.c_int * n)()
+        hs = (C.c_void_p * n)(*[s._h.value for s in solvers])
+        op = (C.c_void_p * n)()
+        var_lens = (solvers[0].nz, solvers[0].nl, solvers[0].nv, solvers[0].nv)
+        for d in range(n):
+            B = None
+            for i, (k, ln) in enumerate(zip(names, lens)):
+                if ln == 0:
+                    bs[d].base[i], bs[d].stride[i] = None, 0
+                    continue
+                p, st, dev = _ptr_stride(data[d][k], ln)
+                assert dev
+                bs[d].base[i], bs[d].stride[i] = p, st
+                B = data[d][k].shape[0] if B is None else B
+            _fill_var(vs[d], xs[d], var_lens)
+            counts[d] = B
+            op[d] = outs[d].data_ptr()
+        return kind, bs, vs, counts, hs, op, var_lens
+
+    def Solve(self, solvers, data, xs, outs, root: int, root_x, root_out):
+        """``data[d]``: dict of shard d's arrays, ``xs[d] = (z, l, v, y)``, ``outs[d]``: ``(B_d, 40)``
+        uint8, all on ``devices[d]``; ``root_x = (z, l, v, y)`` and ``root_out`` hold the whole batch
+        on ``devices[root]``."""
+        names, lens = (MPC_SEQ, solvers[0].seq_len) if solvers[0]._kind == "mpc" else (DENSE_ARR, solvers[0].arr_len)
+        kind, bs, vs, counts, hs, op, var_lens = self._shards(solvers, names, lens, data, xs, outs)
+        rv = _VarBatch()
+        _fill_var(rv, root_x, var_lens)
+        _check(self._lib, getattr(self._lib, f"fbstab_hip_{kind}_solve_batch_sharded")(
+            self._g, hs, counts, bs, vs, op, root, C.byref(rv), C.c_void_p(root_out.data_ptr())))
+
+    def RecedingSweep(self, solvers, data, xs, outs, A, B, steps: int, retire: bool, u_logs, root: int, root_u_log):
+        """fbstab_hip_mpc_receding_sweep_sharded; ``A``/``B``: one plant (numpy) for all trajectories;
+        ``u_logs[d]``: ``(steps, B_d, nu)`` on devices[d]; ``root_u_log``: the shards' logs one after the
+        other on devices[root].  Returns the per-step statistics summed over the shards."""
+        import torch
+        kind, bs, vs, counts, hs, op, _ = self._shards(solvers, MPC_SEQ, solvers[0].seq_len, data, xs, outs)
+        n = len(self.devices)
+        plants = (_Plant * n)()
+        keep = []
+        for d in range(n):
+            dev = xs[d][0].device
+            Ad = torch.from_numpy(np.asfortranarray(np.asarray(A, dtype=np.float64)).T.copy().reshape(-1)).to(dev)
+            Bd = torch.from_numpy(np.asfortranarray(np.asarray(B, dtype=np.float64)).T.copy().reshape(-1)).to(dev)
+            keep += [Ad, Bd]
+            plants[d] = _Plant(Ad.data_ptr(), Bd.data_ptr(), 0, 0)
+        ul = (C.c_void_p * n)(*[u.data_ptr() for u in u_logs])
+        stats = np.zeros((steps, 4), dtype=np.uint64)
+        _check(self._lib, self._lib.fbstab_hip_mpc_receding_sweep_sharded(
+            self._g, hs, counts, bs, vs, op, plants, steps, 1 if retire else 0, ul, root,
+            C.c_void_p(root_u_log.data_ptr()), stats.ctypes.data))
+        return stats
+
+
+def _fill_var(vb, x, var_lens):
+    for i, (a, n) in enumerate(zip(x, var_lens)):
+        if n == 0:
+            vb.base[i], vb.stride[i] = None, 0
+            continue
+        p, st, dev = _ptr_stride(a, n)
+        assert dev
+        vb.base[i], vb.stride[i] = p, st

@@ -9,6 +9,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../fbstab_hip.h"
 #include "dense_types.h"
@@ -278,6 +279,73 @@ class FBstabMpcBatch {
 
  private:
   fbstab_mpc_handle_t h_ = nullptr;
+};
+
+// The same batches over several GPUs of one node, from ONE host thread: a solver per
+// device, shard d = the next counts[d] QPs of the batch with its arrays resident on
+// devices[d]; the shards run side by side, solutions and SolverOut records are gathered
+// to devices[root] in one RCCL operation over xGMI (fbstab_hip_mpc_solve_batch_sharded).
+class FBstabMpcSharded {
+ public:
+  FBstabMpcSharded(const FBstabMpcSharded&) = delete;
+  void operator=(const FBstabMpcSharded&) = delete;
+  FBstabMpcSharded(int N, int nx, int nu, int nc, const std::vector<int>& devices, int max_batch_per_device) {
+    if (N < 1 || nx < 1 || nu < 1 || nc < 1)
+      throw std::runtime_error("In FBstabMpc::FBstabMpc: problem sizes must be positive.");
+    if (fbstab_hip_shard_group_create(static_cast<int>(devices.size()), devices.data(), &g_) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpcSharded: ") + fbstab_hip_last_error());
+    h_.assign(devices.size(), nullptr);
+    for (size_t d = 0; d < devices.size(); d++)
+      if (fbstab_hip_mpc_create(N, nx, nu, nc, max_batch_per_device, devices[d], &h_[d]) != FBSTAB_HIP_OK) {
+        const std::string why = fbstab_hip_last_error();
+        Release();
+        throw std::runtime_error("In FBstabMpcSharded: " + why);
+      }
+  }
+  ~FBstabMpcSharded() { Release(); }
+  int devices() const { return static_cast<int>(h_.size()); }
+  void UpdateOptions(const FBstabMpc::Options& options) {
+    FBstabMpc::Options o = options;
+    o.ValidateOptions();
+    fbstab_options_t c = o.ToC();
+    for (fbstab_mpc_handle_t h : h_) fbstab_hip_mpc_set_options(h, &c);
+  }
+  // counts, data, x, out: one entry per device (device memory of that device);
+  // root_x / root_out: the whole batch on devices[root]
+  void Solve(const std::vector<int>& counts, const std::vector<fbstab_mpc_batch_t>& data,
+             const std::vector<fbstab_var_batch_t>& x, const std::vector<fbstab_solver_out_t*>& out, int root,
+             const fbstab_var_batch_t& root_x, fbstab_solver_out_t* root_out) {
+    if (counts.size() != h_.size() || data.size() != h_.size() || x.size() != h_.size() || out.size() != h_.size())
+      throw std::runtime_error("In FBstabMpcSharded::Solve: one entry per device is required.");
+    if (fbstab_hip_mpc_solve_batch_sharded(g_, h_.data(), counts.data(), data.data(), x.data(), out.data(), root,
+                                           &root_x, root_out) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpcSharded::Solve: ") + fbstab_hip_last_error());
+  }
+  // BASELINE configs[4]: every device sweeps its trajectories, the applied inputs are
+  // gathered once at the end (fbstab_hip_mpc_receding_sweep_sharded)
+  void RecedingSweep(const std::vector<int>& counts, const std::vector<fbstab_mpc_batch_t>& data,
+                     const std::vector<fbstab_var_batch_t>& x, const std::vector<fbstab_solver_out_t*>& out,
+                     const std::vector<fbstab_receding_plant_t>& plants, int steps, bool retire,
+                     const std::vector<double*>& u_log, int root, double* root_u_log,
+                     unsigned long long* stats = nullptr) {
+    if (counts.size() != h_.size() || data.size() != h_.size() || x.size() != h_.size() || out.size() != h_.size() ||
+        plants.size() != h_.size() || u_log.size() != h_.size())
+      throw std::runtime_error("In FBstabMpcSharded::RecedingSweep: one entry per device is required.");
+    if (fbstab_hip_mpc_receding_sweep_sharded(g_, h_.data(), counts.data(), data.data(), x.data(), out.data(),
+                                              plants.data(), steps, retire ? 1 : 0, u_log.data(), root, root_u_log,
+                                              stats) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabMpcSharded::RecedingSweep: ") + fbstab_hip_last_error());
+  }
+
+ private:
+  void Release() {
+    for (fbstab_mpc_handle_t h : h_) fbstab_hip_mpc_destroy(h);
+    h_.clear();
+    fbstab_hip_shard_group_destroy(g_);
+    g_ = nullptr;
+  }
+  fbstab_shard_group_t g_ = nullptr;
+  std::vector<fbstab_mpc_handle_t> h_;
 };
 
 }  // namespace fbstab

@@ -224,6 +224,38 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t handle, const fbstab_mpc_bat
 /* Diagnostic builds only (-DFB_STAMP): in-kernel per-phase cycle counters. */
 int fbstab_hip_debug_stamps(unsigned long long* out32, int reset);
 
+/* ---- several GPUs of one node, one process --------------------------------
+ * The path shards embarrassingly: QP q of a batch depends on nothing but its own data
+ * (FBstabMpc::Solve is a pure function of qp and the guess, fbstab/fbstab_mpc.h:181-195).
+ * A shard group names the devices; handles[d] is a solver created on devices[d]; shard d
+ * is the contiguous block of counts[d] QPs behind the shards 0 .. d-1, its arrays
+ * (data[d], x[d], out[d]) resident on device d.  The shards run side by side without
+ * any exchange, then the solutions (z, l, v, y) and SolverOut records of all shards go to
+ * root_x / root_out on devices[root] in ONE RCCL operation (grouped ncclSend / ncclRecv
+ * over xGMI; the root's own shard is a device copy).  The solution arrays are packed
+ * (stride = length) or column slices of one record per QP, with the same layout on the
+ * root.  Synchronous.  No counterpart in the reference, which is single-threaded. */
+typedef struct fbstab_shard_group* fbstab_shard_group_t;
+int fbstab_hip_shard_group_create(int ndev, const int* devices, fbstab_shard_group_t* group);
+int fbstab_hip_shard_group_destroy(fbstab_shard_group_t group);
+/* collectives issued so far and send/recv pairs inside them (tests, diagnostics) */
+int fbstab_hip_shard_group_stats(fbstab_shard_group_t group, long long* gathers, long long* rccl_ops);
+int fbstab_hip_mpc_solve_batch_sharded(fbstab_shard_group_t group, const fbstab_mpc_handle_t* handles,
+                                       const int* counts, const fbstab_mpc_batch_t* data,
+                                       const fbstab_var_batch_t* x, fbstab_solver_out_t* const* out,
+                                       int root, const fbstab_var_batch_t* root_x,
+                                       fbstab_solver_out_t* root_out);
+/* BASELINE configs[4] sharded by trajectory: fbstab_hip_mpc_receding_sweep on every
+ * device at once, then ONE collective that brings the applied inputs to the root:
+ * shard d's [steps][counts[d]][nu] log at root_u_log + steps * nu * (counts[0] + ... +
+ * counts[d-1]).  stats (host, may be NULL): per step, summed over the shards. */
+int fbstab_hip_mpc_receding_sweep_sharded(fbstab_shard_group_t group, const fbstab_mpc_handle_t* handles,
+                                          const int* counts, const fbstab_mpc_batch_t* data,
+                                          const fbstab_var_batch_t* x, fbstab_solver_out_t* const* out,
+                                          const fbstab_receding_plant_t* plants, int steps, int retire,
+                                          double* const* u_log, int root, double* root_u_log,
+                                          unsigned long long* stats);
+
 /* ---- dense -------------------------------------------------------------- */
 int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
                             fbstab_dense_handle_t* handle);
@@ -241,6 +273,12 @@ int fbstab_hip_dense_solve_batch_final(fbstab_dense_handle_t handle, int batch,
 int fbstab_hip_dense_solve_traced(fbstab_dense_handle_t handle, const fbstab_dense_batch_t* data,
                                   const fbstab_var_batch_t* x, fbstab_solver_out_t* out,
                                   fbstab_trace_record_t* trace, int capacity, int* count);
+/* As fbstab_hip_mpc_solve_batch_sharded (FBstabDense::Solve, fbstab/fbstab_dense.h:136-149). */
+int fbstab_hip_dense_solve_batch_sharded(fbstab_shard_group_t group, const fbstab_dense_handle_t* handles,
+                                         const int* counts, const fbstab_dense_batch_t* data,
+                                         const fbstab_var_batch_t* x, fbstab_solver_out_t* const* out,
+                                         int root, const fbstab_var_batch_t* root_x,
+                                         fbstab_solver_out_t* root_out);
 /* As fbstab_hip_mpc_debug_newton, for the dense path (DenseCholeskySolver::Initialize +
  * Solve, dense_cholesky_solver.cc:32-127).  io: [zbar, lbar, vbar] in,
  * [dz, dl, dv, A*dz, W_z, W_l, r_z, r_l, ok] out. */

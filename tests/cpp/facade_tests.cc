@@ -8,6 +8,7 @@
 // (absent from the image): a failed expectation prints and counts.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -385,6 +386,53 @@ static void DeviceResidentRefs() {
   EXPECT_THROW(solver.Solve(ref, &x));
 }
 
+// FBstabMpcSharded with a group of ONE device (what a test box has): the shard's
+// solution is gathered into separate root buffers and equals the host-memory solve.
+static void ShardedOnOneDevice() {
+  Ocp ocp;
+  ocp.DoubleIntegrator(20);
+  const FBstabMpc::ProblemData& d = ocp.data;
+  DeviceArray Q(d.Q.data(), d.Q.size()), R(d.R.data(), d.R.size()), S(d.S.data(), d.S.size()),
+      q(d.q.data(), d.q.size()), r(d.r.data(), d.r.size()), A(d.A.data(), d.A.size()), B(d.B.data(), d.B.size()),
+      c(d.c.data(), d.c.size()), E(d.E.data(), d.E.size()), L(d.L.data(), d.L.size()), dd(d.d.data(), d.d.size()),
+      x0(d.x0.data(), d.x0.size());
+  const int N = ocp.N, nx = ocp.nx, nu = ocp.nu, nc = ocp.nc;
+  const int nz = (N + 1) * (nx + nu), nl = (N + 1) * nx, nv = (N + 1) * nc;
+  DeviceArray z(std::vector<double>(nz, 0.0)), l(std::vector<double>(nl, 0.0)), v(std::vector<double>(nv, 0.0)),
+      y(std::vector<double>(nv, 0.0));
+  DeviceArray rz(std::vector<double>(nz, 9.0)), rl(std::vector<double>(nl, 9.0)), rv(std::vector<double>(nv, 9.0)),
+      ry(std::vector<double>(nv, 9.0));
+  DeviceArray outs(std::vector<double>(5, 0.0)), routs(std::vector<double>(5, 0.0));  // 40-byte records
+  fbstab_mpc_batch_t b;
+  const DeviceArray* arr[FBSTAB_MPC_NSEQ] = {&Q, &R, &S, &q, &r, &A, &B, &c, &E, &L, &dd, &x0};
+  for (int i = 0; i < FBSTAB_MPC_NSEQ; i++) { b.base[i] = arr[i]->p; b.stride[i] = static_cast<long long>(arr[i]->n); }
+  fbstab_var_batch_t xv, rxv;
+  double* xp[4] = {z.p, l.p, v.p, y.p};
+  double* rp[4] = {rz.p, rl.p, rv.p, ry.p};
+  const long long len[4] = {nz, nl, nv, nv};
+  for (int i = 0; i < 4; i++) { xv.base[i] = xp[i]; xv.stride[i] = len[i]; rxv.base[i] = rp[i]; rxv.stride[i] = len[i]; }
+  FBstabMpcSharded solver(N, nx, nu, nc, std::vector<int>(1, 0), 1);
+  EXPECT_TRUE(solver.devices() == 1);
+  solver.UpdateOptions(MpcOpts());
+  solver.Solve(std::vector<int>(1, 1), std::vector<fbstab_mpc_batch_t>(1, b), std::vector<fbstab_var_batch_t>(1, xv),
+               std::vector<fbstab_solver_out_t*>(1, reinterpret_cast<fbstab_solver_out_t*>(outs.p)), 0, rxv,
+               reinterpret_cast<fbstab_solver_out_t*>(routs.p));
+  FBstabMpc::Variable xh(N, nx, nu, nc);
+  FBstabMpc host_solver(N, nx, nu, nc);
+  host_solver.UpdateOptions(MpcOpts());
+  SolverOut oh = host_solver.Solve(ocp.data, &xh);
+  const std::vector<double> zr = rz.host(), vr = rv.host(), orec = routs.host();
+  for (int i = 0; i < nz; i++) EXPECT_TRUE(zr[i] == xh.z(i));
+  for (int i = 0; i < nv; i++) EXPECT_TRUE(vr[i] == xh.v(i));
+  fbstab_solver_out_t o;
+  std::memcpy(&o, orec.data(), sizeof(o));
+  EXPECT_TRUE(o.eflag == FBSTAB_SUCCESS && o.newton_iters == oh.newton_iters && o.prox_iters == oh.prox_iters);
+  EXPECT_THROW(solver.Solve(std::vector<int>(2, 1), std::vector<fbstab_mpc_batch_t>(1, b),
+                            std::vector<fbstab_var_batch_t>(1, xv),
+                            std::vector<fbstab_solver_out_t*>(1, reinterpret_cast<fbstab_solver_out_t*>(outs.p)), 0, rxv,
+                            reinterpret_cast<fbstab_solver_out_t*>(routs.p)));
+}
+
 static void ErrorBehaviour() {
   EXPECT_THROW(FBstabMpc(0, 2, 1, 6));     // fbstab_mpc.cc:62-65
   EXPECT_THROW(FBstabDense(2, -1, 2));     // fbstab_dense.cc:19-23
@@ -472,6 +520,7 @@ int main(int argc, char** argv) {
   LongHorizonRefAndServo();
   MapTypedRefsAndVector4();
   DeviceResidentRefs();
+  ShardedOnOneDevice();
   ErrorBehaviour();
   printf(g_fail ? "%d FAILED\n" : "ALL FACADE TESTS PASSED\n", g_fail);
   return g_fail ? 1 : 0;

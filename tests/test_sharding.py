@@ -141,3 +141,91 @@ def test_sharded_receding_sweep_equals_single_process():
     assert U.shape == (steps, world * per_rank, 4)
     assert np.array_equal(U, want)
     assert np.abs(want).max() > 0.1
+
+
+# ---- the C-ABI's own multi-GPU entry (include/fbstab_hip.h: fbstab_hip_*_sharded) --------
+def test_shard_group_argument_checks_without_gpu():
+    """No GPU here: the group cannot be created (no CPU path), bad arguments are rejected
+    before anything touches a device."""
+    import ctypes as C
+    from fbstab_amd import hip_api
+    lib = hip_api.load_library()
+    g = C.c_void_p()
+    one = (C.c_int * 1)(0)
+    assert lib.fbstab_hip_shard_group_create(0, one, C.byref(g)) == 1 and not g.value
+    assert lib.fbstab_hip_shard_group_create(1, None, C.byref(g)) == 1
+    if lib.fbstab_hip_device_count() == 0:
+        assert lib.fbstab_hip_shard_group_create(1, one, C.byref(g)) == 2
+        assert b"no HIP device" in lib.fbstab_hip_last_error()
+    assert lib.fbstab_hip_shard_group_destroy(None) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("self_send", ["0", "1"])
+def test_sharded_entries_on_one_device_equal_the_plain_calls(monkeypatch, self_send):
+    """fbstab_hip_mpc_solve_batch_sharded / _dense_ / _receding_sweep_sharded with a
+    group of ONE device (all the hardware a test box has): solutions, SolverOut records
+    and the input log on the root equal those of the plain calls bit for bit, one
+    collective per call.  With FBSTAB_HIP_SHARD_SELF_SEND=1 the root's own shard
+    travels through grouped ncclSend / ncclRecv as a peer's would (RCCL loaded with
+    dlopen, a one-rank communicator): the rehearsal of the xGMI path."""
+    import torch
+    from fbstab_amd import hip_api
+    from tools import fixtures as fx
+    monkeypatch.setenv("FBSTAB_HIP_SHARD_SELF_SEND", self_send)
+    dev = torch.device("cuda:0")
+    up = lambda p: {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    g = hip_api.ShardGroup([0])
+    B = 64
+    for kind, p in (("mpc", fx.synthetic_mpc_batch(B, first_id=900)), ("dense", fx.synthetic_dense_batch(B, 50, 10, 100))):
+        mk = (lambda: hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B)) if kind == "mpc" else \
+            (lambda: hip_api.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=B))
+        s = mk()
+        data = up(p)
+        z = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+        ref = (z(p.nz), z(p.nl), z(p.nv), z(p.nv))
+        out_ref = hip_api.out_to_numpy(s.Solve(data, *ref))
+        # packed arrays: z, l, v, y and the records travel as five pieces
+        x = (z(p.nz), z(p.nl), z(p.nv), z(p.nv))
+        root = (z(p.nz) + 7, z(p.nl) + 7, z(p.nv) + 7, z(p.nv) + 7)
+        out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
+        root_out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
+        before = g.stats()
+        g.Solve([s], [data], [x], [out], 0, root, root_out)
+        after = g.stats()
+        assert after["gathers"] == before["gathers"] + 1
+        assert after["rccl_ops"] - before["rccl_ops"] == (5 if self_send == "1" else 0)
+        for a, b in zip(root, ref):
+            assert torch.equal(a, b)
+        o = hip_api.out_to_numpy(root_out)
+        for f in ("eflag", "residual", "newton_iters", "prox_iters", "initial_residual"):
+            assert np.array_equal(o[f], out_ref[f]), f
+        # one record per QP (the bench's layout): ONE piece for the solution
+        nvar = p.nz + p.nl + 2 * p.nv
+        cut = lambda r: (r[:, :p.nz], r[:, p.nz:p.nz + p.nl], r[:, p.nz + p.nl:p.nz + p.nl + p.nv], r[:, p.nz + p.nl + p.nv:nvar])
+        rec, rroot = z(nvar + 5), z(nvar + 5) + 3
+        before = g.stats()
+        g.Solve([s], [data], [cut(rec)], [out], 0, cut(rroot), root_out)
+        assert g.stats()["rccl_ops"] - before["rccl_ops"] == (2 if self_send == "1" else 0)
+        for a, b in zip(cut(rroot), ref):
+            assert torch.equal(a, b)
+        s.close()
+    # configs[4]: the sweep, the applied inputs gathered once at the end
+    T, steps = 32, 6
+    p = fx.synthetic_mpc_batch(T, first_id=40)
+    A, Bm = fx.quadrotor_model()
+    z = lambda n: torch.zeros((T, n), dtype=torch.float64, device=dev)
+    s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=T)
+    r = s.RecedingSweep(up(p), z(p.nz), z(p.nl), z(p.nv), z(p.nv), A, Bm, steps, retire=True, log_inputs=True)
+    s.close()
+    s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=T)
+    u = torch.zeros((steps, T, p.nu), dtype=torch.float64, device=dev)
+    ru = torch.full((steps, T, p.nu), 5.0, dtype=torch.float64, device=dev)
+    out = torch.zeros((T, 40), dtype=torch.uint8, device=dev)
+    before = g.stats()
+    st = g.RecedingSweep([s], [up(p)], [(z(p.nz), z(p.nl), z(p.nv), z(p.nv))], [out], A, Bm, steps, True, [u], 0, ru)
+    assert g.stats()["gathers"] == before["gathers"] + 1
+    assert torch.equal(ru, r["u"]) and torch.equal(u, r["u"])
+    assert np.array_equal(st[:, 0].astype(np.int64), r["stats"]["newton_sum"])
+    s.close()
+    g.close()
