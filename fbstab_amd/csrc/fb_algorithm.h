@@ -483,6 +483,7 @@ struct Solver : TraceState<TRACE> {
           out = out_base + q;
           combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
           p.load_guess(c);
+          p.choose_costate_form(sigma);
           dx_norm = sqrt((double)p.num_primal_dual());
           open_prox(sigma, &Ek, &Ei0);
           E0 = Ek;

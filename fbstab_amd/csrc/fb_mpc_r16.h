@@ -125,8 +125,8 @@ struct MpcR16 {
   static constexpr int pABc = pABr + NSP;              // column r of [A B], NX slots
   static constexpr int kPackSlots = (pABc + NX + 1) & ~1;
   static constexpr int kPack = LPQ * kPackSlots;
-  // poff[N+1] ints and the flag word
-  static constexpr long hdr_doubles(int N) { return ((N + 1) / 2 + 16) & ~15L; }
+  // poff[N+1] ints, the flag word and the two scale words of the costate form (below)
+  static constexpr long hdr_doubles(int N) { return ((N + 5) / 2 + 15) & ~15L; }
   static constexpr long ws_doubles(int N) { return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1); }
 
   static constexpr int off(int slot) { return (slot >> 1) * 2 * LPQ + (slot & 1); }
@@ -322,6 +322,26 @@ struct MpcR16 {
   // the forward sweep adds it as such.  The skipped products are exact zeros, so
   // the result equals the general path bit for bit.  Detected while packing.
   bool bounds = false;
+  // The costate step dl(i) of the backward sweep, two forms of the same quantity:
+  //   (a) dl(i) = -inv(Pi_i)(theta_i + dx_i), the reference's (riccati_linear_solver.cc:321-325);
+  //   (b) dl(i) from the state rows of the Newton system's first block row
+  //       (abstract_components.h:276-288),
+  //         dl(i) = [(H + sigma I) dz(i)]_x + [A B]'dl(i+1) + [A'dv(i)]_x + rz_x + sigma (z - zbar)_x,
+  //       which the pair (dz, dl) of (a) satisfies identically.
+  // (b) needs neither inv(Pi) nor theta in the backward sweep: they stay out of the record
+  // (6 slots written and 6 read per stage and Newton step) and the sweeps lose the LDS image
+  // of inv(Pi) - 8 % more QP/s on the BASELINE workload.  Its rounding error is that of the
+  // sum's largest terms, eps |K| |dz| with |K| <= |H| + 1/sigma + |C'Gamma C| and
+  // Gamma <= 1/sigma, against eps |inv(Pi)| |theta + dx| <= eps |dz| / sigma for (a): the
+  // same class as long as |H| and the column sums of C'C stay within a small factor of
+  // 1/sigma and 1.  That is what `rowdl` records (choose_costate_form): bound constraints
+  // with entries of order one - the usual MPC constraints - take (b), everything else (a);
+  // e.g. the reference's servo-motor problem (output constraint rows with entries 1280,
+  // |C'Gamma C| ~ 1e6 / sigma) keeps (a), where (b) was measured to shift an iteration
+  // count.  Both forms give the oracle's iteration counts on every test problem they
+  // serve.
+  bool rowdl = false;
+  float cmax2 = 0.f, hmax = 0.f;  // max_r sum_k C[k][r]^2 and max_r sum_c |H[r][c]| over the stages (load_guess)
   lds_ptr lds;
   const MpcBatchPtrs* data;  // kernel arguments (uniform)
   const VarBatchPtrs* var;
@@ -495,6 +515,7 @@ struct MpcR16 {
     int* const po = poff;
     const lds_iptr lp = lpo;
     bool single = true;  // no constraint row with two nonzeros seen so far (row-uniform)
+    double c2m = 0.0, hm = 0.0;  // this lane's largest sum_k C[k][r]^2 and sum_c |H[r][c]| so far
     int canon = 0;  // offset of the copy the previous stage uses (row-uniform)
     double lastKr[NSP], lastABr[NSP], lastCc[NC], lastABc[NX];  // that copy's values, this lane's share
     sfor<0, NSP>([&](auto Cc_) { lastKr[decltype(Cc_)::value] = lastABr[decltype(Cc_)::value] = 0.0; });
@@ -550,10 +571,15 @@ struct MpcR16 {
         }
         {
           const int rowsh = LPQ * ((threadIdx.x & 63) / LPQ);
+          double c2 = 0.0, hs = 0.0;
           sfor<0, NC>([&](auto Kk) {
             const unsigned long long m = __ballot(Cc[decltype(Kk)::value] != 0.0);
             single = single && __popc((unsigned)(m >> rowsh) & (unsigned)((1ull << LPQ) - 1ull)) <= 1;
+            c2 = fma(Cc[decltype(Kk)::value], Cc[decltype(Kk)::value], c2);
           });
+          sfor<0, NSP>([&](auto Cc_) { hs += fabs(Kr[decltype(Cc_)::value]); });
+          c2m = fmax(c2m, c2);
+          hm = fmax(hm, hs);
         }
         // A stage whose matrices equal (bitwise) those of the previous stage
         // shares its copy: nothing is written for it.
@@ -609,11 +635,26 @@ struct MpcR16 {
     {
       bool fresh_all = true;
       if constexpr (KEEP) fresh_all = !reuse;
-      if (fresh_all) po[N_ + 1] = single ? 1 : 0;  // (kept with the copies for FBSTAB_HIP_KEEP_MATRICES)
-      else single = po[N_ + 1] != 0;
+      if (fresh_all) {  // (kept with the copies for FBSTAB_HIP_KEEP_MATRICES)
+        cmax2 = (float)qp_reduce<RQ, OpMax16>(c2m);
+        hmax = (float)qp_reduce<RQ, OpMax16>(hm);
+        po[N_ + 1] = single ? 1 : 0;
+        po[N_ + 2] = __float_as_int(cmax2);
+        po[N_ + 3] = __float_as_int(hmax);
+      } else {
+        single = po[N_ + 1] != 0;
+        cmax2 = __int_as_float(po[N_ + 2]);
+        hmax = __int_as_float(po[N_ + 3]);
+      }
       bounds = single;
     }
     c.sync();
+  }
+
+  // Which form of the costate step this QP's backward sweeps take (see `rowdl`); called
+  // once per QP, after load_guess().
+  FB_DEV void choose_costate_form(double sigma) {
+    rowdl = bounds && cmax2 <= 4.f && (double)hmax * sigma <= 1.0;
   }
 
   // Natural residual blocks at x: rz = Hz + f + G'l + A'v, rl = h - Gz
@@ -1306,6 +1347,14 @@ struct MpcR16 {
                           double* trial_outer2) {
     FB_WAVE_COUNT(27);  // Newton steps executed by the wavefront (any row active)
     FB_WAVE_TIMER(20);
+    // (row-uniform; rows of a wavefront that disagree run one form after the other)
+    if (rowdl) return newton_step_t<true>(c, sigma, alpha, trial_inner2, trial_outer2);
+    return newton_step_t<false>(c, sigma, alpha, trial_inner2, trial_outer2);
+  }
+  // ROW: the costate step from the Newton system's row, form (b) above
+  template <bool ROW>
+  FB_DEV bool newton_step_t(const C& c, double sigma, double alpha, double* trial_inner2,
+                            double* trial_outer2) {
     // Locals only below: lambdas must not capture `this`.
     const int N_ = N;
     const int r = c.tid;
@@ -1417,7 +1466,7 @@ struct MpcR16 {
       // inv(Pi_i) joins the record as its lower triangle: rows to the linear image
       // in LDS, 16 consecutive elements per slot back
       const int tri_r = (ro * (ro + 1)) >> 1;
-      {
+      if constexpr (!ROW) {
         c.sync();  // the previous stage has read its images
         if constexpr (kAsmImages) {
           img_write_pinv(Tr + kPl + tri_r, ro, Pinv);
@@ -1537,7 +1586,7 @@ struct MpcR16 {
     double Xp[nXs + 1], Pp[nPs + 1];  // the packed factor record of the stage: triangle slots, then t / theta
     auto load_fac = [&](const double* R) {
       ldv<fX, nXs + 1>(R, Xp);
-      ldv<fP, nPs + 1>(R, Pp);
+      if constexpr (!ROW) ldv<fP, nPs + 1>(R, Pp);
     };
     BwdIn bin;
     pcur = po[N_];
@@ -1569,8 +1618,11 @@ struct MpcR16 {
       const int tri_r = (ro * (ro + 1)) >> 1;
       c.sync();
       sfor<0, nXs>([&](auto S_) { Tr[kXl + LPQ * decltype(S_)::value + r] = Xp[decltype(S_)::value]; });
-      sfor<0, nPs>([&](auto S_) { Tr[kPl + LPQ * decltype(S_)::value + r] = Pp[decltype(S_)::value]; });
-      const double tcur = Xp[nXs], thcur = Pp[nPs];
+      if constexpr (!ROW)
+        sfor<0, nPs>([&](auto S_) { Tr[kPl + LPQ * decltype(S_)::value + r] = Pp[decltype(S_)::value]; });
+      const double tcur = Xp[nXs];
+      [[maybe_unused]] double thcur = 0.0;
+      if constexpr (!ROW) thcur = Pp[nPs];
       FB_SB();
       load_fac(Rp);
       FB_SB();
@@ -1589,11 +1641,12 @@ struct MpcR16 {
         XC[j] = j >= ro ? vc : 0.0;
         XR[j] = j <= ro ? vr : 0.0;
       });
-      sfor<0, NX>([&](auto Cc) {
-        constexpr int cc = decltype(Cc)::value;
-        const double v = Tr[kPl + (cc <= ro ? tri_r + cc : tri(cc) + r)];
-        Pinv[cc] = rx ? v : 0.0;
-      });
+      if constexpr (!ROW)
+        sfor<0, NX>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          const double v = Tr[kPl + (cc <= ro ? tri_r + cc : tri(cc) + r)];
+          Pinv[cc] = rx ? v : 0.0;
+        });
       }
       FB_SB();
       // s = t - W' dl(i+1) = t - inv(Lc) u ;  [dx; du] = inv(Lc)' s
@@ -1607,14 +1660,17 @@ struct MpcR16 {
         img_read_xcol(Tr + kXl + ro, ro, XC);
       }
       const double dzu = bc_dot<0, NS, RQ>(XC, s);
-      // dl = -inv(Pi)(theta + dx)
-      const double tx = thcur + dzu;
-      if constexpr (kAsmImages) {
-        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
-        img_read_pinv(Tr + kPl + tri_r, Tr + kPl + ro, ro, Pinv);
+      // dl = -inv(Pi)(theta + dx), form (a); form (b) follows A'dv below
+      double dli = 0.0;
+      if constexpr (!ROW) {
+        const double tx = thcur + dzu;
+        if constexpr (kAsmImages) {
+          sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
+          img_read_pinv(Tr + kPl + tri_r, Tr + kPl + ro, ro, Pinv);
+        }
+        dli = -bc_dot<0, NX, RQ>(Pinv, tx);
+        if (!rx) dli = 0.0;
       }
-      double dli = -bc_dot<0, NX, RQ>(Pinv, tx);
-      if (!rx) dli = 0.0;
       FB_SB();
       double dzb[NS];  // [dx; du](i), every lane
       bc_all<NS, RQ>(dzu, dzb);
@@ -1641,16 +1697,22 @@ struct MpcR16 {
         st2(R, sDV + 2 * sl, d, valid ? a : 0.0);
         dvs[sl] = d;
       });
-      // ---- wz = H dz + G'dl + A'dv
+      // ---- wz = H dz + G'dl + A'dv; (G'dl)_x = [A B]'dl(i+1) - dl(i)
       double w;
       {
-        double p[4] = {dot4<NS>(Hr, dzb) + (u - dli), 0.0, 0.0, 0.0};
+        double p[4] = {dot4<NS>(Hr, dzb) + (ROW ? u : u - dli), 0.0, 0.0, 0.0};
         bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
                         [&](auto I, double t) {
                           constexpr int k = decltype(I)::value;
                           p[k & 3] = fma(Cc_[k], t, p[k & 3]);
                         });
         w = (p[0] + p[1]) + (p[2] + p[3]);
+        if constexpr (ROW) {
+          // form (b): the state rows of (H + sigma I) dz + G'dl + A'dv = -(rz + sigma (z - zbar))
+          const double rin = cu.zr[1] + sigma * (cu.zr[0] - cu.bb[0]);  // inner residual, z block
+          dli = rx ? (w + sigma * dzu) + rin : 0.0;
+          w -= dli;
+        }
       }
       double wlv = 0.0;  // wl(i + 1)
       if (i < N_) {

@@ -36,6 +36,7 @@ template <class P, class C>
 __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_options_t& opts, double* dbg) {
   p.load_guess(ctx);
   if constexpr (P::kOwnVectorOps) {
+    p.choose_costate_form(opts.sigma0);
     p.probe_set_xbar(ctx, dbg);
     p.residual(ctx);
     double a, b;
