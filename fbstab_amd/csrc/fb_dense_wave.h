@@ -10,10 +10,14 @@
 //     (dense_cholesky_solver.cc:52-69) lives in REGISTERS, lane t holding row t
 //     of the full symmetric matrix (64 doubles);
 //   * A' Gamma A is accumulated on the matrix cores (v_mfma_f64_16x16x4, the ten
-//     16x16 tiles of the lower triangle), operands read from a transposed copy
-//     of A in global scratch (At[j + k nz]: every operand load and every A'x
-//     product is coalesced); the tiles reach the row layout through a 64 x 16
-//     staging panel in LDS, one column block at a time;
+//     16x16 tiles of the lower triangle), operands read straight from the caller's
+//     column-major A: a lane takes FOUR consecutive rows of its column with one
+//     32-byte access (the four lanes that share a column cover one 128-byte line)
+//     and the four rows feed four k-steps - the contraction runs over the rows of A
+//     in a permuted order, which the sum does not care about - so that no transposed
+//     copy of A exists (40 KB per QP at 50/10/100: a third of the scratch a resident
+//     QP used to hold); the tiles reach the row layout through a 64 x 16 staging
+//     panel in LDS, one column block at a time;
 //   * the pivoted LDL' (Eigen::LDLT's rule: largest |diagonal| of what is left,
 //     the first maximum wins; dense_cholesky_solver.cc:70-79) eliminates in
 //     place without swapping anything: the pivot row goes to LDS once, every
@@ -58,9 +62,9 @@ struct DenseWaveLayout {
   // LDS carve (offsets in doubles)
   int o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz, o_rz, o_rl, o_wz, o_wl,
       o_gam, o_rvm, o_rowbuf, o_stage, lds_doubles;
-  // global scratch of one workgroup (doubles): A', the multipliers, H in accumulator
+  // global scratch of one workgroup (doubles): the multipliers, H in accumulator
   // layout (40 x 64) and G' (Gt[64 q + t] = G[q][t])
-  long o_at, o_lg, o_hd, o_gt, ws_doubles;
+  long o_lg, o_hd, o_gt, ws_doubles;
 
   __host__ __device__ void init(int nz_, int nl_, int nv_) {
     nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
@@ -74,8 +78,7 @@ struct DenseWaveLayout {
     o_rowbuf = s; s += 64;
     o_stage = s; s += 64 * kLd;
     lds_doubles = (s + 1) & ~1;
-    o_at = 0;
-    o_lg = ((long)nv * nz + 15) & ~15L;
+    o_lg = 0;
     o_hd = o_lg + 64 * 64;
     o_gt = o_hd + 40 * 64;
     ws_doubles = o_gt + 64 * (long)(nl > 0 ? nl : 1);
@@ -95,9 +98,9 @@ struct DenseWave {
   DenseWaveLayout lay;
   DenseData D;
   double *uz, *ul, *uv, *uy;
-  // global scratch: A' (At[j + k nz] = A[k][j]), the multipliers Lg[64 k + t], the lower
-  // triangle of H as the MFMA accumulators hold it (Hd[64 (4 tile + q) + lane]) and G'
-  double *At, *Lg, *Hd, *Gt;
+  // global scratch: the multipliers Lg[64 k + t], the lower triangle of H as the MFMA
+  // accumulators hold it (Hd[64 (4 tile + q) + lane]) and G'
+  double *Lg, *Hd, *Gt;
   int nz, nl, nv;
   lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
   lds_ptr gam, rvm, rowbuf, stage;
@@ -112,13 +115,12 @@ struct DenseWave {
     rz = lds + lay.o_rz; rl = lds + lay.o_rl; wz = lds + lay.o_wz; wl = lds + lay.o_wl;
     gam = lds + lay.o_gam; rvm = lds + lay.o_rvm;
     rowbuf = lds + lay.o_rowbuf; stage = lds + lay.o_stage;
-    At = ws + lay.o_at;
     Lg = ws + lay.o_lg;
     Hd = ws + lay.o_hd;
     Gt = ws + lay.o_gt;
   }
 
-  // The wavefront's own global stores (At, Lg) become visible to its other lanes:
+  // The wavefront's own global stores (Lg, Hd, Gt) become visible to its other lanes:
   // one L1 serves the whole CU and is written through, what is needed is that the
   // stores have left the wavefront (s_waitcnt vmcnt(0)).
   static FB_DEV void global_fence() {
@@ -165,7 +167,27 @@ struct DenseWave {
     return s;
   }
   FB_DEV double A_row_dot(int i, lds_ptr x) const { return row_dot(D.A, nv, nz, i, x); }   // (A x)_i
-  FB_DEV double A_col_dot(int j, lds_ptr x) const { return row_dot(At, nz, nv, j, x); }    // (A'x)_j
+  // (A'x)_j = sum_k A[k + j nv] x[k]: column j is contiguous, the lane walks it sixteen
+  // entries (one cache line) at a time.  Only the passes that run once per proximal
+  // iteration use it (residual, feasibility); the Newton step takes A'(rv/mu) from the
+  // matrix-core operands.
+  FB_DEV double A_col_dot(int j, lds_ptr x) const {
+    const double* p = D.A + (long)j * nv;
+    double s0 = 0.0, s1 = 0.0;
+    constexpr int U = 16;
+    for (int k = 0; k < nv; k += U) {
+      double a[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) a[u] = p[k + u < nv ? k + u : nv - 1];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const double w = k + u < nv ? x[k + u < nv ? k + u : nv - 1] : 0.0;
+        if (u & 1) s1 = fma(a[u], w, s1);
+        else s0 = fma(a[u], w, s0);
+      }
+    }
+    return s0 + s1;
+  }
 
   FB_DEV double forcing_norm(const C& c) const {  // dense_data.h:72-73
     double s[1] = {0.0};
@@ -178,25 +200,13 @@ struct DenseWave {
   FB_DEV int num_primal_dual() const { return nz + nl + nv; }
   FB_DEV double bvec(int i) const { return D.b[i]; }
 
-  // x <- caller's guess, the transposed copy of A, y = b - A z (impl:334-347,
-  // full_variable.cc:47-53)
+  // x <- caller's guess, y = b - A z (impl:334-347, full_variable.cc:47-53), H and G' in
+  // the layouts the Newton step reads them in
   FB_DEV void load_guess(const C& c) const {
     FB_WAVE_TIMER(9);
     for (int i = c.tid; i < nz; i += 64) z[i] = uz[i];
     for (int i = c.tid; i < nl; i += 64) l[i] = ul[i];
     for (int i = c.tid; i < nv; i += 64) v[i] = uv[i];
-    for (int k0 = 0; k0 < nv; k0 += 64) {  // (ten columns' loads in flight, then their stores)
-      const int k = k0 + c.tid;
-      const int kc = k < nv ? k : nv - 1;
-      for (int j0 = 0; j0 < nz; j0 += 10) {
-        double a[10];
-#pragma unroll
-        for (int u = 0; u < 10; u++) a[u] = D.A[kc + (long)(j0 + u < nz ? j0 + u : nz - 1) * nv];
-#pragma unroll
-        for (int u = 0; u < 10; u++)
-          if (k < nv && j0 + u < nz) At[(j0 + u) + (long)k * nz] = a[u];
-      }
-    }
     {
       // H as the accumulators of assemble() hold it: lane l, register q of tile (I, J)
       // <-> entry (16 I + l/16 + 4 q, 16 J + l%16), rows and columns past nz clamped
@@ -322,42 +332,88 @@ struct DenseWave {
         }
       }
     }
-    // A operand of tile row I: lane l holds A[k0 + l/16][16 I + l%16]; B operand of
-    // tile column J: the same entry of block column J times Gamma (rows past nv: 0).
-    // KU steps' operands are requested together.  The same operands give A' (rv/mu)
-    // of the right-hand side (dense_cholesky_solver.cc:98-100): lane (kq, ij) sums
-    // the rows k = kq mod 4 of column 16 I + ij, the four partial sums meet below.
+    // Sixteen rows of A per trip, four k-steps.  Lane (kq, ij) holds four rows of column
+    // 16 I + ij for every tile row I, and step q takes element q: A operand of tile row I =
+    // A[k][16 I + ij], B operand of tile column J = the same entry of block column J times
+    // Gamma_k.  Rows past nv re-read the last rows with weight zero.  The next trip's operands are
+    // requested before this trip's products.  The same operands give A'(rv/mu) of the
+    // right-hand side (dense_cholesky_solver.cc:98-100): lane (kq, ij) sums its rows of
+    // column 16 I + ij, the four partial sums meet below.
     FB_DW_LAP(0);
-    constexpr int KU = 5;
+    typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
     double part[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < nv; k0 += 4 * KU) {
-      double a[KU][4], g[KU], rm[KU];
+    const double* acol[4];
 #pragma unroll
-      for (int u = 0; u < KU; u++) {
-        const int kk = k0 + 4 * u + kq;
-        const int kc = kk < nv ? kk : nv - 1;
-        const double* row = At + (long)kc * nz;
+    for (int I = 0; I < 4; I++) acol[I] = D.A + (long)col[I] * nv;
+    struct Ops {
+      d4 a[4];
+      double g[4], rm[4];
+    };
+    auto load_ops = [&](int k0, Ops& o) {
+      // two row pairs per lane: rows k0 + 2 kq, + 1 (the four kq of a column cover 64
+      // contiguous bytes with one 16-byte access each) and the same pair eight rows on
+      typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+      if (nv >= 2) {
 #pragma unroll
-        for (int I = 0; I < 4; I++) a[u][I] = row[col[I]];
-        g[u] = kk < nv ? gam[kc] : 0.0;
-        rm[u] = kk < nv ? rvm[kc] : 0.0;
+        for (int h = 0; h < 2; h++) {
+          const int kb = k0 + 8 * h + 2 * kq;
+          int kc = kb, skip = 0;
+          if (kb + 2 > nv) { kc = nv - 2; skip = kb - kc; }  // past the end: the last pair, weight zero
+#pragma unroll
+          for (int I = 0; I < 4; I++) {
+            const dbl2 t2 = *reinterpret_cast<const d2u*>(acol[I] + kc);
+            o.a[I][2 * h] = t2[0];
+            o.a[I][2 * h + 1] = t2[1];
+          }
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const bool mine = q >= skip;
+            const double gq = gam[kc + q], rq = rvm[kc + q];
+            o.g[2 * h + q] = mine ? gq : 0.0;
+            o.rm[2 * h + q] = mine ? rq : 0.0;
+          }
+        }
+      } else {  // a single row in all: one trip, element by element
+        const int kb = k0 + 4 * kq;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int kk = q < nv ? q : nv - 1;
+#pragma unroll
+          for (int I = 0; I < 4; I++) o.a[I][q] = acol[I][kk];
+          const bool mine = kb == 0 && q < nv;
+          const double gq = gam[kk], rq = rvm[kk];
+          o.g[q] = mine ? gq : 0.0;
+          o.rm[q] = mine ? rq : 0.0;
+        }
       }
+    };
+    auto use_ops = [&](const Ops& o) {
 #pragma unroll
-      for (int u = 0; u < KU; u++) {
+      for (int q = 0; q < 4; q++) {
         double bb[4];
 #pragma unroll
         for (int I = 0; I < 4; I++) {
-          bb[I] = g[u] * a[u][I];
-          part[I] = fma(a[u][I], rm[u], part[I]);
+          bb[I] = o.g[q] * o.a[I][q];
+          part[I] = fma(o.a[I][q], o.rm[q], part[I]);
         }
 #pragma unroll
         for (int I = 0; I < 4; I++) {
           if (I < nt16) {
 #pragma unroll
             for (int J = 0; J <= I; J++)
-              acc[tile_of(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][I], bb[J], acc[tile_of(I, J)], 0, 0, 0);
+              acc[tile_of(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[I][q], bb[J], acc[tile_of(I, J)], 0, 0, 0);
           }
         }
+      }
+    };
+    {
+      Ops oa, ob;
+      load_ops(0, oa);
+      for (int k0 = 0; k0 < nv; k0 += 32) {
+        if (k0 + 16 < nv) load_ops(k0 + 16, ob);
+        use_ops(oa);
+        if (k0 + 32 < nv) load_ops(k0 + 32, oa);
+        if (k0 + 16 < nv) use_ops(ob);
       }
     }
     {
@@ -748,7 +804,7 @@ struct DenseWave {
     if (t < nz) {
       double gdl = 0.0;  // (G'dl)_t from the transposed copy
       for (int q = 0; q < nl; q++) gdl = fma(Gt[64 * q + t], dl[q], gdl);
-      wz[t] = hdz + gdl + row_dot<25>(At, nz, nv, t, dv);
+      wz[t] = hdz + gdl + A_col_dot(t, dv);
     } else if (t < n) {
       wl[t - nz] = -hdz;
     }
