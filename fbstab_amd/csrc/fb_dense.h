@@ -36,7 +36,7 @@ struct DenseLayout {
   int nz, nl, nv, nk;
   // LDS carve (offsets in doubles)
   int o_k, o_rhs, o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz,
-      o_rz, o_rl, o_wz, o_wl, o_gam, o_rvm, o_perm, o_red, lds_doubles;
+      o_rz, o_rl, o_wz, o_wl, o_gam, o_rvm, o_perm, o_red, o_slot, lds_doubles;
   // A (nv x nz) is constant over the whole solve and used by every phase:
   // when it fits it is kept in LDS with an odd leading dimension lda (column
   // walks by different lanes then hit different banks).  a_lds == 0: read A
@@ -45,6 +45,12 @@ struct DenseLayout {
   // k_global != 0: K lives in global scratch (k_doubles per workgroup), not at o_k
   int k_global;
   long k_doubles;
+  // v_global != 0 (with k_global): the iterate vectors do not fit the LDS either and live
+  // behind K in the workgroup's global scratch (v_doubles of them; the o_* offsets then
+  // count from there) - the LDS holds the reduction scratch alone.  The reference
+  // allocates on the heap for any size (fbstab_dense.cc:18-42).
+  int v_global;
+  long v_doubles;
   // wave != 0 (nz + nl <= 64, K in LDS): the factorisation and the substitutions run
   // on ONE wavefront with the matrix rows in registers (ldlt_rows) - the first
   // wavefront of the workgroup; the others wait at a barrier.  The K region then
@@ -57,20 +63,23 @@ struct DenseLayout {
 #endif
   void init(int nz_, int nl_, int nv_, int nthreads) {
     wave = nz_ + nl_ <= 64;
-    carve(nz_, nl_, nv_, nthreads, 0);
+    carve(nz_, nl_, nv_, nthreads, 0, 0);
     if ((long)lds_doubles * 8 > 160 * 1024 || k_doubles > (1L << 30)) {
       wave = 0;
-      carve(nz_, nl_, nv_, nthreads, 1);
+      carve(nz_, nl_, nv_, nthreads, 1, 0);
+      if ((long)lds_doubles * 8 > 160 * 1024) carve(nz_, nl_, nv_, nthreads, 1, 1);
     }
   }
 
 #if !defined(FB_HOSTSIM)
   __host__ __device__
 #endif
-  void carve(int nz_, int nl_, int nv_, int nthreads, int kg) {
+  void carve(int nz_, int nl_, int nv_, int nthreads, int kg, int vg) {
     nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
     k_doubles = (long)nk * nk;
     k_global = kg;
+    v_global = vg;
+    v_doubles = 0;
     long s = 0;
     o_k = 0;
     o_rowbuf = o_dpiv = o_ord = 0;
@@ -87,7 +96,12 @@ struct DenseLayout {
     o_rz = s; s += nz; o_rl = s; s += nl; o_wz = s; s += nz; o_wl = s; s += nl;
     o_gam = s; s += nv; o_rvm = s; s += nv;
     o_perm = s; s += (nk + 1) / 2 + 1;  // nk ints
+    if (v_global) {  // everything so far sits in global scratch; the LDS starts here
+      v_doubles = (s + 15) & ~15L;
+      s = 0;
+    }
     o_red = s; s += kMaxReduce * ((nthreads + 63) / 64);
+    o_slot = s; s += 2;  // (the queue's hand-out word of multi-wavefront workgroups)
     s = (s + 1) & ~1L;
     lda = nv | 1;
     o_a = s;
@@ -99,9 +113,12 @@ struct DenseLayout {
   }
 };
 
-template <class C, bool KGLOBAL = false>
+template <class C, bool KGLOBAL = false, bool VGLOBAL = false>
 struct DenseProblem {
   typedef typename std::conditional<KGLOBAL, double*, lds_ptr>::type kptr;
+  // the iterate vectors: LDS, or the workgroup's global scratch (DenseLayout::v_global)
+  typedef typename std::conditional<VGLOBAL, double*, lds_ptr>::type vptr;
+  typedef typename std::conditional<VGLOBAL, int*, FB_LDS int*>::type iptr;
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
   DenseLayout lay;
@@ -109,10 +126,11 @@ struct DenseProblem {
   double *uz, *ul, *uv, *uy;
   lds_ptr lds;
   int nz, nl, nv;
-  lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
-  lds_ptr gam, rvm, rhs, Al;
+  vptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
+  vptr gam, rvm, rhs;
+  lds_ptr Al;
   kptr K;
-  FB_LDS int* perm;
+  iptr perm;
 
   FB_DEV void bind(const DenseLayout& L_, const DenseData& D_, double* uz_, double* ul_,
                    double* uv_, double* uy_, lds_ptr lds_, double* k_scratch = nullptr) {
@@ -120,32 +138,35 @@ struct DenseProblem {
     nz = lay.nz; nl = lay.nl; nv = lay.nv;
     if constexpr (KGLOBAL) K = k_scratch;
     else K = lds + lay.o_k;
-    rhs = lds + lay.o_rhs;
-    z = lds + lay.o_z; l = lds + lay.o_l; v = lds + lay.o_v; y = lds + lay.o_y;
-    zb = lds + lay.o_zb; lb = lds + lay.o_lb; vb = lds + lay.o_vb; yb = lds + lay.o_yb;
-    dz = lds + lay.o_dz; dl = lds + lay.o_dl; dv = lds + lay.o_dv; adz = lds + lay.o_adz;
-    rz = lds + lay.o_rz; rl = lds + lay.o_rl; wz = lds + lay.o_wz; wl = lds + lay.o_wl;
-    gam = lds + lay.o_gam; rvm = lds + lay.o_rvm;
-    perm = (FB_LDS int*)(lds + lay.o_perm);
+    vptr vb_;  // base of the vector carve
+    if constexpr (VGLOBAL) vb_ = k_scratch + lay.k_doubles;
+    else vb_ = lds;
+    rhs = vb_ + lay.o_rhs;
+    z = vb_ + lay.o_z; l = vb_ + lay.o_l; v = vb_ + lay.o_v; y = vb_ + lay.o_y;
+    zb = vb_ + lay.o_zb; lb = vb_ + lay.o_lb; vb = vb_ + lay.o_vb; yb = vb_ + lay.o_yb;
+    dz = vb_ + lay.o_dz; dl = vb_ + lay.o_dl; dv = vb_ + lay.o_dv; adz = vb_ + lay.o_adz;
+    rz = vb_ + lay.o_rz; rl = vb_ + lay.o_rl; wz = vb_ + lay.o_wz; wl = vb_ + lay.o_wl;
+    gam = vb_ + lay.o_gam; rvm = vb_ + lay.o_rvm;
+    perm = (iptr)(vb_ + lay.o_perm);
     Al = lds + lay.o_a;
   }
 
   // dot of column j of a column-major m-row matrix with an LDS vector
-  FB_DEV double col_dot(const double* M, int m, int j, lds_ptr x) const {
+  FB_DEV double col_dot(const double* M, int m, int j, vptr x) const {
     const double* col = M + (long)j * m;
     double s = 0.0;
     for (int k = 0; k < m; k++) s += col[k] * x[k];
     return s;
   }
   // dot of row i of a column-major m x n matrix with an LDS vector
-  FB_DEV double row_dot(const double* M, int m, int n, int i, lds_ptr x) const {
+  FB_DEV double row_dot(const double* M, int m, int n, int i, vptr x) const {
     double s = 0.0;
     for (int k = 0; k < n; k++) s += M[i + (long)k * m] * x[k];
     return s;
   }
 
   // (A x)_i and (A' x)_j from the LDS copy of A when present
-  FB_DEV double A_row_dot(int i, lds_ptr x) const {
+  FB_DEV double A_row_dot(int i, vptr x) const {
     if (lay.a_lds) {
       double s = 0.0;
       for (int k = 0; k < nz; k++) s += Al[i + k * lay.lda] * x[k];
@@ -153,7 +174,7 @@ struct DenseProblem {
     }
     return row_dot(D.A, nv, nz, i, x);
   }
-  FB_DEV double A_col_dot(int j, lds_ptr x) const {
+  FB_DEV double A_col_dot(int j, vptr x) const {
     if (lay.a_lds) {
       lds_ptr col = Al + j * lay.lda;
       double s = 0.0;
@@ -717,7 +738,7 @@ struct DenseProblem {
         const int cj = 16 * J + ij < nz ? 16 * J + ij : nz - 1;
         lds_ptr ai = Al + ci * lay.lda + kq;
         lds_ptr aj = Al + cj * lay.lda + kq;
-        lds_ptr gk = gam + kq;
+        vptr gk = gam + kq;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < nv; k0 += 4)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[k0], gk[k0] * aj[k0], acc, 0, 0, 0);

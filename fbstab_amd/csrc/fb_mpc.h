@@ -27,6 +27,8 @@
 //   * dv = rv/mus + Gamma .* (A dz)  ==  (rv + gamma .* A dz) ./ mus.
 #pragma once
 
+#include <type_traits>
+
 #include "fb_common.h"
 
 namespace fbk {
@@ -50,6 +52,11 @@ struct MpcLayout {
   int w_sb, w_rb, w_linv, w_m, w_minv, w_am, w_sm, w_sg, w_sginv, w_pp, w_p, w_ln;
   int w_gam, w_rvm, w_r1, w_r2, w_th, w_thp, w_h, w_tx, w_tu, w_t1, w_t2, w_lp, w_out;
   int w_red, lds_doubles;
+  // wglobal != 0: the carve above does not fit the LDS and lives at v_carve of the
+  // workgroup's global scratch instead (MpcProblem<C, true>); launch_lds_doubles is what
+  // a launch asks for (the whole carve, or the reduction scratch alone)
+  int wglobal, launch_lds_doubles;
+  long v_carve;
 
 #if !defined(FB_HOSTSIM)
   __host__ __device__
@@ -96,24 +103,43 @@ struct MpcLayout {
     w_out = s; s += ns + nx + nc;
     w_red = s; s += kMaxReduce * ((nthreads + 63) / 64);
     lds_doubles = (s + 1) & ~1;
+    wglobal = (long)lds_doubles * 8 > 160 * 1024 ? 1 : 0;
+    launch_lds_doubles = lds_doubles;
+    v_carve = 0;
+    if (wglobal) {
+      v_carve = ws_doubles;
+      ws_doubles += (lds_doubles + 15) & ~15L;
+      launch_lds_doubles = (kMaxReduce * ((nthreads + 63) / 64) + ns + nx + nc + 17) & ~1;
+    }
   }
 };
 
-template <class C>
+// WGLOBAL: the stage tile and the work matrices of the Newton step - everything the
+// layout carves out of the LDS except the reduction scratch - live in the workgroup's
+// GLOBAL scratch instead: the instance for stages whose matrices do not fit the 160 KB
+// of LDS (the reference allocates on the heap for any size, fbstab_mpc.cc:61-89).  One
+// wavefront per QP either way: its global-memory operations stay in program order, so
+// the same synchronisation serves both.
+template <class C, bool WGLOBAL = false>
 struct MpcProblem {
+#if defined(FB_HOSTSIM)
+  typedef lds_ptr mptr;
+#else
+  typedef typename std::conditional<WGLOBAL, double*, lds_ptr>::type mptr;
+#endif
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
   MpcLayout lay;
   MpcData D;
   double *uz, *ul, *uv, *uy;  // caller's (z,l,v,y) for this QP
-  lds_ptr lds;
+  mptr lds;  // base of the stage tile / work-matrix carve (LDS, or global scratch: WGLOBAL)
   double* ws;  // this workgroup's global scratch
   int nz, nl, nv;
   double *z, *l, *v, *y, *zb, *lb, *vb, *yb, *dz, *dl, *dv, *adz, *rz, *rl, *wz, *wl;
   double *gam, *rvm, *fac;
 
   FB_DEV void bind(const MpcLayout& L_, const MpcData& D_, double* uz_, double* ul_,
-                   double* uv_, double* uy_, lds_ptr lds_, double* ws_) {
+                   double* uv_, double* uy_, mptr lds_, double* ws_) {
     lay = L_; D = D_; uz = uz_; ul = ul_; uv = uv_; uy = uy_; lds = lds_; ws = ws_;
     nz = lay.nz; nl = lay.nl; nv = lay.nv;
     z = ws + lay.v_z; l = ws + lay.v_l; v = ws + lay.v_v; y = ws + lay.v_y;
@@ -125,7 +151,7 @@ struct MpcProblem {
 
   // ---- small helpers -------------------------------------------------------
   template <class Src>
-  FB_DEV void copy_in(const C& c, lds_ptr dst, Src src, int n) const {
+  FB_DEV void copy_in(const C& c, mptr dst, Src src, int n) const {
     for (int i = c.tid; i < n; i += C::nt) dst[i] = src[i];
   }
 
@@ -157,18 +183,18 @@ struct MpcProblem {
   // (H zz)_i[r] from the tile (mpc_data.cc:28-63); r in [0, ns).
   FB_DEV double tile_Hz(int r) const {
     const int nx = lay.nx, nu = lay.nu;
-    lds_ptr zx = lds + lay.s_z;
-    lds_ptr zu = zx + nx;
+    mptr zx = lds + lay.s_z;
+    mptr zu = zx + nx;
     double s = 0.0;
     if (r < nx) {
-      lds_ptr Q = lds + lay.t_q;
-      lds_ptr S = lds + lay.t_s;
+      mptr Q = lds + lay.t_q;
+      mptr S = lds + lay.t_s;
       for (int k = 0; k < nx; k++) s += Q[r + k * nx] * zx[k];
       for (int k = 0; k < nu; k++) s += S[k + r * nu] * zu[k];
     } else {
       const int ru = r - nx;
-      lds_ptr S = lds + lay.t_s;
-      lds_ptr R = lds + lay.t_r;
+      mptr S = lds + lay.t_s;
+      mptr R = lds + lay.t_r;
       for (int k = 0; k < nx; k++) s += S[ru + k * nu] * zx[k];
       for (int k = 0; k < nu; k++) s += R[ru + k * nu] * zu[k];
     }
@@ -177,17 +203,17 @@ struct MpcProblem {
   // (G' ll)_i[r] (mpc_data.cc:171-198).
   FB_DEV double tile_GTl(int i, int r) const {
     const int nx = lay.nx;
-    lds_ptr li = lds + lay.s_l;
-    lds_ptr ln = lds + lay.s_ln;
+    mptr li = lds + lay.s_l;
+    mptr ln = lds + lay.s_ln;
     double s = 0.0;
     if (r < nx) {
       s = -li[r];
       if (i < lay.N) {
-        lds_ptr A = lds + lay.t_a;
+        mptr A = lds + lay.t_a;
         for (int k = 0; k < nx; k++) s += A[k + r * nx] * ln[k];
       }
     } else if (i < lay.N) {
-      lds_ptr B = lds + lay.t_b;
+      mptr B = lds + lay.t_b;
       const int ru = r - nx;
       for (int k = 0; k < nx; k++) s += B[k + ru * nx] * ln[k];
     }
@@ -196,13 +222,13 @@ struct MpcProblem {
   // (A' vv)_i[r] (mpc_data.cc:217-237).
   FB_DEV double tile_ATv(int r) const {
     const int nx = lay.nx, nc = lay.nc;
-    lds_ptr vi = lds + lay.s_v;
+    mptr vi = lds + lay.s_v;
     double s = 0.0;
     if (r < nx) {
-      lds_ptr E = lds + lay.t_e + r * nc;
+      mptr E = lds + lay.t_e + r * nc;
       for (int k = 0; k < nc; k++) s += E[k] * vi[k];
     } else {
-      lds_ptr L = lds + lay.t_l + (r - nx) * nc;
+      mptr L = lds + lay.t_l + (r - nx) * nc;
       for (int k = 0; k < nc; k++) s += L[k] * vi[k];
     }
     return s;
@@ -210,9 +236,9 @@ struct MpcProblem {
   // (A zz)_i[k] = E x + L u (mpc_data.cc:84-104).
   FB_DEV double tile_Az(int k) const {
     const int nx = lay.nx, nu = lay.nu, nc = lay.nc;
-    lds_ptr zx = lds + lay.s_z;
-    lds_ptr E = lds + lay.t_e;
-    lds_ptr L = lds + lay.t_l;
+    mptr zx = lds + lay.s_z;
+    mptr E = lds + lay.t_e;
+    mptr L = lds + lay.t_l;
     double s = 0.0;
     for (int j = 0; j < nx; j++) s += E[k + j * nc] * zx[j];
     for (int j = 0; j < nu; j++) s += L[k + j * nc] * zx[nx + j];
@@ -222,9 +248,9 @@ struct MpcProblem {
   // mpc_data.cc:127-152).
   FB_DEV double tile_ABz(int r) const {
     const int nx = lay.nx, nu = lay.nu;
-    lds_ptr zx = lds + lay.s_z;
-    lds_ptr A = lds + lay.t_a;
-    lds_ptr B = lds + lay.t_b;
+    mptr zx = lds + lay.s_z;
+    mptr A = lds + lay.t_a;
+    mptr B = lds + lay.t_b;
     double s = 0.0;
     for (int j = 0; j < nx; j++) s += A[r + j * nx] * zx[j];
     for (int j = 0; j < nu; j++) s += B[r + j * nx] * zx[nx + j];
@@ -346,7 +372,7 @@ struct MpcProblem {
   // ---- dense micro-kernels on LDS matrices (n <= 64 <= NT) -------------------
   // In-place lower Cholesky, one thread per row (left-looking: column j is
   // finished from the already final columns < j).  Workgroup-uniform result.
-  FB_DEV bool chol(const C& c, lds_ptr A, int n) const {
+  FB_DEV bool chol(const C& c, mptr A, int n) const {
     for (int j = 0; j < n; j++) {
       for (int r = j + c.tid; r < n; r += C::nt) {
         double t = A[r + j * n];
@@ -365,7 +391,7 @@ struct MpcProblem {
   }
   // X = inv(Lo) for lower-triangular Lo (column c by thread c); the strict
   // upper triangle of X is zeroed.  Caller syncs afterwards.
-  FB_DEV void tri_inv(const C& c, lds_ptr Lo, lds_ptr X, int n) const {
+  FB_DEV void tri_inv(const C& c, mptr Lo, mptr X, int n) const {
     for (int cc = c.tid; cc < n; cc += C::nt) {
       for (int r = 0; r < cc; r++) X[r + cc * n] = 0.0;
       X[cc + cc * n] = 1.0 / Lo[cc + cc * n];
@@ -384,19 +410,19 @@ struct MpcProblem {
   // (riccati_linear_solver.cc:131-136).
   FB_DEV bool newton_step(const C& c, double sigma, double alpha) const {
     const int N = lay.N, nx = lay.nx, nu = lay.nu, nc = lay.nc, ns = lay.ns;
-    lds_ptr tQ = lds + lay.t_q; lds_ptr tR = lds + lay.t_r; lds_ptr tS = lds + lay.t_s;
-    lds_ptr tA = lds + lay.t_a; lds_ptr tB = lds + lay.t_b; lds_ptr tE = lds + lay.t_e;
-    lds_ptr tL = lds + lay.t_l;
-    lds_ptr Sb = lds + lay.w_sb; lds_ptr Rb = lds + lay.w_rb;
-    lds_ptr Linv = lds + lay.w_linv; lds_ptr M = lds + lay.w_m; lds_ptr Minv = lds + lay.w_minv;
-    lds_ptr AM = lds + lay.w_am; lds_ptr SM = lds + lay.w_sm; lds_ptr SG = lds + lay.w_sg;
-    lds_ptr SGinv = lds + lay.w_sginv; lds_ptr PP = lds + lay.w_pp; lds_ptr P = lds + lay.w_p;
-    lds_ptr Ln = lds + lay.w_ln;
-    lds_ptr Gam = lds + lay.w_gam; lds_ptr Rvm = lds + lay.w_rvm;
-    lds_ptr r1 = lds + lay.w_r1; lds_ptr r2 = lds + lay.w_r2;
-    lds_ptr th = lds + lay.w_th; lds_ptr thp = lds + lay.w_thp; lds_ptr hh = lds + lay.w_h;
-    lds_ptr tx = lds + lay.w_tx; lds_ptr tu = lds + lay.w_tu;
-    lds_ptr t1 = lds + lay.w_t1; lds_ptr t2 = lds + lay.w_t2; lds_ptr lp = lds + lay.w_lp;
+    mptr tQ = lds + lay.t_q; mptr tR = lds + lay.t_r; mptr tS = lds + lay.t_s;
+    mptr tA = lds + lay.t_a; mptr tB = lds + lay.t_b; mptr tE = lds + lay.t_e;
+    mptr tL = lds + lay.t_l;
+    mptr Sb = lds + lay.w_sb; mptr Rb = lds + lay.w_rb;
+    mptr Linv = lds + lay.w_linv; mptr M = lds + lay.w_m; mptr Minv = lds + lay.w_minv;
+    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SG = lds + lay.w_sg;
+    mptr SGinv = lds + lay.w_sginv; mptr PP = lds + lay.w_pp; mptr P = lds + lay.w_p;
+    mptr Ln = lds + lay.w_ln;
+    mptr Gam = lds + lay.w_gam; mptr Rvm = lds + lay.w_rvm;
+    mptr r1 = lds + lay.w_r1; mptr r2 = lds + lay.w_r2;
+    mptr th = lds + lay.w_th; mptr thp = lds + lay.w_thp; mptr hh = lds + lay.w_h;
+    mptr tx = lds + lay.w_tx; mptr tu = lds + lay.w_tu;
+    mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2; mptr lp = lds + lay.w_lp;
 
     // Base case L(0) = sqrt(sigma) I  =>  inv(L(0)) = I / sqrt(sigma)
     // (riccati_linear_solver.cc:127).
@@ -460,7 +486,7 @@ struct MpcProblem {
             const int r = idx - nq - nr - nsx;
             const long g = (long)i * ns + r;
             double s = -(rz[g] + sigma * (z[g] - zb[g]));
-            lds_ptr col = r < nx ? tE + r * nc : tL + (r - nx) * nc;
+            mptr col = r < nx ? tE + r * nc : tL + (r - nx) * nc;
             for (int k = 0; k < nc; k++) s -= col[k] * Rvm[k];
             r1[r] = s;
           } else {

@@ -84,8 +84,9 @@ __device__ __forceinline__ MpcData mpc_data_of(const MpcBatchArgs& data, long q)
 #define FB_MPC_MIN_WAVES 1
 #endif
 // DBG: the Newton-step probe; TRACE: `dbg` is the trace buffer of
-// fbstab_hip_mpc_solve_traced (see Solver in fb_algorithm.h).
-template <int NT, bool DBG, bool TRACE = false>
+// fbstab_hip_mpc_solve_traced (see Solver in fb_algorithm.h); WG: the stage tile and the
+// work matrices in global scratch (MpcLayout::wglobal: shapes beyond the LDS).
+template <int NT, bool DBG, bool TRACE = false, bool WG = false>
 __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLayout lay, MpcBatchArgs data,
                                                         VarBatchArgs x,
                                                         fbstab_solver_out_t* out,
@@ -96,18 +97,21 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
   typedef Ctx<NT> C;
   C ctx;
   ctx.tid = threadIdx.x;
-  ctx.red = lds + lay.w_red;
+  ctx.red = WG ? lds : lds + lay.w_red;
   double* ws = scratch + (long)blockIdx.x * lay.ws_doubles;
   for (;;) {
-    const int q = next_qp<NT>(counter, lds + lay.w_out);
+    const int q = next_qp<NT>(counter, WG ? lds + kMaxReduce * ((NT + 63) / 64) : lds + lay.w_out);
     if (q >= batch) break;
-    MpcProblem<C> p;
+    MpcProblem<C, WG> p;
+    typename MpcProblem<C, WG>::mptr mb;
+    if constexpr (WG) mb = ws + lay.v_carve;
+    else mb = lds;
     p.bind(lay, mpc_data_of(data, q), x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
-           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ws);
+           x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], mb, ws);
     if constexpr (DBG) {
       newton_probe(p, ctx, opts, dbg);
     } else {
-      Solver<MpcProblem<C>, C, TRACE> solver(p, ctx, opts, dbg);
+      Solver<MpcProblem<C, WG>, C, TRACE> solver(p, ctx, opts, dbg);
       solver.solve(out + q);
     }
     ctx.sync();
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
 __global__ void fbstab_receding_plant_kernel(int batch, int nx, int nu, int nz, int nl, int nv, const double* A,
                                              long long sA, const double* B, long long sB, double* x0, long long sx0,
                                              VarBatchArgs x, const fbstab_solver_out_t* out, int* retired,
-                                             int retire, double* u_log, unsigned long long* stats) {
+                                             int retire, double* u_log, unsigned long long* stats, double* xtmp) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = q < batch;
   fbstab_solver_out_t o;
@@ -167,16 +171,18 @@ __global__ void fbstab_receding_plant_kernel(int batch, int nx, int nu, int nz, 
     }
   }
   if (!live) return;
-  double u[8], xn[64];
-  for (int j = 0; j < nu && j < 8; j++) u[j] = gone ? 0.0 : z[nx + j];
+  // (u0 = z[nx .. nx + nu) is read where it is used; the new state is collected in
+  // registers up to 64 states, in the caller's per-trajectory buffer beyond)
   if (u_log)
-    for (int j = 0; j < nu && j < 8; j++) u_log[(long long)q * nu + j] = u[j];
+    for (int j = 0; j < nu; j++) u_log[(long long)q * nu + j] = gone ? 0.0 : z[nx + j];
   const double* Aq = A + q * sA;
   const double* Bq = B + q * sB;
+  double xloc[64];
+  double* xn = nx <= 64 ? xloc : xtmp + (long long)q * nx;
   for (int r = 0; r < nx; r++) {
     double acc = 0.0;
     for (int c = 0; c < nx; c++) acc = fma(Aq[r + c * nx], xs[c], acc);
-    for (int j = 0; j < nu && j < 8; j++) acc = fma(Bq[r + j * nx], u[j], acc);
+    for (int j = 0; j < nu; j++) acc = fma(Bq[r + j * nx], gone ? 0.0 : z[nx + j], acc);
     xn[r] = gone ? 0.0 : acc;
   }
   for (int r = 0; r < nx; r++) xs[r] = xn[r];
@@ -194,7 +200,9 @@ struct KScratchArg<true> {
   __device__ double* get() const { return p; }
 };
 
-template <int NT, bool TRACE = false, bool KGLOBAL = false>
+// VGLOBAL (with KGLOBAL): the iterate vectors too live in the workgroup's global scratch
+// (DenseLayout::v_global: nv beyond what the LDS holds).
+template <int NT, bool TRACE = false, bool KGLOBAL = false, bool VGLOBAL = false>
 __global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_kernel(DenseLayout lay, DenseBatchArgs data,
                                                           VarBatchArgs x,
                                                           fbstab_solver_out_t* out,
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_kernel(Den
   ctx.tid = threadIdx.x;
   ctx.red = lds + lay.o_red;
   for (;;) {
-    const int q = next_qp<NT>(counter, lds + lay.o_rhs);
+    const int q = next_qp<NT>(counter, lds + lay.o_slot);
     if (q >= batch) break;
     DenseData D;
     D.H = data.base[FBSTAB_DENSE_H] + q * data.stride[FBSTAB_DENSE_H];
@@ -218,12 +226,12 @@ __global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_kernel(Den
     D.h = data.base[FBSTAB_DENSE_h] + q * data.stride[FBSTAB_DENSE_h];
     D.A = data.base[FBSTAB_DENSE_A] + q * data.stride[FBSTAB_DENSE_A];
     D.b = data.base[FBSTAB_DENSE_b] + q * data.stride[FBSTAB_DENSE_b];
-    DenseProblem<C, KGLOBAL> p;
+    DenseProblem<C, KGLOBAL, VGLOBAL> p;
     double* ks = nullptr;
-    if constexpr (KGLOBAL) ks = kscratch.get() + (long)blockIdx.x * lay.k_doubles;
+    if constexpr (KGLOBAL) ks = kscratch.get() + (long)blockIdx.x * (lay.k_doubles + lay.v_doubles);
     p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1],
            x.base[2] + q * x.stride[2], x.base[3] + q * x.stride[3], lds, ks);
-    Solver<DenseProblem<C, KGLOBAL>, C, TRACE> solver(p, ctx, opts, trace.get());
+    Solver<DenseProblem<C, KGLOBAL, VGLOBAL>, C, TRACE> solver(p, ctx, opts, trace.get());
     solver.solve(out + q);
     ctx.sync();
   }
@@ -581,7 +589,7 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   if (!s) return fail(FBSTAB_HIP_ERR_DEVICE, "out of host memory");
   s->threads = kMpcThreads;
   s->lay.init(N, nx, nu, nc, s->threads);
-  s->lds_bytes = s->lay.lds_doubles * (int)sizeof(double);
+  s->lds_bytes = s->lay.launch_lds_doubles * (int)sizeof(double);
   // FBSTAB_HIP_GENERIC=1 forces the flat-vector kernel (comparisons, tests)
   const char* force_generic = getenv("FBSTAB_HIP_GENERIC");
   if (!(force_generic && atoi(force_generic) > 0)) s->rec = record_instance_for(nx, nu, nc);
@@ -596,9 +604,9 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
     const char* pad = getenv("FBSTAB_HIP_LDS_PAD_BYTES");
     if (pad && atoi(pad) > 0) s->lds_bytes += atoi(pad) & ~15;
   }
-  if (nx > s->threads || s->lds_bytes > kLdsLimitBytes) {
+  if (s->lds_bytes > kLdsLimitBytes) {  // (not reached: the flat-vector layout moves to global scratch first)
     delete s;
-    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "stage matrices do not fit the 160 KiB LDS budget");
+    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "stage vectors do not fit the 160 KiB LDS budget");
   }
   int rc = s->common_init(device, max_batch);
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
@@ -610,8 +618,12 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
     if (s->exact) kerns = {r.solve_exact, r.solve_keep_exact, r.probe_exact};
     else kerns = {r.solve, r.solve_keep, r.probe};
   } else {
-    kerns = {reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>),
-             reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>)};
+    if (s->lay.wglobal)
+      kerns = {reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false, false, true>),
+               reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true, false, true>)};
+    else
+      kerns = {reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false>),
+               reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true>)};
   }
   hipError_t e = hipSuccess;
   for (const void* k : kerns)
@@ -731,15 +743,15 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
   if (d_trace) {
-    const int lds = h->lay.lds_doubles * (int)sizeof(double);
-    if (h->lay.nx > kMpcThreads || lds > kLdsLimitBytes)
-      return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "stage matrices do not fit the 160 KiB LDS budget");
-    auto kern = fbstab_mpc_kernel<kMpcThreads, false, true>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int lds = h->lay.launch_lds_doubles * (int)sizeof(double);
+    const void* kern = h->lay.wglobal
+                           ? reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false, true, true>)
+                           : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false, true, false>);
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (!h->trace_ws) HIP_TRY(hipMalloc(&h->trace_ws, sizeof(double) * (size_t)h->lay.ws_doubles));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(kMpcThreads), lds, s, h->lay, a, v, d_out, h->opts,
-                       h->trace_ws, h->counter, 1, d_trace);
+    int one = 1;
+    void* args[] = {&h->lay, &a, &v, &d_out, &h->opts, &h->trace_ws, &h->counter, &one, &d_trace};
+    HIP_TRY(hipLaunchKernel(kern, dim3(1), dim3(kMpcThreads), args, (size_t)lds, s));
   } else if (h->rec) {
     // FBSTAB_HIP_KEEP_MATRICES: one QP per slot, slot = QP index
     const bool keep = (flags & FBSTAB_HIP_KEEP_MATRICES) && dev_ptrs && batch <= h->workgroups * h->qps_per_wg;
@@ -751,8 +763,12 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
     if (rc != FBSTAB_HIP_OK) return rc;
     h->kept_batch = keep ? batch : -1;
   } else {
-    hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, false>), dim3(grid), dim3(h->threads), h->lds_bytes, s,
-                       h->lay, a, v, d_out, h->opts, h->scratch, h->counter, batch, (double*)nullptr);
+    const void* kern = h->lay.wglobal
+                           ? reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false, false, true>)
+                           : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, false, false, false>);
+    double* no_dbg = nullptr;
+    void* args[] = {&h->lay, &a, &v, &d_out, &h->opts, &h->scratch, &h->counter, &batch, &no_dbg};
+    HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(h->threads), args, (size_t)h->lds_bytes, s));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev1, s));
@@ -830,8 +846,6 @@ int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t h, int batch, const fbstab
   if (rc != FBSTAB_HIP_OK) return rc;
   if (!plant || !plant->A || !plant->B || steps < 0)
     return fail(FBSTAB_HIP_ERR_ARGUMENT, "plant matrices and a non-negative step count are required");
-  if (h->lay.nx > 64 || h->lay.nu > 8)
-    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "receding sweep: nx <= 64 and nu <= 8");
   for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
     if (!data->base[i]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer");
   for (int i = 0; i < 4; i++)
@@ -903,6 +917,8 @@ int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t h, int batch, const fbstab
   }
   const int flags = FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_ASYNC | FBSTAB_HIP_KEEP_MATRICES;
   h->kept_batch = -1;  // the first step builds the matrix copies
+  DevBuf d_xtmp;  // the plant step's new states, for more than 64 of them per trajectory
+  if (L.nx > 64) HIP_TRY(hipMalloc(&d_xtmp.p, sizeof(double) * (size_t)batch * L.nx));
   for (int k = 0; k < steps; k++) {
     if (kernel_ms) HIP_TRY(hipEventRecord(ev[2 * k], s));
     rc = mpc_solve_impl(h, batch, data, x, out, flags, s, nullptr);
@@ -912,7 +928,7 @@ int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t h, int batch, const fbstab
                        L.nz, L.nl, L.nv, plant->A, plant->stride_A, plant->B, plant->stride_B, x0,
                        data->stride[FBSTAB_MPC_x0], v, out, static_cast<int*>(d_ret.p), retire,
                        u_log ? u_log + (long long)k * batch * L.nu : nullptr,
-                       static_cast<unsigned long long*>(d_stats.p) + 4 * k);
+                       static_cast<unsigned long long*>(d_stats.p) + 4 * k, static_cast<double*>(d_xtmp.p));
   }
   HIP_TRY(hipGetLastError());
   if (stats)
@@ -962,8 +978,12 @@ int fbstab_hip_mpc_debug_newton(fbstab_mpc_handle_t h, const fbstab_mpc_batch_t*
     rc = launch_record(h, h->exact ? h->rec->probe_exact : h->rec->probe, 1, s, a, v, h->d_out, 1, d_io, false);
     if (rc != FBSTAB_HIP_OK) return rc;
   } else {
-    hipLaunchKernelGGL((fbstab_mpc_kernel<kMpcThreads, true>), dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a,
-                       v, h->d_out, h->opts, h->scratch, h->counter, 1, d_io);
+    const void* kern = h->lay.wglobal
+                           ? reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true, false, true>)
+                           : reinterpret_cast<const void*>(fbstab_mpc_kernel<kMpcThreads, true, false, false>);
+    int one = 1;
+    void* args[] = {&h->lay, &a, &v, &h->d_out, &h->opts, &h->scratch, &h->counter, &one, &d_io};
+    HIP_TRY(hipLaunchKernel(kern, dim3(1), dim3(h->threads), args, (size_t)h->lds_bytes, s));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(io, d_io, sizeof(double) * n_io, hipMemcpyDeviceToHost, s));
@@ -1041,7 +1061,7 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
     s->lay.init(nz, nl, nv, kDenseThreads);  // (the traced solve's layout)
     s->lds_bytes = s->wlay.lds_doubles * (int)sizeof(double);
   }
-  if (s->lds_bytes > kLdsLimitBytes) {
+  if (s->lds_bytes > kLdsLimitBytes) {  // (not reached: the vectors move to global scratch first)
     delete s;
     return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "the iterate vectors do not fit the 160 KiB LDS budget");
   }
@@ -1049,6 +1069,8 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   if (rc != FBSTAB_HIP_OK) { s->release(); delete s; return rc; }
   const void* kern = s->wave ? reinterpret_cast<const void*>(fbstab_dense_wave_kernel<false>)
                      : s->threads == 64 ? reinterpret_cast<const void*>(fbstab_dense_kernel<64>)
+                     : s->lay.v_global
+                         ? reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads, false, true, true>)
                      : s->lay.k_global
                          ? reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads, false, true>)
                          : reinterpret_cast<const void*>(fbstab_dense_kernel<kDenseThreads>);
@@ -1073,8 +1095,8 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
   s->scratch_bytes = 0;
   if (s->wave)  // A' and the multipliers of every resident workgroup (fb_dense_wave.h)
     s->scratch_bytes = (long long)sizeof(double) * s->wlay.ws_doubles * s->workgroups;
-  else if (s->lay.k_global)  // K of every resident workgroup (fb_dense.h)
-    s->scratch_bytes = (long long)sizeof(double) * s->lay.k_doubles * s->workgroups;
+  else if (s->lay.k_global)  // K (and, v_global, the iterate vectors) of every resident workgroup (fb_dense.h)
+    s->scratch_bytes = (long long)sizeof(double) * (s->lay.k_doubles + s->lay.v_doubles) * s->workgroups;
   if (s->scratch_bytes > 0) {
     e = hipMalloc(&s->scratch, (size_t)s->scratch_bytes);
     // (fb_dense_wave.h relies on the multiplier rows past nz + nl being zero)
@@ -1164,7 +1186,13 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
   HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
   int grid = h->workgroups < batch ? h->workgroups : batch;
   HIP_TRY(hipEventRecord(h->ev0, s));
-  if (d_trace && h->lay.k_global) {
+  if (d_trace && h->lay.v_global) {
+    auto kern = fbstab_dense_kernel<kDenseThreads, true, true, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(h->threads), h->lds_bytes, s, h->lay, a, v, d_out, h->opts,
+                       h->counter, 1, TraceArg<true>{d_trace}, KScratchArg<true>{h->scratch});
+  } else if (d_trace && h->lay.k_global) {
     auto kern = fbstab_dense_kernel<kDenseThreads, true, true>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes));
@@ -1188,6 +1216,10 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
   } else if (h->threads == 64) {
     hipLaunchKernelGGL(fbstab_dense_kernel<64>, dim3(grid), dim3(64), h->lds_bytes, s, h->lay, a, v, d_out,
                        h->opts, h->counter, batch, TraceArg<false>(), KScratchArg<false>());
+  } else if (h->lay.v_global) {
+    hipLaunchKernelGGL((fbstab_dense_kernel<kDenseThreads, false, true, true>), dim3(grid), dim3(h->threads),
+                       h->lds_bytes, s, h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>(),
+                       KScratchArg<true>{h->scratch});
   } else if (h->lay.k_global) {
     hipLaunchKernelGGL((fbstab_dense_kernel<kDenseThreads, false, true>), dim3(grid), dim3(h->threads),
                        h->lds_bytes, s, h->lay, a, v, d_out, h->opts, h->counter, batch, TraceArg<false>(),

@@ -63,4 +63,7 @@ def test_argument_validation_without_gpu(lib):
     assert b"problem sizes must be positive" in lib.fbstab_hip_last_error()
     assert lib.fbstab_hip_dense_create(2, -1, 2, 1, 0, C.byref(h)) == 1
     assert lib.fbstab_hip_mpc_create(30, 12, 4, 20, 0, 0, C.byref(h)) == 1
-    assert lib.fbstab_hip_mpc_create(30, 80, 4, 20, 1, 0, C.byref(h)) == 3  # nx > 64
+    if lib.fbstab_hip_device_count() == 0:
+        # no shape is refused for its size (stages wider than the LDS run from global
+        # scratch): what stops this call here is the missing device
+        assert lib.fbstab_hip_mpc_create(30, 80, 4, 20, 1, 0, C.byref(h)) == 2

