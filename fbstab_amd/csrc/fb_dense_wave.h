@@ -340,7 +340,6 @@ struct DenseWave {
     // right-hand side (dense_cholesky_solver.cc:98-100): lane (kq, ij) sums its rows of
     // column 16 I + ij, the four partial sums meet below.
     FB_DW_LAP(0);
-    typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
     double part[4] = {0.0, 0.0, 0.0, 0.0};
     const double* acol[4];
 #pragma unroll

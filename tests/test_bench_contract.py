@@ -49,6 +49,15 @@ def test_latest_bench_line_carries_the_whole_truth():
     assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
     if rf["traffic"] is not None:
         assert "replayed" in rf["traffic_source"] and rf["traffic_source"].startswith("profiles/")
+        # the corrected counter bytes (read side doubled, MI355X_MICROARCH.md
+        # HBM section), the raw sum beside them, their ratio to the algorithmic bytes and the
+        # regime the counters were taken in
+        assert rf["traffic"] > rf["traffic_raw"] > rf["algorithmic_bytes_per_launch"]
+        assert abs(rf["traffic_ratio"] - rf["traffic"] / rf["algorithmic_bytes_per_launch"]) < 1e-9 * rf["traffic_ratio"]
+        assert "one launch at a time" in rf["traffic_regime"] or "in flight" in rf["traffic_regime"]
+    cb = r["cpu_baseline"]
+    assert cb["affinity_cpus"] >= 1 and cb["os_cpu_count"] >= cb["affinity_cpus"]
+    assert cb["cgroup_cpu_quota"] is None or cb["cgroup_cpu_quota"] > 0
     for k in ("serial", "ltv_dense_rows", "dense", "receding"):
         assert isinstance(r[k], dict) and r[k]["value"] > 0 and r[k]["unit"] == "QPs/sec", (path, k)
     assert r["serial"]["steps_in_flight"] == 1 and r["serial"]["value"] <= r["value"] * 1.02

@@ -14,17 +14,23 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   echo "pass $i rc=$?"
 done
 cd $R
-for j in $(seq 1 $i); do python3 tools/rocpd_summary.py pmc $OUT/p$j/p_results.db _kernel > $OUT/p$j.json 2>/dev/null; rm -rf $OUT/p$j; done
+for j in $(seq 1 $i); do python3 tools/rocpd_summary.py pmc $OUT/p$j/p_results.db fbstab_ > $OUT/p$j.json 2>/dev/null; rm -rf $OUT/p$j; done
 python3 - <<PY
 import json,glob
+# the solver kernel's dispatches (a warm-up and the timed ones): counters of the LAST one
 tot={}
 for f in sorted(glob.glob("$OUT/p*.json")):
     try: rows=json.load(open(f))
     except Exception as e: print(f,"unreadable"); continue
-    last=max(r["dispatch_id"] for r in rows) if rows else None
+    if not rows: continue
+    last=max(r["dispatch_id"] for r in rows)
     for r in rows:
-        if r["dispatch_id"]==last: tot[r["counter"]]=r["value"]; tot.setdefault("duration_ms",[]).append(r["duration_ns"]/1e6)
-tot["duration_ms"]=sorted(set(tot.get("duration_ms",[])))
+        if r["dispatch_id"]==last:
+            tot[r["counter"]]=r["value"]; tot.setdefault("kernel_ms_under_pmc",[]).append(round(r["duration_ns"]/1e6,3))
+tot["kernel_ms_under_pmc"]=sorted(set(tot.get("kernel_ms_under_pmc",[])))
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    tot["hbm_bytes_per_launch_raw"]=(tot["FETCH_SIZE"]+tot["WRITE_SIZE"])*1024
+    tot["hbm_bytes_per_launch_fetch_doubled"]=(2*tot["FETCH_SIZE"]+tot["WRITE_SIZE"])*1024
 json.dump(tot, open("$OUT/summary.json","w"), indent=1)
 print(json.dumps(tot))
 PY
