@@ -244,7 +244,9 @@ FB_DEV double sat(double x, double lo, double hi) {
 // range scaling and special-case selects around v_rsq_f64): hardware seed, one
 // coupled Goldschmidt step and ONE residual correction - within an ulp - and no
 // scaling (a^2 + b^2 has underflowed or overflowed long before the scaling would
-// matter).  sqrt(0) = 0 exactly: the NaN of 0 * inf is dropped by the final max.
+// matter).  Zero, infinity and NaN come back as they are (sqrt(0) = 0 exactly; an
+// overflowed or NaN iterate then propagates as it does through the reference's sqrt and
+// ends where the reference's solve ends - in a failed factorisation, impl:263-267).
 FB_DEV double fsqrt(double x) {
 #if defined(FB_HOSTSIM)
   return sqrt(x);
@@ -256,7 +258,7 @@ FB_DEV double fsqrt(double x) {
   h = fma(h, d, h);
   const double e = fma(-g, g, x);
   g = fma(e, h, g);
-  return __builtin_fmax(g, 0.0);
+  return __builtin_amdgcn_class(x, 0x180 /* +denormal | +normal */) ? g : x;
 #endif
 }
 

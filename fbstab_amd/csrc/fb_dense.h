@@ -280,6 +280,19 @@ struct DenseProblem {
     }
   }
   FB_DEV bool ldlt(const C& c) const {
+    {
+      // A NaN on the diagonal (an iterate that overflowed) ends Eigen's factorisation: its
+      // pivot search compares false against it and the pivot it takes is invalid over a
+      // non-zero column - NumericalIssue, the reference throws (impl:263-267).  (The
+      // searches below would find NO pivot among NaNs.)
+      double bad[1] = {0.0};
+      for (int i = c.tid; i < lay.nk; i += C::nt) {
+        const double d = K[i + (long)i * lay.nk];
+        if (d != d) bad[0] = 1.0;
+      }
+      c.max(bad);
+      if (bad[0] != 0.0) return false;
+    }
 #if !defined(FB_HOSTSIM)
     if constexpr (!KGLOBAL) {
       if (lay.wave) {

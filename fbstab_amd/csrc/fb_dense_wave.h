@@ -578,6 +578,11 @@ struct DenseWave {
     int ord = 64, permv = 0;
     double dpiv = 0.0;
     bool found_zero_pivot = false;
+    // A NaN on the diagonal (an iterate that overflowed: the matrix is NaN wherever a NaN
+    // Gamma reaches) ends Eigen's factorisation - its pivot search compares false against
+    // it, the pivot it then takes is invalid over a non-zero column: NumericalIssue, and the
+    // reference throws (impl:263-267).  Below, NaN marks the rows that are gone.
+    if (__ballot(alive && dg != dg) != 0ull) return false;
     FB_DW_LAPS_DECL;
     for (int k = 0; k < n; k++) {
       // largest |diagonal| of what is left; the first maximum wins (Eigen's maxCoeff)

@@ -327,3 +327,45 @@ def test_dense_vectors_longer_than_the_lds(hip, oracle):
     assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all()
     assert np.array_equal(out2["newton_iters"], out["newton_iters"])
     np.testing.assert_allclose(np.sqrt((nrm[:, :3] ** 2).sum(axis=1)), out["residual"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["mpc_record", "mpc_flat", "dense_wave", "dense_256"])
+def test_overflowed_and_nan_guesses_end_where_the_reference_ends(hip, oracle, monkeypatch, kind):
+    """An initial guess with a NaN, an infinity or an entry whose square overflows: the
+    reference's sqrt propagates it through the Fischer-Burmeister function, the first
+    factorisation fails and Solve throws (impl:263-267; the oracle raises for every
+    case below).  The batch API reports exactly these QPs as DIVERGENCE (the documented
+    stand-in for the throw) and solves the healthy QPs beside them as if alone."""
+    if kind.startswith("mpc"):
+        monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kind == "mpc_flat" else "0")
+        p = fx.synthetic_mpc_batch(6, first_id=10)
+        s = hip.FBstabMpcBatch(*p.sizes(), max_batch=6)
+        solve1 = lambda q, g: oracle.solve_mpc(q, x0guess=g, opts=default_options())
+    else:
+        monkeypatch.setenv("FBSTAB_HIP_DENSE_THREADS", "256" if kind == "dense_256" else "0")
+        p = fx.synthetic_dense_batch(6, 20, 5, 40, first_id=10)
+        s = hip.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=6)
+        solve1 = lambda q, g: oracle.solve_dense(q, x0guess=g, opts=default_options())
+    z = np.zeros((6, p.nz)); l = np.zeros((6, p.nl)); v = np.zeros((6, p.nv)); y = np.zeros((6, p.nv))
+    v[1, 5] = np.nan
+    v[2, 7] = 1e200
+    z[3, 3] = np.inf
+    v[4, 2] = -1e200
+    bad = [1, 2, 3, 4]
+    # the oracle, one QP at a time: the poisoned ones raise, the healthy ones converge
+    ref = {}
+    for q in range(6):
+        one = type(p)(*p.sizes()) if kind.startswith("mpc") else type(p)(p.nz, p.nl, p.nv)
+        one.arrays = {k: a[q:q + 1] for k, a in p.arrays.items()}
+        g = (z[q:q + 1].copy(), l[q:q + 1].copy(), v[q:q + 1].copy())
+        if q in bad:
+            with pytest.raises(RuntimeError, match="Initialize failed"):
+                solve1(one, g)
+        else:
+            ref[q] = solve1(one, g)
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    s.close()
+    assert out["eflag"].tolist() == [0, 1, 1, 1, 1, 0]
+    for q, r in ref.items():
+        assert out["newton_iters"][q] == r[4]["newton_iters"][0] and out["prox_iters"][q] == r[4]["prox_iters"][0]
+        assert np.abs(z[q] - r[0][0]).max() <= 1e-5 * (1 + np.abs(r[0][0]).max())
