@@ -836,8 +836,16 @@ struct MpcR16 {
   };
   // R0: the owner's record base with this lane's offset within ITS row (2 * r)
   template <int K>
+#ifndef FB_R16_COOP_INLINE
+#define FB_R16_COOP_INLINE 0
+#endif
+#if FB_R16_COOP_INLINE
+  static __device__ __forceinline__ TrialNorms<K> trial_pass_coop(const double* R0, int N_, double t0,
+                                                                            double beta, double sigma, double alpha) {
+#else
   static __device__ __attribute__((noinline)) TrialNorms<K> trial_pass_coop(const double* R0, int N_, double t0,
                                                                             double beta, double sigma, double alpha) {
+#endif
     constexpr int QW = kQpPerWave;
     const int lane = threadIdx.x & 63;
     const int q = lane / LPQ, r = lane & (LPQ - 1);
