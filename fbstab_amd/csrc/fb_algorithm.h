@@ -454,7 +454,11 @@ struct Solver : TraceState<TRACE> {
     // waits here until no row of the wavefront stands before a Newton step, and the
     // waiting rows then fetch together: their passes over a fresh QP run side by side
     // again instead of one row at a time.
-    enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5, kPause = 6 };
+    // kWantOpen / kWantClose (policies with P::kCoopProx): the row asks for its open_prox /
+    // close_subproblem pass and yields; the wavefront runs the pass for it with ALL its rows
+    // (below) and the row goes on at kAfterOpen / kAfterClose.
+    enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5, kPause = 6,
+           kWantOpen = 7, kWantClose = 8, kAfterOpen = 9, kAfterClose = 10 };
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -465,8 +469,11 @@ struct Solver : TraceState<TRACE> {
     [[maybe_unused]] bool fetch_now = true;  // (align_rows) the wavefront has just released its waiting rows
     // line-search trial passes run by all rows of the wavefront for one of them at a time
     constexpr bool kCoop = P::kCoopTrials && !Queue::kCanAlignRows;
+    constexpr bool kCoopP = kCoop && P::kCoopProx;
+    [[maybe_unused]] bool fresh = false;   // (kCoopP) the open_prox asked for is the first of its QP
+    [[maybe_unused]] int feas_c = kFeasible;  // (kCoopP) verdict of the close pass served last
     for (;;) {
-      while (phase != kNewton && phase != kDone && phase != kPause) {
+      while (phase != kNewton && phase != kDone && phase != kPause && phase != kWantOpen && phase != kWantClose) {
         if (phase == kFetch) {
           if constexpr (Queue::kCanAlignRows) {
             if (qu.align_rows() && !fetch_now) {
@@ -485,6 +492,11 @@ struct Solver : TraceState<TRACE> {
           p.load_guess(c);
           p.choose_costate_form(sigma);
           dx_norm = sqrt((double)p.num_primal_dual());
+          if constexpr (kCoopP) {
+            fresh = true;
+            phase = kWantOpen;
+            continue;
+          }
           open_prox(sigma, &Ek, &Ei0);
           E0 = Ek;
           rk_last = Ek;
@@ -497,6 +509,24 @@ struct Solver : TraceState<TRACE> {
             continue;  // phase stays kFetch
           }
           inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
+          phase = kProxTop;
+        } else if (phase == kAfterOpen) {
+          // (kCoopP) the wavefront has run this row's open_prox pass: Ek, Ei0 are in
+          if (fresh) {
+            fresh = false;
+            E0 = Ek;
+            rk_last = Ek;
+            newton = 0;
+            prox = 0;
+            k = 0;
+            if (o.inner_tol_min > o.inner_tol_max) {
+              p.write_x(c);
+              finish(out, FBSTAB_SATURATE_ERROR, rk_last, newton, prox, E0);
+              phase = kFetch;
+              continue;
+            }
+            inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
+          }
           phase = kProxTop;
         } else if (phase == kProxTop) {
           if (k >= o.max_prox_iters) {  // impl:219-223
@@ -544,7 +574,13 @@ struct Solver : TraceState<TRACE> {
           // kEpilogue: subproblem epilogue (impl:301-303) and the rest of the
           // proximal iteration (impl:186-216)
           int feas = kFeasible;
-          if constexpr (P::kOwnVectorOps) {
+          if constexpr (kCoopP) {
+            if (phase == kEpilogue) {
+              phase = kWantClose;
+              continue;
+            }
+            feas = feas_c;  // kAfterClose
+          } else if constexpr (P::kOwnVectorOps) {
             feas = close_subproblem(&dx_norm);
           } else {
             p.flush(c);
@@ -577,8 +613,44 @@ struct Solver : TraceState<TRACE> {
           }
           prox++;
           k++;
+          if constexpr (kCoopP) {
+            phase = kWantOpen;
+            continue;
+          }
           open_prox(sigma, &Ek, &Ei0);
           phase = kProxTop;
+        }
+      }
+      if constexpr (kCoopP) {
+        // ---- the proximal-level passes the rows have asked for, each run by ALL rows of the
+        // wavefront for one of them (P::close_subproblem_coop / open_prox_coop); the rows that
+        // stand before a Newton step wait for them - with their lanes at work
+        unsigned long long wc = __ballot(phase == kWantClose), wo = __ballot(phase == kWantOpen);
+        if ((wc | wo) != 0ull) {
+          constexpr unsigned long long kRowMask = (C::nt == 64) ? ~0ull : ((1ull << C::nt) - 1ull);
+          while (wc != 0ull) {
+            const int owner = __builtin_ctzll(wc);
+            double dxn;
+            const int f = p.close_subproblem_coop(owner, o.infeas_tol, o.check_feasibility != 0, &dxn);
+            if (((threadIdx.x ^ owner) & 63 & ~(C::nt - 1)) == 0) {
+              feas_c = f;
+              dx_norm = dxn;
+              phase = kAfterClose;
+            }
+            wc &= ~(kRowMask << (owner & ~(C::nt - 1)));
+          }
+          while (wo != 0ull) {
+            const int owner = __builtin_ctzll(wo);
+            double ek, ei0;
+            p.open_prox_coop(owner, o.alpha, &ek, &ei0);
+            if (((threadIdx.x ^ owner) & 63 & ~(C::nt - 1)) == 0) {
+              Ek = ek;
+              Ei0 = ei0;
+              phase = kAfterOpen;
+            }
+            wo &= ~(kRowMask << (owner & ~(C::nt - 1)));
+          }
+          continue;
         }
       }
       if constexpr (kCoop) {

@@ -1204,6 +1204,367 @@ struct MpcR16 {
     *Ei0 = sqrt(nat + qp_reduce<RQ, OpSum16>(s_vi));
   }
 
+  // ---- the proximal-level passes run by ALL rows for ONE QP -----------------------------
+  // open_prox() and close_subproblem() are passes over the stages without a recurrence:
+  // stage i needs nothing but the records of stages i - 1, i, i + 1 and the stage's matrix
+  // copy.  Run by the row that owns the QP they keep a quarter of the wavefront busy while
+  // the other rows wait (the rows of a wavefront stand at different points of their
+  // solves); here row q takes the stages q, q + QW, q + 2 QW, ... of the OWNER's records, as
+  // trial_pass_coop() does for the line search.  The matrix rows come straight from the
+  // owner's matrix copy in global memory (a few KB that every row of the wavefront reads
+  // again and again: L1), NOT through the helper rows' LDS images of their own copies -
+  // restaging those after every pass is what made the first attempt at this a loss (round 2).
+  // Same terms as the owner's passes; the sums over the stages are formed per row and then
+  // over the rows.  Real calls, like the trial pass.
+#ifndef FB_R16_COOP_PROX
+#define FB_R16_COOP_PROX 1
+#endif
+  static constexpr bool kCoopProx = FB_R16_COOP_PROX != 0 && kCoopTrials;
+  struct OwnerView {
+    double* R0;        // the owner's records, this lane's offset within ITS row included
+    const double* P0;  // the owner's matrix copies, likewise
+    lds_iptr po;       // the owner's table of matrix-copy offsets (LDS)
+    int N;
+  };
+  FB_DEV OwnerView owner_view(int owner) const {
+    const int own0 = owner & ~(LPQ - 1);
+    auto lane64 = [&](unsigned long long x) {
+      return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(x >> 32), own0) << 32) |
+             (unsigned)__builtin_amdgcn_readlane((int)x, own0);
+    };
+    OwnerView o;
+    const int r2 = 2 * (threadIdx.x & (LPQ - 1));
+    o.R0 = reinterpret_cast<double*>(lane64((unsigned long long)rec)) + r2;
+    o.P0 = reinterpret_cast<const double*>(lane64((unsigned long long)pack)) + r2;
+    o.po = (lds_iptr)(unsigned long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long)lpo, own0);
+    o.N = __builtin_amdgcn_readlane(N, own0);
+    return o;
+  }
+  static FB_DEV double rows_sum(double x) {  // sum over the QP's lanes, then over the rows: every lane gets it
+    const double rs = qp_reduce<RQ, OpSum16>(x);
+    double tot = lane_value(rs, 0);
+    sfor<1, kQpPerWave>([&](auto Q_) { tot += lane_value(rs, LPQ * decltype(Q_)::value); });
+    return tot;
+  }
+  static FB_DEV double rows_max(double x) {
+    const double rs = qp_reduce<RQ, OpMax16>(x);
+    double tot = lane_value(rs, 0);
+    sfor<1, kQpPerWave>([&](auto Q_) { tot = fmax(tot, lane_value(rs, LPQ * decltype(Q_)::value)); });
+    return tot;
+  }
+  static FB_DEV void pass_fence() {  // records written by one row, read by another
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+
+  struct OpenSums {
+    double nat, vo, vi;
+  };
+  // open_prox() for the owner's QP (same statements per stage)
+  static __device__ __attribute__((noinline)) OpenSums open_pass_coop(double* R0, const double* P0, lds_iptr po,
+                                                                      int N_, double alpha) {
+    constexpr int QW = kQpPerWave;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPQ, r = lane & (LPQ - 1);
+    const bool rx = r < NX;
+    double s_nat = 0.0, s_vo = 0.0, s_vi = 0.0;
+    // What a trip reads, all of it requested at the top of the trip.  (Measured and dropped,
+    // gpurun_out/r03_s, r03_t: the record part requested a trip ahead, 478 k against 518 k
+    // QP/s - like every other attempt to put more loads in flight in this kernel -, and the
+    // matrix rows a trip ahead as well: the 64 doubles went to scratch memory, 330 k.)
+    struct In {
+      dbl2 fh, vy[KS];
+      double zz, ll, zn, ln, hn;
+    };
+    auto load = [&](int i, In& in) {
+      const int ii = i <= N_ ? i : N_;
+      const double* R = R0 + (long)ii * kRec;
+      const double* Rn = R + (ii < N_ ? kRec : 0);
+      in.fh = ld2(R, sF);
+      sfor<0, KS>([&](auto S_) { in.vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
+      in.zz = ld(R, sZ);
+      in.ll = ld(R, sL);
+      in.zn = ld(Rn, sZ);
+      in.ln = ld(Rn, sL);
+      in.hn = ld(Rn, sH);
+    };
+    for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
+      const bool live = i <= N_;
+      const int ii = live ? i : N_;
+      const bool has_next = ii < N_;
+      double* R = R0 + (long)ii * kRec;
+      In cu;
+      load(i, cu);
+      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+      {
+        const double* Pk = P0 + po[ii];
+        ldv<pK, NS>(Pk, Kr);
+        ldv<pC, NC>(Pk, Cc);
+        ldv<pABr, NS>(Pk, ABr);
+        ldv<pABc, NX>(Pk, ABc);
+      }
+      const dbl2 fh = cu.fh;
+      dbl2 vy[KS];
+      sfor<0, KS>([&](auto S_) { vy[decltype(S_)::value] = cu.vy[decltype(S_)::value]; });
+      const double zz = cu.zz, ll = cu.ll;
+      double zn = cu.zn, ln = cu.ln, hn = cu.hn;
+      if (!has_next) zn = ln = hn = 0.0;
+      double zb[NS], lnb[NX];
+      bc_all<NS, RQ>(zz, zb);
+      bc_all<NX, RQ>(ln, lnb);
+      double s = fh[0] + dot4<NS>(Kr, zb);
+      s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
+      {
+        double p[4] = {s, 0.0, 0.0, 0.0};
+        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(vy[decltype(I)::value / LPQ][0]); },
+                        [&](auto I, double t) {
+                          constexpr int k = decltype(I)::value;
+                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
+                        });
+        s = (p[0] + p[1]) + (p[2] + p[3]);
+      }
+      const double rl0 = rx ? fh[1] + zz : 0.0;
+      const double abz = dot4<NS>(ABr, zb);
+      const double rln = rx ? hn - (abz - zn) : 0.0;
+      double vo = 0.0, vi = 0.0;
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const double pn = pnr(vy[sl][1], vy[sl][0], alpha);  // zero on padding lanes
+        const double pf = pfb(vy[sl][1], vy[sl][0], alpha);
+        vo = fma(pn, pn, vo);
+        vi = fma(pf, pf, vi);
+      });
+      if (live) {
+        st2(R, sZB, zz, ll);
+        st(R, sRZ, s);
+        double nat = s * s;
+        if (i == 0) {
+          st(R, sRL, rl0);
+          nat = fma(rl0, rl0, nat);
+        }
+        if (has_next) {
+          st(R + kRec, sRL, rln);
+          nat = fma(rln, rln, nat);
+        }
+        double vbs[KS], ybs[KS];
+        sfor<0, KS>([&](auto S_) { vbs[decltype(S_)::value] = vy[decltype(S_)::value][0]; ybs[decltype(S_)::value] = vy[decltype(S_)::value][1]; });
+        stv<sVB, KS>(R, vbs);
+        stv<sYB, KS>(R, ybs);
+        s_nat += nat;
+        s_vo += vo;
+        s_vi += vi;
+      }
+    }
+    OpenSums o;
+    o.nat = rows_sum(s_nat);
+    o.vo = rows_sum(s_vo);
+    o.vi = rows_sum(s_vi);
+    return o;
+  }
+  // every lane of the wavefront calls this; every lane gets the owner's norms
+  FB_DEV void open_prox_coop(int owner, double alpha, double* Ek, double* Ei0) const {
+    FB_WAVE_COUNT(25);
+    FB_WAVE_TIMER(22);
+    pass_fence();
+    const OwnerView ov = owner_view(owner);
+    const OpenSums o = open_pass_coop(ov.R0, ov.P0, ov.po, ov.N, alpha);
+    pass_fence();
+    *Ek = sqrt(o.nat + o.vo);
+    *Ei0 = sqrt(o.nat + o.vi);
+  }
+
+  struct CloseSums {
+    double dx2, m_adz, m_gdz, m_hdz, m_dz, m_atv, m_u, s_fdz, s_p2;
+  };
+  // close_subproblem() for the owner's QP: t is the owner's pending step; Cl is THIS row's
+  // transpose buffer (not the resident matrix copy)
+  static __device__ __attribute__((noinline)) CloseSums close_pass_coop(double* R0, const double* P0, lds_iptr po,
+                                                                        lds_ptr Cl, int N_, double t, bool check) {
+    constexpr int QW = kQpPerWave;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPQ, r = lane & (LPQ - 1);
+    const bool rx = r < NX;
+    double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
+    double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
+    C cc_;
+    cc_.tid = r;
+    // What a trip reads, all of it requested at the top of the trip, before the trip stores
+    // anything: the row that takes stage i + 1 in this very trip rewrites what `nxt` is read
+    // from.  (WLN, from which the stage above takes its wl a trip later, is left as it is.)
+    struct In {
+      dbl2 zr, bb, dw, lr, dwl;       // stage i
+      dbl2 nzr, nbb, ndw, nlr, ndwl;  // stage i + 1
+      double wlp;                     // WLN(i - 1)
+      dbl2 vy[KS], da[KS], fh;
+      double vb[KS], bs[KS];
+    };
+    auto load = [&](int i, In& in) {
+      const int ii = i <= N_ ? i : N_;
+      const double* R = R0 + (long)ii * kRec;
+      const double* Rn = R + (ii < N_ ? kRec : 0);
+      in.zr = ld2(R, sZ); in.bb = ld2(R, sZB); in.dw = ld2(R, sDZ); in.lr = ld2(R, sL); in.dwl = ld2(R, sDL);
+      in.nzr = ld2(Rn, sZ); in.nbb = ld2(Rn, sZB); in.ndw = ld2(Rn, sDZ); in.nlr = ld2(Rn, sL); in.ndwl = ld2(Rn, sDL);
+      in.wlp = ld(R - (ii > 0 ? kRec : 0), sWLN);
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        in.vy[sl] = ld2(R, sV + 2 * sl);
+        in.da[sl] = ld2(R, sDV + 2 * sl);
+      });
+      ldv<sVB, KS>(R, in.vb);
+      if (check) {
+        in.fh = ld2(R, sF);
+        sfor<0, KS>([&](auto S_) { in.bs[decltype(S_)::value] = ld(R, sB + decltype(S_)::value); });
+      }
+    };
+    for (int i = q; i - q <= N_; i += QW) {
+      const bool live = i <= N_;
+      const int ii = live ? i : N_;
+      const bool has_next = ii < N_;
+      double* R = R0 + (long)ii * kRec;
+      In cu;
+      load(i, cu);
+      double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
+      if (check) {
+        const double* Pk = P0 + po[ii];
+        ldv<pK, NS>(Pk, Kr);
+        ldv<pC, NC>(Pk, Cc);
+        ldv<pABr, NS>(Pk, ABr);
+        ldv<pABc, NX>(Pk, ABc);
+      }
+      ZL cur;
+      {
+        const double wl = wl_of_stage(ii, rx, cu.dw[0], cu.wlp);
+        cur.z = fma(t, cu.dw[0], cu.zr[0]);
+        cur.rz = fma(t, cu.dw[1], cu.zr[1]);
+        cur.l = fma(t, cu.dwl[0], cu.lr[0]);
+        cur.rl = fma(t, wl, cu.lr[1]);
+        cur.dz = cur.z - cu.bb[0];
+        cur.dl = cur.l - cu.bb[1];
+      }
+      ZL nxt;
+      nxt.dz = has_next ? fma(t, cu.ndw[0], cu.nzr[0]) - cu.nbb[0] : 0.0;
+      nxt.dl = has_next ? fma(t, cu.ndwl[0], cu.nlr[0]) - cu.nbb[1] : 0.0;
+      dbl2 vy[KS], da[KS];
+      double vb[KS];
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        vy[sl] = cu.vy[sl];
+        da[sl] = cu.da[sl];
+        vb[sl] = cu.vb[sl];
+      });
+      dbl2 fh = {0.0, 0.0};
+      double bs[KS];
+      sfor<0, KS>([&](auto S_) { bs[decltype(S_)::value] = 0.0; });
+      if (check) {
+        fh = cu.fh;
+        sfor<0, KS>([&](auto S_) { bs[decltype(S_)::value] = cu.bs[decltype(S_)::value]; });
+      }
+      double dx2 = fma(cur.dz, cur.dz, cur.dl * cur.dl);
+      double dvs[KS], vvs[KS], yys[KS];
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        vvs[sl] = fmax0(fma(t, da[sl][0], vy[sl][0]));
+        yys[sl] = fma(-t, da[sl][1], vy[sl][1]);
+        dvs[sl] = vvs[sl] - vb[sl];
+        dx2 = fma(dvs[sl], dvs[sl], dx2);
+      });
+      double l_adz = -1e300, l_gdz = 0.0, l_hdz = 0.0, l_dz = 0.0, l_atv = 0.0, l_u = 0.0, l_fdz = 0.0, l_p2 = 0.0;
+      if (check) {
+        double dzb[NS], dlnb[NX];
+        bc_all<NS, RQ>(cur.dz, dzb);
+        bc_all<NX, RQ>(nxt.dl, dlnb);
+        l_hdz = fabs(dot4<NS>(Kr, dzb));
+        l_dz = fabs(cur.dz);
+        {
+          double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? cur.dl : 0.0), 0.0, 0.0, 0.0};
+          bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
+                          [&](auto I, double tt) {
+                            constexpr int k = decltype(I)::value;
+                            p[k & 3] = fma(Cc[k], tt, p[k & 3]);
+                          });
+          l_atv = fabs((p[0] + p[1]) + (p[2] + p[3]));
+        }
+        l_fdz = fh[0] * cur.dz;
+        l_u = fabs(cur.dl);
+        l_p2 = fh[1] * cur.dl;
+        if (ii == 0) l_gdz = rx ? fabs(cur.dz) : 0.0;
+        if (has_next) {
+          const double g = dot4<NS>(ABr, dzb) - nxt.dz;
+          l_gdz = fmax(l_gdz, rx ? fabs(g) : 0.0);
+        }
+        cc_.sync();
+        sfor<0, NC>([&](auto Kk) { Cl[r * CS + decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
+        cc_.sync();
+        sfor<0, KS>([&](auto S_) {
+          constexpr int sl = decltype(S_)::value;
+          const int k = r + LPQ * sl;
+          const int kk = k < NC ? k : 0;
+          double clk[NS];
+          sfor<0, NS>([&](auto Cc2) { clk[decltype(Cc2)::value] = Cl[decltype(Cc2)::value * CS + kk]; });
+          const double az = dot4<NS>(clk, dzb);
+          if (k < NC) l_adz = fmax(l_adz, az);
+          l_u = fmax(l_u, fabs(dvs[sl]));
+          l_p2 = fma(bs[sl], dvs[sl], l_p2);
+        });
+      }
+      if (live) {
+        st2(R, sZ, cur.z, cur.rz);
+        st2(R, sL, cur.l, cur.rl);
+        st2(R, sDZ, cur.dz, 0.0);
+        st2(R, sDL, cur.dl, cu.dwl[1]);  // (no step is pending from here on: WLN is dead until the next sweep writes it)
+        sfor<0, KS>([&](auto S_) {
+          constexpr int sl = decltype(S_)::value;
+          st2(R, sV + 2 * sl, vvs[sl], yys[sl]);
+          st2(R, sDV + 2 * sl, dvs[sl], 0.0);
+        });
+        s_dx += dx2;
+        m_adz = fmax(m_adz, l_adz);
+        m_gdz = fmax(m_gdz, l_gdz);
+        m_hdz = fmax(m_hdz, l_hdz);
+        m_dz = fmax(m_dz, l_dz);
+        m_atv = fmax(m_atv, l_atv);
+        m_u = fmax(m_u, l_u);
+        s_fdz += l_fdz;
+        s_p2 += l_p2;
+      }
+    }
+    CloseSums o;
+    o.dx2 = rows_sum(s_dx);
+    o.m_adz = rows_max(m_adz);
+    o.m_gdz = rows_max(m_gdz);
+    o.m_hdz = rows_max(m_hdz);
+    o.m_dz = rows_max(m_dz);
+    o.m_atv = rows_max(m_atv);
+    o.m_u = rows_max(m_u);
+    o.s_fdz = rows_sum(s_fdz);
+    o.s_p2 = rows_sum(s_p2);
+    return o;
+  }
+  // every lane calls this; every lane gets the owner's verdict and ||dx||.  The owner's
+  // pending step is consumed (its row clears pend_t).
+  FB_DEV int close_subproblem_coop(int owner, double tol, bool check, double* dx_norm) {
+    FB_WAVE_COUNT(26);
+    FB_WAVE_TIMER(21);
+    pass_fence();
+    const OwnerView ov = owner_view(owner);
+    const int own0 = owner & ~(LPQ - 1);
+    const double t = lane_value(pend_t, own0);
+    if (((threadIdx.x ^ owner) & 63 & ~(LPQ - 1)) == 0) pend_t = 0.0;
+    const CloseSums o = close_pass_coop(ov.R0, ov.P0, ov.po, lds + kPackLds, ov.N, t, check);
+    pass_fence();
+    *dx_norm = sqrt(o.dx2);
+    if (!check) return kFeasible;
+    bool dual_feasible = true, primal_feasible = true;
+    if ((o.m_adz <= o.m_dz * tol) && (o.m_gdz <= tol * o.m_dz) && (o.m_hdz <= tol * o.m_dz) && (o.s_fdz < 0) &&
+        (o.m_dz > 1e-14))
+      dual_feasible = false;
+    if ((o.m_atv <= tol * o.m_u) && (o.s_p2 < 0)) primal_feasible = false;
+    if (primal_feasible && dual_feasible) return kFeasible;
+    if (primal_feasible && !dual_feasible) return kDualInfeasible;
+    if (!primal_feasible && dual_feasible) return kPrimalInfeasible;
+    return kBothInfeasible;
+  }
+
   // ---- results ---------------------------------------------------------------------
   // which: 0 = x, 1 = xbar, 2 = certificate dx with dx.y = y - ybar + b
   // (impl:202-210, full_variable.cc:55-65)
