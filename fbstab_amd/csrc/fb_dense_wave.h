@@ -11,28 +11,35 @@
 //     of the full symmetric matrix (64 doubles);
 //   * A' Gamma A is accumulated on the matrix cores (v_mfma_f64_16x16x4, the ten
 //     16x16 tiles of the lower triangle), operands read straight from the caller's
-//     column-major A: a lane takes FOUR consecutive rows of its column with one
-//     32-byte access (the four lanes that share a column cover one 128-byte line)
-//     and the four rows feed four k-steps - the contraction runs over the rows of A
-//     in a permuted order, which the sum does not care about - so that no transposed
+//     column-major A: a trip takes sixteen rows and a lane holds two adjacent row
+//     PAIRS of its column (16 bytes each; the four lanes that share a column cover
+//     64 contiguous bytes per access) - the contraction runs over the rows of A in
+//     a permuted order, which the sum does not care about - so that no transposed
 //     copy of A exists (40 KB per QP at 50/10/100: a third of the scratch a resident
 //     QP used to hold); the tiles reach the row layout through a 64 x 16 staging
 //     panel in LDS, one column block at a time;
+//   * LDL' in the NATURAL order, unrolled over its steps and fused with both
+//     substitutions (factor_solve_static, round 3): K is quasi-definite, every
+//     elimination order factors it, and a compile-time order makes every register
+//     index an immediate - no pivot search, no pick of a run-time column, half the
+//     trailing updates, the multipliers used where they are formed and the backward
+//     sweep a lane-local dot product;
 //   * the pivoted LDL' (Eigen::LDLT's rule: largest |diagonal| of what is left,
-//     the first maximum wins; dense_cholesky_solver.cc:70-79) eliminates in
-//     place without swapping anything: the pivot row goes to LDS once, every
-//     lane reads its own entry of it (the multiplier column, by symmetry) and
-//     the row itself as 16-byte broadcasts.  The multipliers of step k go to a
-//     64 x 64 global scratch (row k, lane t: one coalesced store per pivot) from
-//     where both substitutions read them back, loads issued eight steps ahead;
+//     the first maximum wins; dense_cholesky_solver.cc:70-79), which eliminates in
+//     place without swapping anything and keeps its multipliers in a 64 x 64 global
+//     scratch, stays behind it for the matrices the natural order cannot take (a
+//     zero, denormal, infinite or NaN pivot): there the verdict is Eigen's;
 //   * right-hand side and solution of the substitutions stay in a register
 //     (lane t owns entry t), solved entries are handed round by v_readlane.
 //
 // Reference code answered to: DenseData products (dense_data.cc:12-41),
 // DenseCholeskySolver::Initialize / Solve (dense_cholesky_solver.cc:32-127),
-// FullFeasibility::CheckFeasibility (full_feasibility.cc:25-88).  Same
-// factorisation as Eigen's up to rounding (right-looking here, left-looking
-// there; the pivot order is the same rule).
+// FullFeasibility::CheckFeasibility (full_feasibility.cc:25-88).  The pivoted
+// path is the same factorisation as Eigen's up to rounding (right-looking here,
+// left-looking there; the pivot order is the same rule); the natural-order path
+// solves the same systems with a different rounding, which shows where the
+// answer is not unique: the multipliers of dual-degenerate QPs (tests/
+// test_gpu_parity.py, _unique_duals).
 #pragma once
 
 #include <float.h>
@@ -657,6 +664,138 @@ struct DenseWave {
     return true;
   }
 
+  // ---- LDL' in the natural order, fused with both substitutions (round 3) -------------
+  // K is quasi-definite for sigma > 0: the leading block H + sigma I + A'Gamma A is
+  // positive definite, the Schur complement behind it negative definite, so LDL' exists
+  // for EVERY symmetric permutation and the natural order is the block elimination an
+  // implementation without a pivoting library would write down (Cholesky of the leading
+  // block, then of sigma I + G E^-1 G').  Eigen's rule (largest remaining |diagonal|,
+  // dense_cholesky_solver.cc:70-79) eliminates the same leading block first - the
+  // diagonal of the trailing one is -sigma - in a different order inside it; the two
+  // factorisations solve the same system to rounding.  With the order known at compile
+  // time the whole step list unrolls and every register index is an immediate:
+  //   * no pivot search, no pick of a run-time column out of the registers;
+  //   * step k updates columns k + 1 .. 63 only (the pivoted loop has to sweep all 64);
+  //   * the multipliers are used where they are formed: the right-hand side is
+  //     eliminated along with the matrix (Gaussian elimination of the augmented column),
+  //     nothing goes to the global scratch and the forward sweep with its 63 loads is gone;
+  //   * what a finished step leaves in lane k - row k of D L' in registers k + 1 .. 63,
+  //     frozen from then on - is what the backward sweep needs: lane t takes its own dot
+  //     product, one v_readlane pair and one FMA per solved entry, instead of a sum over
+  //     the wavefront per entry.
+  // The pivot row reaches the other lanes as in the pivoted loop: the column (= the row,
+  // by symmetry) goes to LDS with one store, the first kRlCols columns behind the pivot
+  // come back through v_readlane - column k + 1 first, the next pivot and its reciprocal
+  // hang on it -, the rest as 16-byte LDS broadcasts.  Rows and columns n .. 63 are an
+  // identity block (their pivots read as 1).
+  // Returns false - and leaves K and x destroyed - if a pivot is zero, denormal, infinite
+  // or NaN: the caller assembles K again and takes the pivoted path, whose verdict on such
+  // a matrix is Eigen's.
+#ifndef FB_DW_STATIC_ORDER
+#define FB_DW_STATIC_ORDER 1
+#endif
+#ifndef FB_DW_RL_COLS
+#define FB_DW_RL_COLS 8
+#endif
+  static constexpr int kRlCols = FB_DW_RL_COLS;
+#ifndef FB_DW_ST_BATCH
+#define FB_DW_ST_BATCH 8
+#endif
+#ifndef FB_DW_RCP_STEPS
+#define FB_DW_RCP_STEPS 3
+#endif
+  static constexpr int kStBatch = FB_DW_ST_BATCH;  // 16-byte LDS reads in flight
+  // 1 / d: hardware seed and three Newton steps, without the scaling and fix-up of the
+  // IEEE sequence (the exponent of d is checked by the caller).  Two steps - what the IEEE
+  // sequence takes before its final correction of the quotient - leave ~1e-11: z of
+  // dense shape (30, 20, 64) then differed from the oracle's by 8e-9 instead of 1e-13 and
+  // the duals of its degenerate QPs by 3e-2 (gpurun_out/r03_x).
+  static FB_DEV double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int i = 0; i < FB_DW_RCP_STEPS; i++) r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+  }
+  FB_DEV bool factor_solve_static(const C& c, double (&Kr)[64], double& x) const {
+    int n = lay.nk, t = c.tid;
+    asm volatile("" : "+s"(n), "+v"(t));
+    unsigned emin = 0x7ffu, emax = 0u;
+    double dinv = 0.0;
+    auto pivot = [&](auto K_, double& r) {  // reciprocal of pivot k, its exponent noted
+      constexpr int k = decltype(K_)::value;
+      const double dk = lane_of(Kr[k], k);
+      const double d = k < n ? dk : 1.0;
+      const unsigned e = ((unsigned)__double2hiint(d) >> 20) & 0x7ffu;
+      emin = e < emin ? e : emin;
+      emax = e > emax ? e : emax;
+      r = rcp_nr(d);
+    };
+    double r;
+    pivot(std::integral_constant<int, 0>{}, r);
+    FB_DW_LAPS_DECL;
+    sfor<0, 63>([&](auto K_) {
+      constexpr int k = decltype(K_)::value;
+      const double colk = Kr[k];  // K[t][k] = K[k][t]
+      const double nlm = t > k ? -(colk * r) : 0.0;
+      dinv = t == k ? r : dinv;
+      rowbuf[t] = colk;
+      x = fma(nlm, lane_of(x, k), x);
+      Kr[k + 1] = fma(nlm, lane_of(colk, k + 1), Kr[k + 1]);
+      pivot(std::integral_constant<int, k + 1>{}, r);
+      // first column that comes from LDS: even, at least kRlCols behind the pivot
+      constexpr int jl = (k + 1 + kRlCols + 1) & ~1;
+      constexpr int jA = jl < 64 ? jl : 64;
+      sfor<k + 2, jA>([&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        Kr[j] = fma(nlm, lane_of(colk, j), Kr[j]);
+      });
+      if constexpr (jA < 64) {
+        __builtin_amdgcn_wave_barrier();  // (LDS keeps a wavefront's accesses in order)
+        constexpr int NP = (64 - jA) / 2;  // pairs
+        dbl2 sj[kStBatch];
+        auto request = [&](auto P0) {
+          constexpr int p0 = decltype(P0)::value;
+          sfor<0, kStBatch>([&](auto U_) {
+            constexpr int u = decltype(U_)::value;
+            if constexpr (p0 + u < NP) sj[u] = *reinterpret_cast<FB_LDS const dbl2*>(rowbuf + jA + 2 * (p0 + u));
+          });
+        };
+        request(std::integral_constant<int, 0>{});
+        sfor<0, (NP + kStBatch - 1) / kStBatch>([&](auto B_) {
+          constexpr int p0 = decltype(B_)::value * kStBatch;
+          dbl2 cur[kStBatch];
+          sfor<0, kStBatch>([&](auto U_) { cur[decltype(U_)::value] = sj[decltype(U_)::value]; });
+          if constexpr (p0 + kStBatch < NP) request(std::integral_constant<int, p0 + kStBatch>{});
+          sfor<0, kStBatch>([&](auto U_) {
+            constexpr int u = decltype(U_)::value;
+            if constexpr (p0 + u < NP) {
+              constexpr int j = jA + 2 * (p0 + u);
+              Kr[j] = fma(nlm, cur[u][0], Kr[j]);
+              Kr[j + 1] = fma(nlm, cur[u][1], Kr[j + 1]);
+            }
+          });
+        });
+        __builtin_amdgcn_wave_barrier();  // (the next column is stored behind these reads)
+      }
+    });
+    dinv = t == 63 ? r : dinv;
+    FB_DW_LAP(3);
+    if (emin == 0u || emax == 0x7ffu) {
+      FB_DW_LAPS_FLUSH(0);
+      return false;
+    }
+    // D L' w = y: lane t holds row t of D L' (columns t + 1 ..) and 1 / d_t
+    x *= dinv;
+    sfor<0, 63>([&](auto J_) {
+      constexpr int j = 63 - decltype(J_)::value;
+      const double u = t < j ? Kr[j] * dinv : 0.0;
+      x = fma(-u, lane_of(x, j), x);
+    });
+    FB_DW_LAP(1);
+    FB_DW_LAPS_FLUSH(0);
+    return true;
+  }
+
   // x <- K^{-1} x with the factors above (P' L^{-T} D^{+} L^{-1} P of
   // dense_cholesky_solver.cc:112 with the permutation implicit in the elimination
   // order).  Lane t owns entry t.  A multiplier is zero wherever its row was no
@@ -726,11 +865,29 @@ struct DenseWave {
     if (t < nz) { rhs0 = -(rz[t] + sigma * (z[t] - zb[t])); x = rhs0 - atr; }
     else if (t < n) { rhs0 = rl[t - nz] + sigma * (l[t - nz] - lb[t - nz]); x = rhs0; }
     FB_WAVE_LAP(11);
-    int ord, permv;
-    double dpiv;
-    if (!factor(c, Kr, dg, &ord, &dpiv, &permv)) return false;
+#if FB_DW_STATIC_ORDER
+    bool solved = false;
+    {
+      // (a NaN on the diagonal - an overflowed iterate - goes straight to the pivoted
+      // path, which answers it the way Eigen does)
+      const double x0 = x;
+      if (__ballot(t < n && dg != dg) == 0ull) solved = factor_solve_static(c, Kr, x);
+      if (!solved) {
+        x = x0;
+        load_hd(t, hd);
+        assemble(c, hd, sigma, Kr, &dg, &atr);
+      }
+    }
     FB_WAVE_LAP(12);
-    x = substitute(t, x, ord, dpiv, permv);
+    if (!solved)
+#endif
+    {
+      int ord, permv;
+      double dpiv;
+      if (!factor(c, Kr, dg, &ord, &dpiv, &permv)) return false;
+      FB_WAVE_LAP(12);
+      x = substitute(t, x, ord, dpiv, permv);
+    }
     FB_WAVE_LAP(13);
     if (t < nz) dz[t] = x;
     else if (t < n) dl[t - nz] = x;

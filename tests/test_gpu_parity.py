@@ -59,7 +59,28 @@ def _solve_dense_host(hip, p, opts, guess=None):
     return z, l, v, y, out
 
 
-def _assert_parity(gpu, cpu, abs_tol, exact_frac=0.99, max_dn=2):
+def _unique_duals(dense, vc, act_tol=1e-7):
+    """Dense QPs of the batch whose multipliers are pinned by the KKT conditions: the
+    gradients of the equalities and of the active inequalities (oracle's v > 0) are
+    linearly independent.  Elsewhere (l, v) is any point of a face - FBstab returns the
+    one its proximal path runs into, which depends on the rounding of every Newton solve
+    in the directions where K's eigenvalues are of the size of sigma (cond(K) ~ 1e16):
+    the one-wavefront kernel, which eliminates in the natural order, and the oracle,
+    which pivots like Eigen, then agree in z, y and G'l + A'v but not in l and v."""
+    nz, nl, nv = dense.nz, dense.nl, dense.nv
+    B = vc.shape[0]
+    uniq = np.zeros(B, dtype=bool)
+    for i in range(B):
+        A = dense.arrays["A"][i].reshape(nz, nv).T
+        rows = [A[vc[i] > act_tol]]
+        if nl:
+            rows.append(dense.arrays["G"][i].reshape(nz, nl).T)
+        M = np.vstack(rows)
+        uniq[i] = M.shape[0] == 0 or np.linalg.matrix_rank(M, tol=1e-8) == M.shape[0]
+    return uniq
+
+
+def _assert_parity(gpu, cpu, abs_tol, exact_frac=0.99, max_dn=2, dense=None):
     zg, lg, vg, yg, og = gpu
     zc, lc, vc, yc, oc = cpu
     assert np.array_equal(og["eflag"], oc["eflag"])
@@ -67,18 +88,35 @@ def _assert_parity(gpu, cpu, abs_tol, exact_frac=0.99, max_dn=2):
     dn = np.abs(og["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
     assert dn.max() <= max_dn, dn.max()
     assert (dn == 0).mean() >= exact_frac or len(dn) < 100 and (dn != 0).sum() <= 1, (dn != 0).sum()
-    for g, c in ((zg, zc), (lg, lc), (vg, vc), (yg, yc)):
+    pinned = np.ones(zc.shape[0], dtype=bool)
+    if dense is not None:
+        # multipliers: entry by entry where they are unique, through G'l + A'v everywhere
+        pinned = _unique_duals(dense, vc)
+        nz, nl, nv = dense.nz, dense.nl, dense.nv
+        A = dense.arrays["A"].reshape(-1, nz, nv)   # A[b, k, i] = A_b[i][k]
+        img = lambda l, v: (np.einsum("bki,bi->bk", A, v) +
+                            (np.einsum("bkq,bq->bk", dense.arrays["G"].reshape(-1, nz, nl), l) if nl else 0.0))
+        ig, ic = img(lg, vg), img(lc, vc)
+        scale = 1.0 + np.abs(ic).max(axis=1, keepdims=True)
+        assert (np.abs(ig - ic) <= 10 * abs_tol * scale).all(), np.abs(ig - ic).max()
+    for g, c, sel in ((zg, zc, None), (lg, lc, pinned), (vg, vc, pinned), (yg, yc, None)):
         if c.size:
             scale = 1.0 + np.abs(c).max(axis=1, keepdims=True)
-            assert (np.abs(g - c) <= 10 * abs_tol * scale).all(), np.abs(g - c).max()
+            close = np.abs(g - c) <= 10 * abs_tol * scale
+            if sel is not None:
+                close = close[sel]
+            assert close.all(), np.abs(g - c).max()
     ok = oc["eflag"] == 0
     np.testing.assert_allclose(og["initial_residual"], oc["initial_residual"], rtol=1e-10)
     # residuals agree where they are well above the rounding floor of a
     # cancellation-dominated quantity (terms are O(1..100), eps*100 ~ 1e-14,
     # amplified by the Newton step's conditioning, cond(K) up to 1e11: a few 1e-8)
     big = ok & (oc["residual"] > 1e-7)
+    # (a different elimination order - `dense` - rounds the last step differently:
+    # a tenth of the tolerance the solve stops at)
     if big.any():
-        np.testing.assert_allclose(og["residual"][big], oc["residual"][big], rtol=2e-2, atol=3e-8)
+        np.testing.assert_allclose(og["residual"][big], oc["residual"][big], rtol=2e-2,
+                                   atol=3e-8 if dense is None else max(3e-8, 0.1 * abs_tol))
 
 
 # -- reference end-to-end tests through the C-ABI ------------------------------
@@ -319,7 +357,7 @@ def test_dense_synthetic_batch_parity(hip, oracle):
         o = default_options()
         gpu = _solve_dense_host(hip, p, o)
         cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
-        _assert_parity(gpu, cpu, o.abs_tol)
+        _assert_parity(gpu, cpu, o.abs_tol, dense=p)
         assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
@@ -333,7 +371,7 @@ def test_dense_odd_shapes(hip, oracle, shape):
     o = default_options()
     gpu = _solve_dense_host(hip, p, o)
     cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
-    _assert_parity(gpu, cpu, o.abs_tol)
+    _assert_parity(gpu, cpu, o.abs_tol, dense=p)
     assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
@@ -361,8 +399,8 @@ def test_dense_one_wavefront_kernel_is_selected_and_agrees_with_the_four_wavefro
     four = _solve_dense_host(hip, p, o)
     monkeypatch.delenv("FBSTAB_HIP_DENSE_THREADS")
     cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
-    _assert_parity(wave, cpu, o.abs_tol)
-    _assert_parity(wave, four, o.abs_tol)
+    _assert_parity(wave, cpu, o.abs_tol, dense=p)
+    _assert_parity(wave, four, o.abs_tol, dense=p)
 
 
 def test_dense_many_constraints_fall_back_to_the_four_wavefront_kernel(hip, oracle):
