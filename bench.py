@@ -342,7 +342,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=12, lanes=4):
+def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8):
     """BASELINE configs[1]: batched FBstabDense, batch 4096, nz=50 nl=10 nv=100."""
     p = fx.synthetic_dense_batch(batch, 50, 10, 100)
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}

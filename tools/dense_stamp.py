@@ -24,10 +24,12 @@ for rep in range(2):
 lib.fbstab_hip_debug_stamps(st, 1)
 tot = float(st[28]) or 1.0
 print(f"dense batch={B} kernel_ms={ms:.2f} newton mean={out['newton_iters'].mean():.2f} prox mean={out['prox_iters'].mean():.2f}")
-names = {0: "  LDL': pivot search", 1: "  LDL': pick", 2: "  LDL': column to LDS, multiplier", 3: "  LDL': trailing update",
+# (natural-order path, the default: 3 = the unrolled factorisation with the forward elimination,
+# 1 = the backward sweep; the four LDL' labels describe the pivoted fallback)
+names = {0: "  LDL': pivot search", 1: "  LDL': pick | natural order: backward sweep", 2: "  LDL': column to LDS, multiplier", 3: "  LDL': trailing update | natural order: factorisation + forward elimination",
          4: "  solve: forward loads issued", 5: "  solve: forward chain", 6: "  solve: / D, backward loads issued", 7: "  solve: backward chain",
          19: "  assembly: H into the accumulators", 20: "  assembly: MFMA loop", 21: "  assembly: tiles to rows", 22: "  assembly: G blocks",
-         9: "load_guess", 10: "pfb gradients", 11: "K assembly + rhs", 12: "LDL'", 13: "solve", 14: "dv, A dz, W",
+         9: "load_guess", 10: "pfb gradients", 11: "K assembly + rhs", 12: "LDL' (natural order: factorisation and both sweeps)", 13: "solve (pivoted fallback only)", 14: "dv, A dz, W",
          15: "residual", 16: "feasibility", 17: "norms_at (line search, loop top)", 18: "accept"}
 for k, nm in names.items():
     print(f"   {nm:34s} {100.0 * st[k] / tot:5.1f} %")

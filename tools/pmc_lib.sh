@@ -2,15 +2,19 @@
 # Developer tool (GPU box): traffic and SQ counter passes over ONE launch of the MPC
 # kernel of a build variant.  usage: tools/pmc_lib.sh <outdir> <lib.so> [batch]
 # Each pass is its own process, --pmc with --kernel-trace only, wrapped in timeout.
+# PMC_PROG="tools/dense_bench.py" takes the passes over the dense kernel instead (the last
+# dispatch of the program's solver kernel is the one reported either way).
 R=$PWD; OUT=$R/$1; export FBSTAB_HIP_LIB=$R/$2; B=${3:-8192}; mkdir -p $OUT
+PROG=${PMC_PROG:-tools/variant_bench.py}; ARGS="$B 1"; [ -n "$PMC_PROG" ] && ARGS="${PMC_ARGS:-}"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
  "SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES" \
  "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" \
- "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCC_HIT TCC_MISS TCC_REQ" ; do
+ "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCC_HIT TCC_MISS TCC_REQ" \
+ "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS" ; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --kernel-trace -d $OUT/p$i -o p -- python3 $R/tools/variant_bench.py $B 1 > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace -d $OUT/p$i -o p -- python3 $R/$PROG $ARGS > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
 cd $R
