@@ -1049,6 +1049,11 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
     const char* th = getenv("FBSTAB_HIP_DENSE_THREADS");
     if (th && atoi(th) == 256) s->wave = false;
     if (th && atoi(th) == 64 && nz + nl <= 64) { s->threads = 64; s->wave = false; }
+    // FBSTAB_HIP_DENSE_PIVOTED=1: the one-wavefront kernel factors by Eigen's pivoting
+    // rule every time instead of in the natural order (same systems, the reference's
+    // rounding: 1.5 x the time of a launch on BASELINE configs[1])
+    const char* pv = getenv("FBSTAB_HIP_DENSE_PIVOTED");
+    s->wlay.pivoted = (pv && atoi(pv) != 0) ? 1 : 0;
   }
   s->lay.init(nz, nl, nv, s->threads);
   if (s->threads == 64 && (s->lay.k_global || !s->lay.a_lds)) {  // does not fit that way
