@@ -257,6 +257,12 @@ int fbstab_hip_mpc_receding_sweep_sharded(fbstab_shard_group_t group, const fbst
                                           unsigned long long* stats);
 
 /* ---- dense -------------------------------------------------------------- */
+/* Environment read by fbstab_hip_dense_create (developer / comparison switches; the defaults
+ * are what is benchmarked):
+ *   FBSTAB_HIP_DENSE_PIVOTED=1   nz + nl <= 64: factor by Eigen's pivoting rule
+ *                                (dense_cholesky_solver.cc:70-79) every time instead of in the
+ *                                natural order - the reference's rounding, 1.6 x the time
+ *   FBSTAB_HIP_DENSE_THREADS=256 the four-wavefront kernel (always pivoted) for every shape */
 int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
                             fbstab_dense_handle_t* handle);
 int fbstab_hip_dense_destroy(fbstab_dense_handle_t handle);
