@@ -375,6 +375,21 @@ struct MpcR16 {
     N = N_;
     pend_t = 0.0;
   }
+  // A row that never gets a QP (batch < row slots of the grid) still takes part in the
+  // cooperative passes of its wavefront - with its own LDS region as scratch
+  // (close_subproblem_coop) - so what those read is set before the first fetch.
+  FB_DEV void bind_idle(lds_ptr lds_row, lds_iptr lpo_row, int N_) {
+    lds_off = -1;
+    poff = nullptr;
+    lpo = lpo_row;
+    pack = rec = nullptr;
+    lds = lds_row;
+    data = nullptr;
+    var = nullptr;
+    q = -1;
+    N = N_;
+    pend_t = 0.0;
+  }
   FB_DEV int num_primal_dual() const { return (N + 1) * (2 * prob_nx() + prob_nu() + prob_nc()); }
 
   // ---- record access -------------------------------------------------------------
@@ -521,10 +536,43 @@ struct MpcR16 {
     sfor<0, NSP>([&](auto Cc_) { lastKr[decltype(Cc_)::value] = lastABr[decltype(Cc_)::value] = 0.0; });
     sfor<0, NC>([&](auto Kk) { lastCc[decltype(Kk)::value] = 0.0; });
     sfor<0, NX>([&](auto J) { lastABc[decltype(J)::value] = 0.0; });
+    // The stage's vectors from the caller's arrays (f, h, the guess, b, v): requested a
+    // stage AHEAD.  Behind the matrix loads, the comparison and the stores of their own
+    // stage - the compiler may not move a load of the caller's memory above a store to
+    // the records - they were three more trips to memory per stage, one after the other
+    // (f h; z l; b v), in a pass that has nothing to cover a trip with.
+    struct Small {
+      double f, h, zz, ll, b[KS], vv[KS];
+    };
+    auto load_small = [&](int i, Small& sm) {
+      sm.f = rx ? pq[(long)i * nx_ + r] : (rin ? pr[(long)i * nu_ + ru] : 0.0);
+      sm.h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * nx_ + r]) : 0.0;
+      sm.zz = rx ? uz[(long)i * (nx_ + nu_) + r] : (rin ? uz[(long)i * (nx_ + nu_) + nx_ + ru] : 0.0);
+      sm.ll = rx ? ul[(long)i * nx_ + r] : 0.0;
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const int k = r + LPQ * sl;
+        const bool real = k < NC && k < nc_;
+        sm.b[sl] = real ? -pd[(long)i * nc_ + k] : 0.0;
+        sm.vv[sl] = real ? uv[(long)i * nc_ + k] : 0.0;
+      });
+    };
+#ifndef FB_R16_LOAD_AHEAD
+#define FB_R16_LOAD_AHEAD 0
+#endif
+    [[maybe_unused]] Small nxt_small;
+    if constexpr (FB_R16_LOAD_AHEAD != 0) load_small(0, nxt_small);
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
       double* PK = P0 + (long)i * kPack;
       const bool has_ab = i < N_;
+      Small sm;
+      if constexpr (FB_R16_LOAD_AHEAD != 0) {
+        sm = nxt_small;
+        if (i < N_) load_small(i + 1, nxt_small);
+      } else {
+        load_small(i, sm);  // (at the top of their own stage, with the matrix loads)
+      }
       double Cc[NC];
       bool fresh = true;
       if constexpr (KEEP) fresh = !reuse;
@@ -608,12 +656,9 @@ struct MpcR16 {
       }
       lds_off = -1;
       // constants f, h, b (mpc_data.cc:240-289)
-      const double f = rx ? pq[(long)i * nx_ + r] : (rin ? pr[(long)i * nu_ + ru] : 0.0);
-      const double h = rx ? (i == 0 ? -px0[r] : -pc[(long)(i - 1) * nx_ + r]) : 0.0;
-      st2(R, sF, f, h);
+      st2(R, sF, sm.f, sm.h);
       // the guess and y = b - A z
-      const double zz = rx ? uz[(long)i * (nx_ + nu_) + r] : (rin ? uz[(long)i * (nx_ + nu_) + nx_ + ru] : 0.0);
-      const double ll = rx ? ul[(long)i * nx_ + r] : 0.0;
+      const double zz = sm.zz, ll = sm.ll;
       st2(R, sZ, zz, 0.0);
       st2(R, sL, ll, 0.0);
       st2(R, sDZ, 0.0, 0.0);
@@ -625,8 +670,7 @@ struct MpcR16 {
         constexpr int s = decltype(S_)::value;
         const int k = r + LPQ * s;
         const bool real = valid && k < nc_;
-        const double b = real ? -pd[(long)i * nc_ + k] : 0.0;
-        const double vv = real ? uv[(long)i * nc_ + k] : 0.0;
+        const double b = sm.b[s], vv = sm.vv[s];
         st(R, sB + s, b);
         st2(R, sV + 2 * s, vv, real ? b - az : 0.0);
         st2(R, sDV + 2 * s, 0.0, 0.0);

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
     qu.sweep = reinterpret_cast<const SweepArgs*>(dbg);
     qu.out = out;
   }
+  p.bind_idle(qu.lds(), qu.lpo(), N);
   if constexpr (DBG) {
     if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
