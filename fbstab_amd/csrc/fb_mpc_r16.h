@@ -571,7 +571,9 @@ struct MpcR16 {
         sm = nxt_small;
         if (i < N_) load_small(i + 1, nxt_small);
       } else {
-        load_small(i, sm);  // (at the top of their own stage, with the matrix loads)
+        load_small(i, sm);  // (at the top of their own stage, with the matrix loads: 531 k QP/s
+                            //  against 519 k with the loads where they were and 480 k with
+                            //  them a stage ahead, gpurun_out/r03_ai)
       }
       double Cc[NC];
       bool fresh = true;
@@ -863,9 +865,11 @@ struct MpcR16 {
   // No step is pending here (the Newton step's forward sweep applied it).
   // The pass proper is a real call (trial_pass_coop, not inlined): it takes nothing but
   // scalars, so the policy object stays in registers; inlined into the solver loop the
-  // exact <12,4,32> instance came out of the compiler finishing every QP at its first
-  // convergence test (any other change of the surrounding code made it right again - the
-  // cause was not found; tests/test_gpu_parity.py runs every instance, exact and padded).
+  // exact <12,4,32> instance came out finishing every QP at its first convergence test
+  // (any other change of the surrounding code made it right again; round 3 traced that
+  // kind of failure to rows that join these passes with a policy object no fetch has
+  // bound yet - bind_idle() - see profiles/r03_q_coop_inline_miscompile_notes.txt;
+  // tests/test_gpu_parity.py runs every instance, exact and padded).
 #ifndef FB_R16_COOP_TRIALS
 #define FB_R16_COOP_TRIALS 1
 #endif
@@ -1618,6 +1622,10 @@ struct MpcR16 {
     const int nx_ = prob_nx(), nu_ = prob_nu(), nc_ = prob_nc();
     const double* const R0 = rec;
     double *uz = xarr(0), *ul = xarr(1), *uv = xarr(2), *uy = xarr(3);
+    // (Measured and dropped, gpurun_out/r03_am: all record slots of a stage - and of two
+    // stages - requested before the first store to the caller's arrays, as in load_guess:
+    // 518 k against 520 k QP/s.  The stores here are fire-and-forget and the next stage's
+    // loads do not wait for them.)
     for (int i = 0; i <= N_; i++) {
       const double* R = R0 + (long)i * kRec;
       const double zz = ld(R, WHICH == 0 ? sZ : (WHICH == 1 ? sZB : sDZ));
