@@ -351,6 +351,22 @@ def test_up_to_32_constraint_rows_per_stage_run_on_a_record_kernel(hip, oracle):
         _assert_parity(gpu, cpu, o.abs_tol)
 
 
+@pytest.mark.parametrize("batch", [1, 2, 3, 5, 7])
+def test_rows_that_never_get_a_qp_join_the_cooperative_passes(hip, oracle, batch):
+    """Batches that leave rows of a wavefront without a QP from the start (one 16-lane row
+    per QP, four rows per wavefront): those rows still take part in the cooperative
+    line-search, open_prox and close_subproblem passes of their wavefront.  Their policy
+    objects used to be unbound there (indeterminate members: the failures of the <12,4,32>
+    instance that came and went with unrelated changes); both
+    16-lane instances, BASELINE plant with 20 and with 32 constraint rows per stage."""
+    o = default_options()
+    for p in (fx.synthetic_mpc_batch(batch, first_id=40 + batch), fx.boxed_mpc_batch(batch)):
+        gpu = _solve_mpc_host(hip, p, o)
+        cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+        _assert_parity(gpu, cpu, o.abs_tol)
+        assert (cpu[4]["eflag"] == 0).all() and (cpu[4]["newton_iters"] > 3).all()
+
+
 def test_dense_synthetic_batch_parity(hip, oracle):
     for (nz, nl, nv, B) in ((20, 5, 40, 64), (50, 10, 100, 256)):
         p = fx.synthetic_dense_batch(B, nz, nl, nv)

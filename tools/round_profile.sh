@@ -8,6 +8,7 @@ if [ -f fbstab_amd/var_stamp.so ]; then
   tail -8 $O/mpc_wave_time_shares.txt; tail -24 $O/dense_wave_time_shares.txt
 fi
 bash tools/pmc_lib.sh $O/pmc_mpc fbstab_amd/libfbstab_hip.so 8192 > $O/pmc_mpc.log 2>&1; tail -1 $O/pmc_mpc.log | cut -c1-400
+PMC_PROG=tools/dense_bench.py bash tools/pmc_lib.sh $O/pmc_dense fbstab_amd/libfbstab_hip.so > $O/pmc_dense.log 2>&1; tail -1 $O/pmc_dense.log | cut -c1-300
 timeout 600 python bench.py > $O/bench_line.json 2> $O/bench_line.err; tail -c 300 $O/bench_line.err
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s -- python3 $R/bench.py --cpu-sample 0 --extras 0 > $R/$O/bench_under_rocprof.json 2> $R/$O/bench_under_rocprof.err)
 python3 tools/rocpd_summary.py stats $O/stats/s_results.db $O/kernel_stats_pipelined_bench.csv 2>/dev/null; rm -rf $O/stats; head -5 $O/kernel_stats_pipelined_bench.csv
