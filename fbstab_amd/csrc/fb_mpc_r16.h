@@ -903,15 +903,30 @@ struct MpcR16 {
     sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
     const bool rx = r < NX;
     auto stage_ptr = [&](int i) { return R0 + (long)(i < N_ ? i : N_) * kRec; };
+    // (The slots of a trip are requested a trip ahead - this pass stores nothing.  At the top
+    // of their own trip, FB_R16_TRIAL_AHEAD=0: 485 k against 533 k QP/s, gpurun_out/r03_ap;
+    // two trips ahead: -6 %, round 2.  In the passes that also STORE records - open, close,
+    // the packing pass - every form of requesting ahead has lost, see open_pass_coop.)
+#ifndef FB_R16_TRIAL_AHEAD
+#define FB_R16_TRIAL_AHEAD 1
+#endif
     TrialIn in;
     double wln_in;  // WLN of the stage below (stage 0: unused)
-    load_trial(stage_ptr(q), in);
-    wln_in = ld(stage_ptr(q > 0 ? q - 1 : 0), sWLN);
+    if constexpr (FB_R16_TRIAL_AHEAD != 0) {
+      load_trial(stage_ptr(q), in);
+      wln_in = ld(stage_ptr(q > 0 ? q - 1 : 0), sWLN);
+    }
     for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
+      if constexpr (FB_R16_TRIAL_AHEAD == 0) {
+        load_trial(stage_ptr(i), in);
+        wln_in = ld(stage_ptr(i > 0 ? i - 1 : 0), sWLN);
+      }
       const TrialIn cu = in;
       const double wlp = wln_in;
-      load_trial(stage_ptr(i + QW), in);
-      wln_in = ld(stage_ptr(i + QW - 1), sWLN);
+      if constexpr (FB_R16_TRIAL_AHEAD != 0) {
+        load_trial(stage_ptr(i + QW), in);
+        wln_in = ld(stage_ptr(i + QW - 1), sWLN);
+      }
       const bool live = i <= N_;
       const double wl = wl_of_stage(i, rx, cu.dw[0], wlp);
       sfor<0, K>([&](auto Kk) {
@@ -1319,7 +1334,10 @@ struct MpcR16 {
     // What a trip reads, all of it requested at the top of the trip.  (Measured and dropped,
     // gpurun_out/r03_s, r03_t: the record part requested a trip ahead, 478 k against 518 k
     // QP/s - like every other attempt to put more loads in flight in this kernel -, and the
-    // matrix rows a trip ahead as well: the 64 doubles went to scratch memory, 330 k.)
+    // matrix rows a trip ahead as well: the 64 doubles went to scratch memory, 330 k.
+    // gpurun_out/r03_ao: the next trip's record slots requested between this trip's
+    // arithmetic and its stores - ahead of the stores in the memory queue, held in registers
+    // across the stores only - in this pass and in close_pass_coop: 485 k against 533 k.)
     struct In {
       dbl2 fh, vy[KS];
       double zz, ll, zn, ln, hn;
