@@ -23,6 +23,8 @@
 // function; scalar results are workgroup-uniform.
 #pragma once
 
+#include <type_traits>
+
 #include "fb_common.h"
 
 // Step lengths evaluated per line-search pass (build knob).
@@ -59,6 +61,12 @@ struct TraceArg<true> {
   double* p;
   FB_DEV double* get() const { return p; }
 };
+
+// policies that pack a QP as a cooperative pass (P::kCoopLoad, P::load_guess_coop)
+template <class P, class = void>
+struct coop_load_of : std::false_type {};
+template <class P>
+struct coop_load_of<P, typename std::enable_if<P::kCoopLoad>::type> : std::true_type {};
 
 template <class P, class C, bool TRACE = false>
 struct Solver : TraceState<TRACE> {
@@ -458,7 +466,7 @@ struct Solver : TraceState<TRACE> {
     // close_subproblem pass and yields; the wavefront runs the pass for it with ALL its rows
     // (below) and the row goes on at kAfterOpen / kAfterClose.
     enum { kFetch = 0, kProxTop = 1, kInnerTop = 2, kEpilogue = 3, kNewton = 4, kDone = 5, kPause = 6,
-           kWantOpen = 7, kWantClose = 8, kAfterOpen = 9, kAfterClose = 10 };
+           kWantOpen = 7, kWantClose = 8, kAfterOpen = 9, kAfterClose = 10, kWantLoad = 11, kAfterLoad = 12 };
     int phase = kFetch;
     fbstab_solver_out_t* out = out_base;
     const double sigma = o.sigma0;
@@ -470,10 +478,12 @@ struct Solver : TraceState<TRACE> {
     // line-search trial passes run by all rows of the wavefront for one of them at a time
     constexpr bool kCoop = P::kCoopTrials && !Queue::kCanAlignRows;
     constexpr bool kCoopP = kCoop && P::kCoopProx;
+    constexpr bool kCoopL = kCoopP && coop_load_of<P>::value;  // load_guess as a cooperative pass too
     [[maybe_unused]] bool fresh = false;   // (kCoopP) the open_prox asked for is the first of its QP
     [[maybe_unused]] int feas_c = kFeasible;  // (kCoopP) verdict of the close pass served last
     for (;;) {
-      while (phase != kNewton && phase != kDone && phase != kPause && phase != kWantOpen && phase != kWantClose) {
+      while (phase != kNewton && phase != kDone && phase != kPause && phase != kWantOpen && phase != kWantClose &&
+             phase != kWantLoad) {
         if (phase == kFetch) {
           if constexpr (Queue::kCanAlignRows) {
             if (qu.align_rows() && !fetch_now) {
@@ -489,6 +499,10 @@ struct Solver : TraceState<TRACE> {
           }
           out = out_base + q;
           combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
+          if constexpr (kCoopL) {
+            phase = kWantLoad;
+            continue;
+          }
           p.load_guess(c);
           p.choose_costate_form(sigma);
           dx_norm = sqrt((double)p.num_primal_dual());
@@ -510,6 +524,12 @@ struct Solver : TraceState<TRACE> {
           }
           inner_tol = sat(E0, o.inner_tol_min, o.inner_tol_max);
           phase = kProxTop;
+        } else if (phase == kAfterLoad) {
+          // (kCoopL) the wavefront has packed this row's QP
+          p.choose_costate_form(sigma);
+          dx_norm = sqrt((double)p.num_primal_dual());
+          fresh = true;
+          phase = kWantOpen;
         } else if (phase == kAfterOpen) {
           // (kCoopP) the wavefront has run this row's open_prox pass: Ek, Ei0 are in
           if (fresh) {
@@ -626,8 +646,18 @@ struct Solver : TraceState<TRACE> {
         // wavefront for one of them (P::close_subproblem_coop / open_prox_coop); the rows that
         // stand before a Newton step wait for them - with their lanes at work
         unsigned long long wc = __ballot(phase == kWantClose), wo = __ballot(phase == kWantOpen);
-        if ((wc | wo) != 0ull) {
+        unsigned long long wl = 0ull;
+        if constexpr (kCoopL) wl = __ballot(phase == kWantLoad);
+        if ((wc | wo | wl) != 0ull) {
           constexpr unsigned long long kRowMask = (C::nt == 64) ? ~0ull : ((1ull << C::nt) - 1ull);
+          if constexpr (kCoopL) {
+            while (wl != 0ull) {
+              const int owner = __builtin_ctzll(wl);
+              p.load_guess_coop(owner);
+              if (((threadIdx.x ^ owner) & 63 & ~(C::nt - 1)) == 0) phase = kAfterLoad;
+              wl &= ~(kRowMask << (owner & ~(C::nt - 1)));
+            }
+          }
           while (wc != 0ull) {
             const int owner = __builtin_ctzll(wc);
             double dxn;

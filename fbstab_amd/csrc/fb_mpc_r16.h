@@ -1631,6 +1631,213 @@ struct MpcR16 {
     return kBothInfeasible;
   }
 
+  // ---- load_guess() for the owner's QP, run by all rows (FB_R16_COOP_LOAD) ---------------
+  // Row q packs stages q, q + QW, ...: the stage's matrices and vectors from the caller's
+  // arrays, its records, y = b - A z.  Whether a stage shares the matrix copy of the stage
+  // before it is decided by reading that stage's matrices as well (the sequential pass
+  // carries them from stage to stage); the offsets of the copies in use - "this stage's own"
+  // or "whatever the stage before uses" - follow from one scan over the stages afterwards.
+#ifndef FB_R16_COOP_LOAD
+#define FB_R16_COOP_LOAD 1
+#endif
+  static constexpr bool kCoopLoad = FB_R16_COOP_LOAD != 0 && kCoopProx && !KEEP;
+  struct LoadSums {
+    double c2m, hm;
+    bool single;
+  };
+  static __device__ __attribute__((noinline)) LoadSums load_pass_coop(double* R0, double* P0, int* pog, lds_iptr lp,
+                                                                      lds_ptr Cl, const MpcBatchPtrs* data,
+                                                                      const VarBatchPtrs* var, long qp, int N_,
+                                                                      int nx_, int nu_, int nc_) {
+    constexpr int QW = kQpPerWave;
+    const int lane = threadIdx.x & 63;
+    const int qr = lane / LPQ, r = lane & (LPQ - 1);
+    const int ru = r - NX;
+    const bool rx = r < nx_;
+    const bool rin = r >= NX && ru < nu_;
+    const bool rs_ = rx || rin;
+    auto arr_ = [&](int a) { return data->base[a] + qp * data->stride[a]; };
+    const double *Q = arr_(FBSTAB_MPC_Q), *Rm = arr_(FBSTAB_MPC_R), *S = arr_(FBSTAB_MPC_S), *pq = arr_(FBSTAB_MPC_q),
+                 *pr = arr_(FBSTAB_MPC_r), *A = arr_(FBSTAB_MPC_A), *B = arr_(FBSTAB_MPC_B), *pc = arr_(FBSTAB_MPC_c),
+                 *E = arr_(FBSTAB_MPC_E), *L = arr_(FBSTAB_MPC_L), *pd = arr_(FBSTAB_MPC_d), *px0 = arr_(FBSTAB_MPC_x0);
+    const double *uz = var->base[0] + qp * var->stride[0], *ul = var->base[1] + qp * var->stride[1],
+                 *uv = var->base[2] + qp * var->stride[2];
+    C cc_;
+    cc_.tid = r;
+    bool single = true;
+    double c2m = 0.0, hm = 0.0;
+    struct Mats {
+      double Kr[NSP], ABr[NSP], Cc[NC], ABc[NX];
+    };
+    auto load_mats = [&](int i, Mats& m) {
+      const bool has_ab = i < N_;
+      sfor<0, NSP>([&](auto Cc_) {
+        constexpr int cc = decltype(Cc_)::value;
+        double kv = 0.0, ab = 0.0;
+        if constexpr (cc < NX) {
+          if (cc < nx_) {  // a real state column
+            if (rx) kv = Q[(long)i * nx_ * nx_ + r + cc * nx_];
+            else if (rin) kv = S[(long)i * nu_ * nx_ + ru + cc * nu_];
+            if (rx && has_ab) ab = A[(long)i * nx_ * nx_ + r + cc * nx_];
+          }
+        } else if constexpr (cc < NS) {
+          if (cc - NX < nu_) {  // a real input column
+            if (rx) kv = S[(long)i * nu_ * nx_ + (long)r * nu_ + (cc - NX)];
+            else if (rin) kv = Rm[(long)i * nu_ * nu_ + ru + (cc - NX) * nu_];
+            if (rx && has_ab) ab = B[(long)i * nx_ * nu_ + r + (cc - NX) * nx_];
+          }
+        }
+        m.Kr[cc] = kv;
+        m.ABr[cc] = ab;
+      });
+      {
+        const double* src = rx ? E + ((long)i * nx_ + r) * nc_ : L + ((long)i * nu_ + (rin ? ru : 0)) * nc_;
+        sfor<0, NC>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          m.Cc[k] = (rs_ && k < nc_) ? src[k] : 0.0;
+        });
+      }
+      {
+        const double* src = rx ? A + (long)i * nx_ * nx_ + (long)r * nx_
+                               : B + (long)i * nx_ * nu_ + (long)(rin ? ru : 0) * nx_;
+        sfor<0, NX>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          m.ABc[j] = (rs_ && has_ab && j < nx_) ? src[j] : 0.0;
+        });
+      }
+    };
+    for (int i = qr; i - qr <= N_; i += QW) {  // (the same trip count in every row)
+      const bool live = i <= N_;
+      const int ii = live ? i : N_;
+      double* R = R0 + (long)ii * kRec;
+      double* PK = P0 + (long)ii * kPack;
+      // the stage's vectors, with the matrix loads (see load_guess)
+      const double f = rx ? pq[(long)ii * nx_ + r] : (rin ? pr[(long)ii * nu_ + ru] : 0.0);
+      const double h = rx ? (ii == 0 ? -px0[r] : -pc[(long)(ii - 1) * nx_ + r]) : 0.0;
+      const double zz = rx ? uz[(long)ii * (nx_ + nu_) + r] : (rin ? uz[(long)ii * (nx_ + nu_) + nx_ + ru] : 0.0);
+      const double ll = rx ? ul[(long)ii * nx_ + r] : 0.0;
+      double bs[KS], vs[KS];
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const int k = r + LPQ * sl;
+        const bool real = k < NC && k < nc_;
+        bs[sl] = real ? -pd[(long)ii * nc_ + k] : 0.0;
+        vs[sl] = real ? uv[(long)ii * nc_ + k] : 0.0;
+      });
+      Mats m, mp;
+      load_mats(ii, m);
+      load_mats(ii > 0 ? ii - 1 : 0, mp);
+      {
+        const int rowsh = LPQ * qr;
+        double c2 = 0.0, hs = 0.0;
+        bool sg = true;
+        sfor<0, NC>([&](auto Kk) {
+          const unsigned long long mk = __ballot(m.Cc[decltype(Kk)::value] != 0.0);
+          sg = sg && __popc((unsigned)(mk >> rowsh) & (unsigned)((1ull << LPQ) - 1ull)) <= 1;
+          c2 = fma(m.Cc[decltype(Kk)::value], m.Cc[decltype(Kk)::value], c2);
+        });
+        sfor<0, NSP>([&](auto Cc_) { hs += fabs(m.Kr[decltype(Cc_)::value]); });
+        if (live) {
+          single = single && sg;
+          c2m = fmax(c2m, c2);
+          hm = fmax(hm, hs);
+        }
+      }
+      bool differs = ii == 0;
+      sfor<0, NSP>([&](auto Cc_) {
+        constexpr int cc = decltype(Cc_)::value;
+        differs = differs || !(m.Kr[cc] == mp.Kr[cc]) || !(m.ABr[cc] == mp.ABr[cc]);
+      });
+      sfor<0, NC>([&](auto Kk) { differs = differs || !(m.Cc[decltype(Kk)::value] == mp.Cc[decltype(Kk)::value]); });
+      sfor<0, NX>([&](auto J) { differs = differs || !(m.ABc[decltype(J)::value] == mp.ABc[decltype(J)::value]); });
+      const bool own_copy = qp_reduce<RQ, OpMax16>(differs ? 1.0 : 0.0) > 0.0;
+      double zb[NS];
+      bc_all<NS, RQ>(zz, zb);
+      cc_.sync();
+      sfor<0, NC>([&](auto Kk) { Cl[r * CS + decltype(Kk)::value] = m.Cc[decltype(Kk)::value]; });
+      cc_.sync();
+      double az[KS];
+      sfor<0, KS>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        const int k = r + LPQ * sl;
+        const int kk = k < NC ? k : 0;
+        double clk[NS];
+        sfor<0, NS>([&](auto Cc2) { clk[decltype(Cc2)::value] = Cl[decltype(Cc2)::value * CS + kk]; });
+        az[sl] = dot4<NS>(clk, zb);
+      });
+      if (live) {
+        if (own_copy) {
+          stv<pK, NSP>(PK, m.Kr);
+          stv<pABr, NSP>(PK, m.ABr);
+          stv<pC, NC>(PK, m.Cc);
+          stv<pABc, NX>(PK, m.ABc);
+        }
+        if (r == 0) lp[ii] = own_copy ? ii * kPack : -1;
+        st2(R, sF, f, h);
+        st2(R, sZ, zz, 0.0);
+        st2(R, sL, ll, 0.0);
+        st2(R, sDZ, 0.0, 0.0);
+        st2(R, sDL, 0.0, 0.0);
+        sfor<0, KS>([&](auto S_) {
+          constexpr int sl = decltype(S_)::value;
+          const int k = r + LPQ * sl;
+          const bool real = k < NC && k < nc_;
+          st(R, sB + sl, bs[sl]);
+          st2(R, sV + 2 * sl, vs[sl], real ? bs[sl] - az[sl] : 0.0);
+          st2(R, sDV + 2 * sl, 0.0, 0.0);
+        });
+      }
+    }
+    LoadSums o;
+    o.c2m = rows_max(c2m);
+    o.hm = rows_max(hm);
+    o.single = rows_max(single ? 0.0 : 1.0) == 0.0;
+    // the copy each stage reads: its own, or the one the stage before it reads
+    cc_.sync();
+    if (lane == 0) {
+      int prev = 0;
+      for (int i = 0; i <= N_; i++) {
+        int v = lp[i];
+        if (v < 0) v = prev;
+        lp[i] = v;
+        pog[i] = v;
+        prev = v;
+      }
+      pog[N_ + 1] = o.single ? 1 : 0;
+      pog[N_ + 2] = __float_as_int((float)o.c2m);
+      pog[N_ + 3] = __float_as_int((float)o.hm);
+    }
+    cc_.sync();
+    return o;
+  }
+  // every lane of the wavefront calls this; the owner's row is left as load_guess() leaves it
+  FB_DEV void load_guess_coop(int owner) {
+    FB_WAVE_TIMER(19);
+    pass_fence();
+    const OwnerView ov = owner_view(owner);
+    const int own0 = owner & ~(LPQ - 1);
+    auto lane64 = [&](unsigned long long x) {
+      return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(x >> 32), own0) << 32) |
+             (unsigned)__builtin_amdgcn_readlane((int)x, own0);
+    };
+    const int r2 = 2 * (threadIdx.x & (LPQ - 1));
+    double* P0w = reinterpret_cast<double*>(lane64((unsigned long long)pack)) + r2;
+    int* pog = reinterpret_cast<int*>(lane64((unsigned long long)poff));
+    const MpcBatchPtrs* d = reinterpret_cast<const MpcBatchPtrs*>(lane64((unsigned long long)data));
+    const VarBatchPtrs* x = reinterpret_cast<const VarBatchPtrs*>(lane64((unsigned long long)var));
+    const long qp = (long)lane64((unsigned long long)q);
+    const int nx_ = EXACT ? NX : d->nx, nu_ = EXACT ? NU : d->nu, nc_ = EXACT ? NC : d->nc;
+    const LoadSums o = load_pass_coop(ov.R0, P0w, pog, ov.po, lds + kPackLds, d, x, qp, ov.N, nx_, nu_, nc_);
+    pass_fence();
+    if (((threadIdx.x ^ owner) & 63 & ~(LPQ - 1)) == 0) {
+      pend_t = 0.0;
+      lds_off = -1;
+      cmax2 = (float)o.c2m;
+      hmax = (float)o.hm;
+      bounds = o.single;
+    }
+  }
+
   // ---- results ---------------------------------------------------------------------
   // which: 0 = x, 1 = xbar, 2 = certificate dx with dx.y = y - ybar + b
   // (impl:202-210, full_variable.cc:55-65)
