@@ -53,7 +53,9 @@ namespace fbk {
 
 // Sub-phase cycles of the factorisation loop (diagnostic builds): summed in registers,
 // one atomic per factorisation (an atomic per lap would be most of what is measured).
-#if defined(FB_STAMP) || defined(FB_CLOCKSTAMP)
+// (-DFB_DW_NO_INNER_LAPS keeps the phase laps of newton_step only: the laps inside the unrolled
+// factorisation cost it registers, tools/dense_variant.sh var_dstamp -DFB_CLOCKSTAMP -DFB_DW_NO_INNER_LAPS)
+#if (defined(FB_STAMP) || defined(FB_CLOCKSTAMP)) && !defined(FB_DW_NO_INNER_LAPS)
 #define FB_DW_LAPS_DECL long long dw_acc_[4] = {0, 0, 0, 0}; long long dw_t_ = __builtin_readcyclecounter()
 #define FB_DW_LAP(i) do { const long long n_ = __builtin_readcyclecounter(); dw_acc_[i] += n_ - dw_t_; dw_t_ = n_; } while (0)
 #define FB_DW_LAPS_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 4; i_++) atomicAdd(&g_stamps[(base) + i_], (unsigned long long)dw_acc_[i_]); } while (0)
