@@ -245,7 +245,9 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
     qu.sweep = reinterpret_cast<const SweepArgs*>(dbg);
     qu.out = out;
   }
+#if !defined(FB_R16_NO_BIND_IDLE)  // (the switch exists to show what the rows' unbound policy objects did: DESIGN.md section 7)
   p.bind_idle(qu.lds(), qu.lpo(), N);
+#endif
   if constexpr (DBG) {
     if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
   } else {
