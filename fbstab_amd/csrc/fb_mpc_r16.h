@@ -699,8 +699,11 @@ struct MpcR16 {
 
   // Which form of the costate step this QP's backward sweeps take (see `rowdl`); called
   // once per QP, after load_guess().
+#ifndef FB_R16_ROW_COSTATE
+#define FB_R16_ROW_COSTATE 1  // 0: every QP takes the reference's form (a) - to tell the two apart in a comparison
+#endif
   FB_DEV void choose_costate_form(double sigma) {
-    rowdl = bounds && cmax2 <= 4.f && (double)hmax * sigma <= 1.0;
+    rowdl = FB_R16_ROW_COSTATE != 0 && bounds && cmax2 <= 4.f && (double)hmax * sigma <= 1.0;
   }
 
   // Natural residual blocks at x: rz = Hz + f + G'l + A'v, rl = h - Gz

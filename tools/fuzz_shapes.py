@@ -35,5 +35,10 @@ for it in range(n):
     dz = float(np.abs(z - c[0])[good].max()) if good.any() else 0.0
     flag = "" if (okf and dn.max() <= 2 and dz < 1e-4) else "  <-- CHECK"
     bad += flag != ""
+    if flag:
+        print("   device: eflag", out["eflag"].tolist(), "prox", out["prox_iters"].tolist(), "newton", out["newton_iters"].tolist(),
+              "residual", [f"{r:.2e}" for r in out["residual"]])
+        print("   oracle: eflag", oc["eflag"].tolist(), "prox", oc["prox_iters"].tolist(), "newton", oc["newton_iters"].tolist(),
+              "residual", [f"{r:.2e}" for r in oc["residual"]])
     print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e}{flag}")
 print("shapes to check:", bad)
