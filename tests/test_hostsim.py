@@ -50,3 +50,49 @@ def test_synthetic_workloads_through_device_logic(hostsim, oracle):
     d = fx.synthetic_dense_batch(24, 50, 10, 100)
     for o in (default_options(), default_options(check_feasibility=0, nonmonotone_linesearch=0)):
         _same(hostsim.solve_dense(d, opts=o), oracle.solve_dense(d, opts=o), o.abs_tol)
+
+
+def test_natural_order_elimination_of_the_dense_kkt_matrix():
+    """The one-wavefront dense kernel factors K = [E G'; G -sigma I] in the NATURAL order and
+    eliminates the right-hand side along with the matrix (fb_dense_wave.h,
+    factor_solve_static): step k scales column k by 1/d_k, updates the columns behind it and
+    the right-hand side; what step k leaves in row k - d_k and row k of D L' - serves the
+    backward sweep, every row taking its own dot product.  Same statements here in numpy, on
+    quasi-definite matrices of the kind the Newton step assembles (sigma = 1.5e-8, Gamma up
+    to 1/sigma), against numpy's pivoted LU: the natural order needs no pivoting for them."""
+    rng = np.random.default_rng(5)
+    for (nz, nl, nv) in ((50, 10, 100), (30, 20, 64), (7, 0, 9), (48, 16, 131)):
+        sigma = 1.5e-8
+        M = rng.standard_normal((nz, nz))
+        H = M @ M.T / nz
+        A = rng.standard_normal((nv, nz))
+        G = rng.standard_normal((nl, nz))
+        gam = np.where(rng.random(nv) < 0.3, 1.0 / sigma, rng.random(nv))
+        n = nz + nl
+        K = np.zeros((n, n))
+        K[:nz, :nz] = H + sigma * np.eye(nz) + A.T @ (gam[:, None] * A)
+        K[nz:, :nz] = G
+        K[:nz, nz:] = G.T
+        K[nz:, nz:] = -sigma * np.eye(nl)
+        b = rng.standard_normal(n)
+        Kr, x = K.copy(), b.copy()          # row t of Kr <-> lane t
+        dinv = np.zeros(n)
+        for k in range(n):
+            d = Kr[k, k]
+            assert abs(d) > 0 and np.isfinite(d)
+            dinv[k] = 1.0 / d
+            col = Kr[:, k].copy()           # K[t][k] = K[k][t]: the pivot row, by symmetry
+            nlm = np.where(np.arange(n) > k, -col * dinv[k], 0.0)
+            x += nlm * x[k]
+            Kr[:, k + 1:] += np.outer(nlm, col[k + 1:])
+        x *= dinv                           # D L' w = y, row t holds row t of D L' in columns t+1..
+        for j in range(n - 1, 0, -1):
+            u = np.where(np.arange(n) < j, Kr[:, j] * dinv, 0.0)
+            x -= u * x[j]
+        # (cond(K) up to 1e17 where the active rows and the equalities together outnumber the
+        # variables: what an elimination can promise is a small residual, in the norm)
+        ref = np.linalg.solve(K, b)
+        bound = lambda v: 1e-12 * (np.abs(K).sum(axis=1).max() * np.abs(v).max() + np.abs(b).max())
+        assert np.abs(K @ x - b).max() <= bound(x)
+        assert np.abs(K @ ref - b).max() <= bound(ref)
+        assert np.sign(np.diag(Kr)[:nz]).min() > 0 and (nl == 0 or np.sign(np.diag(Kr)[nz:]).max() < 0)
