@@ -736,7 +736,7 @@ struct DenseWave {
     double r;
     pivot(std::integral_constant<int, 0>{}, r);
     FB_DW_LAPS_DECL;
-    sfor<0, 63>([&](auto K_) {
+    auto step = [&](auto K_) {
       constexpr int k = decltype(K_)::value;
       const double colk = Kr[k];  // K[t][k] = K[k][t]
       const double nlm = t > k ? -(colk * r) : 0.0;
@@ -780,7 +780,17 @@ struct DenseWave {
         });
         __builtin_amdgcn_wave_barrier();  // (the next column is stored behind these reads)
       }
-    });
+    };
+    // (sixteen steps at a time: a block whose rows are all identity padding is skipped -
+    // small problems do not pay for sixty-three steps)
+    sfor<0, 16>(step);
+    if (n > 16) {
+      sfor<16, 32>(step);
+      if (n > 32) {
+        sfor<32, 48>(step);
+        if (n > 48) sfor<48, 63>(step);
+      }
+    }
     dinv = t == 63 ? r : dinv;
     FB_DW_LAP(3);
     if (emin == 0u || emax == 0x7ffu) {
@@ -789,11 +799,15 @@ struct DenseWave {
     }
     // D L' w = y: lane t holds row t of D L' (columns t + 1 ..) and 1 / d_t
     x *= dinv;
-    sfor<0, 63>([&](auto J_) {
+    auto back = [&](auto J_) {
       constexpr int j = 63 - decltype(J_)::value;
       const double u = t < j ? Kr[j] * dinv : 0.0;
       x = fma(-u, lane_of(x, j), x);
-    });
+    };
+    if (n > 48) sfor<0, 16>(back);   // j = 63 .. 48 (columns of identity padding are zero in the rows above them)
+    if (n > 32) sfor<16, 32>(back);  // j = 47 .. 32
+    if (n > 16) sfor<32, 48>(back);  // j = 31 .. 16
+    sfor<48, 63>(back);              // j = 15 .. 1
     FB_DW_LAP(1);
     FB_DW_LAPS_FLUSH(0);
     return true;
