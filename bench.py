@@ -23,6 +23,11 @@ Besides the contract's keys the line carries, measured in the same run at N = 1:
   dense           BASELINE configs[1]: batched FBstabDense, batch 4096, 50/10/100
   receding        BASELINE configs[4]: 4096 warm-started closed-loop trajectories
                   x 200 steps, plant step and retirement on the device
+  latency         ms per COLD solve of small batches (1, 16, 256, 2048) through
+                  fbstab_hip_mpc_solve_batch with device pointers, and of ONE
+                  FBstabMpc::Solve through the C++ facade (host pointers, Display::OFF) -
+                  the reference's only entry (fbstab/fbstab_mpc.h:181-195) - beside the
+                  CPU restatement's single-thread ms per QP
   cpu_baseline    the oracle on the host cores (bounded sample)
 """
 import argparse
@@ -271,6 +276,7 @@ def main():
         torch.cuda.empty_cache()
         blocks["dense"] = bench_dense(torch, dev, fx, hip_api)
         blocks["receding"] = bench_receding(torch, dev, fx, hip_api)
+        blocks["latency"] = bench_latency(torch, dev, fx, hip_api)
     if dist is not None and args.extras != 0 and (world > 1 or os.environ.get("FBSTAB_BENCH_SHARDED_SWEEP") == "1"):
         # N > 1: configs[4] sharded by trajectory (every rank takes part: one gather at
         # the end).  (The environment variable rehearses this branch with one rank.)
@@ -335,6 +341,11 @@ def main():
             n_cpu = 256 * max(1, (os.cpu_count() or 1))
         if n_cpu > 0 and world == 1:
             rec["cpu_baseline"] = cpu_baseline(n_cpu)
+            if "latency" in rec:
+                cpu_ms = 1e3 / rec["cpu_baseline"]["single_thread_value"]
+                lat = rec["latency"]
+                lat["cpu_single_thread_ms_per_qp"] = cpu_ms
+                lat["gpu_batch1_over_cpu_single_thread"] = lat["device_pointers"]["1"]["ms_median"] / cpu_ms
         elif world > 1:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))
@@ -342,8 +353,21 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8):
-    """BASELINE configs[1]: batched FBstabDense, batch 4096, nz=50 nl=10 nv=100."""
+def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8, order=None):
+    """BASELINE configs[1]: batched FBstabDense, batch 4096, nz=50 nl=10 nv=100.  order: None =
+    the handle's default elimination order of the KKT factorisation (Eigen's, the reference's:
+    fbstab_hip_dense_set_factorisation), or "auto" / "natural" (the opt-in faster orders, whose
+    iteration counts can differ from the reference's on degenerate QPs - not on this workload)."""
+    if order is None:
+        r = bench_dense(torch, dev, fx, hip_api, batch, steps, lanes, order="pivoted")
+        r["factorisation_order"] = "pivoted (default: Eigen's rule, dense_cholesky_solver.cc:70-79)"
+        r["opt_in_orders"] = {}
+        for o in ("auto", "natural"):
+            f = bench_dense(torch, dev, fx, hip_api, batch, steps, lanes, order=o)
+            r["opt_in_orders"][o] = {k: f[k] for k in ("value", "ms_per_step", "kernel_ms", "serial_value",
+                                                       "mean_newton_iters", "all_converged", "pivoted_steps_per_launch")}
+            r["opt_in_orders"][o]["roofline_frac"] = f["roofline"]["frac"]
+        return r
     p = fx.synthetic_dense_batch(batch, 50, 10, 100)
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
     mk = lambda n: torch.zeros((batch, n), dtype=torch.float64, device=dev)
@@ -352,6 +376,8 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8):
         L.append(dict(s=hip_api.FBstabDenseBatch(50, 10, 100, max_batch=batch), st=torch.cuda.Stream(device=dev),
                       z=mk(50), l=mk(10), v=mk(100), y=mk(100),
                       out=torch.zeros((batch, 40), dtype=torch.uint8, device=dev)))
+        sv = L[-1]["s"]
+        sv.SetFactorisation({"pivoted": sv.ORDER_PIVOTED, "auto": sv.ORDER_AUTO, "natural": sv.ORDER_NATURAL}[order])
     # one launch alone: kernel time
     ln = L[0]
     for _ in range(2):
@@ -359,6 +385,7 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8):
             a.zero_()
         ln["s"].Solve(data, ln["z"], ln["l"], ln["v"], ln["y"], out=ln["out"])
     k_ms = ln["s"].last_kernel_ms()
+    handed = ln["s"].Factorisation()["pivoted_steps"]
 
     def step(k):
         ln = L[k % lanes]
@@ -398,6 +425,7 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8):
          "value": batch * steps / dt, "unit": "QPs/sec", "ms_per_step": 1e3 * per_step, "steps": steps,
          "steps_in_flight": lanes, "kernel_ms": k_ms, "serial_value": batch / (k_ms * 1e-3),
          "mean_newton_iters": float(outs[0]["newton_iters"].mean()), "all_converged": ok,
+         "pivoted_steps_per_launch": handed,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
                       "traffic_ratio": (traffic / (DENSE_ALG_BYTES_PER_QP * batch)) if traffic else None,
@@ -409,6 +437,58 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8):
     for ln in L:
         ln["s"].close()
     return r
+
+
+def bench_latency(torch, dev, fx, hip_api, batches=(1, 16, 256, 2048), repeats=7):
+    """What ONE caller sees: wall ms of a cold-started solve (zero guess) of a small batch, call
+    to completion, one call at a time.  `device_pointers`: fbstab_hip_mpc_solve_batch on
+    resident arrays (synchronous call).  `facade_host_pointers`: FBstabMpc::Solve of the C++
+    facade on host arrays, Display::OFF (tools/cpp/facade_latency.cc, a child process; the
+    staging copies of one QP's 189 KB are inside the time).  A batch of one occupies one
+    16-lane row of one wavefront: its time is the dependent chain of its ~19 Newton steps."""
+    import subprocess
+    import tempfile
+    res = {"unit": "ms per solve call (cold start, default options)", "repeats": repeats, "device_pointers": {}}
+    for b in batches:
+        p = fx.synthetic_mpc_batch(b)
+        s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=b, device=dev.index or 0)
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        mk = lambda n: torch.zeros((b, n), dtype=torch.float64, device=dev)
+        z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+        ms, kms = [], []
+        for k in range(repeats + 1):
+            for a in (z, l, v):
+                a.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = s.Solve(data, z, l, v, y)     # synchronous
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0))
+            kms.append(s.last_kernel_ms())
+        o = hip_api.out_to_numpy(out)
+        res["device_pointers"][str(b)] = {
+            "ms_median": float(np.median(ms[1:])), "ms_min": float(np.min(ms[1:])),
+            "kernel_ms_median": float(np.median(kms[1:])), "qps_per_sec": b / (1e-3 * float(np.median(ms[1:]))),
+            "max_newton_iters": int(o["newton_iters"].max()), "all_converged": bool((o["eflag"] == 0).all())}
+        s.close()
+    exe = os.path.join(ROOT, "tools", "cpp", "facade_latency")
+    if os.path.exists(exe):
+        p = fx.synthetic_mpc_batch(1)
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            np.asarray(p.sizes(), dtype=np.int32).tofile(f)
+            for k in hip_api.MPC_SEQ:
+                np.ascontiguousarray(p.arrays[k][0], dtype=np.float64).tofile(f)
+            path = f.name
+        try:
+            r = subprocess.run([exe, path, str(repeats)], capture_output=True, text=True, timeout=120)
+            res["facade_host_pointers"] = json.loads(r.stdout) if r.returncode == 0 else {"error": r.stderr[-300:]}
+        except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+            res["facade_host_pointers"] = {"error": str(e)}
+        finally:
+            os.unlink(path)
+    else:
+        res["facade_host_pointers"] = {"error": "tools/cpp/facade_latency not built (__graft_entry__.build())"}
+    return res
 
 
 def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200, dist=None, rank=0, world=1):

@@ -51,10 +51,22 @@ struct StampClock {
 #define FB_STAMP_DECL StampClock fb_clk_; fb_clk_.start()
 #define FB_STAMP_LAP(k) fb_clk_.lap(k)
 #define FB_STAMP_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], 1ull); } while (0)
+#elif defined(FB_PHASE_MARKERS) && !defined(FB_HOSTSIM)
+// tools/isa_ledger.py: the phase boundaries as comments in the assembly (no instruction;
+// the comment stays where the boundary is because the asm statement is volatile)
+#define FB_STAMP_DECL
+#define FB_STAMP_LAP(k) asm volatile("; FBPHASE " #k)
+#define FB_STAMP_COUNT(k)
 #else
 #define FB_STAMP_DECL
 #define FB_STAMP_LAP(k)
 #define FB_STAMP_COUNT(k)
+#endif
+
+#if defined(FB_PHASE_MARKERS) && !defined(FB_HOSTSIM)
+#define FB_PHASE(name) asm volatile("; FBPHASE " #name)
+#else
+#define FB_PHASE(name)
 #endif
 
 // Wave-level event counters of the light diagnostic build (-DFB_CLOCKSTAMP).
@@ -247,6 +259,9 @@ FB_DEV double sat(double x, double lo, double hi) {
 // matter).  Zero, infinity and NaN come back as they are (sqrt(0) = 0 exactly; an
 // overflowed or NaN iterate then propagates as it does through the reference's sqrt and
 // ends where the reference's solve ends - in a failed factorisation, impl:263-267).
+// PRECONDITION x >= 0 (or NaN): every caller passes a sum of squares.  A negative argument
+// is NOT turned into NaN - it comes back as it is, like the other inputs outside the
+// +normal / +denormal classes; a caller that can produce one must test for it itself.
 FB_DEV double fsqrt(double x) {
 #if defined(FB_HOSTSIM)
   return sqrt(x);

@@ -68,7 +68,18 @@ namespace fbk {
 struct DenseWaveLayout {
   static constexpr int kLd = 17;  // leading dimension of the staging panel (odd: rows hit different banks)
   int nz, nl, nv, nk;
-  int pivoted = 0;  // 1: every factorisation by Eigen's rule (FBSTAB_HIP_DENSE_PIVOTED=1; see factor_solve_static)
+  // Elimination order of the LDL' (fbstab_hip_dense_set_factorisation; see factor_solve_static):
+  // 1 = Eigen's rule at every step (the reference's order; the default), 2 = natural order
+  // whenever it exists, 0 = natural order until the QP shows itself ill-conditioned, then
+  // Eigen's rule for the rest of its solve (`sticky`): a step whose natural-order pivots
+  // span more than spread_bits binary orders of magnitude is factored again, and a QP with
+  // at least nz - nl "active" inequality rows at an iterate - rows whose barrier weight
+  // Gamma = gamma / mu exceeds 2^-act_bits / sigma - switches before that step (act_bits = 0:
+  // no such test).
+  int order = 1;
+  int spread_bits = 32;
+  int sticky = 1;
+  int act_bits = 20;
   // LDS carve (offsets in doubles)
   int o_z, o_l, o_v, o_y, o_zb, o_lb, o_vb, o_yb, o_dz, o_dl, o_dv, o_adz, o_rz, o_rl, o_wz, o_wl,
       o_gam, o_rvm, o_rowbuf, o_stage, lds_doubles;
@@ -111,13 +122,17 @@ struct DenseWave {
   // global scratch: the multipliers Lg[64 k + t], the lower triangle of H as the MFMA
   // accumulators hold it (Hd[64 (4 tile + q) + lane]) and G'
   double *Lg, *Hd, *Gt;
+  int* nfallback;  // Newton steps of this launch that went to the pivoted path behind a natural-order attempt
+  mutable bool went_pivoted;  // (wavefront-uniform) this QP has been handed to the pivoted path before
   int nz, nl, nv;
   lds_ptr z, l, v, y, zb, lb, vb, yb, dz, dl, dv, adz, rz, rl, wz, wl;
   lds_ptr gam, rvm, rowbuf, stage;
 
   FB_DEV void bind(const DenseWaveLayout& L_, const DenseData& D_, double* uz_, double* ul_, double* uv_,
-                   double* uy_, lds_ptr lds, double* ws) {
+                   double* uy_, lds_ptr lds, double* ws, int* nfallback_ = nullptr) {
     lay = L_; D = D_; uz = uz_; ul = ul_; uv = uv_; uy = uy_;
+    nfallback = nfallback_;
+    went_pivoted = false;
     nz = lay.nz; nl = lay.nl; nv = lay.nv;
     z = lds + lay.o_z; l = lds + lay.o_l; v = lds + lay.o_v; y = lds + lay.o_y;
     zb = lds + lay.o_zb; lb = lds + lay.o_lb; vb = lds + lay.o_vb; yb = lds + lay.o_yb;
@@ -729,8 +744,8 @@ struct DenseWave {
       const double dk = lane_of(Kr[k], k);
       const double d = k < n ? dk : 1.0;
       const unsigned e = ((unsigned)__double2hiint(d) >> 20) & 0x7ffu;
-      emin = e < emin ? e : emin;
-      emax = e > emax ? e : emax;
+      emin = e < emin ? e : emin;  // (identity padding counts as a pivot of one; a predicate on
+      emax = e > emax ? e : emax;  //  k < n here cost the kernel 770 more spilled registers)
       r = rcp_nr(d);
     };
     double r;
@@ -793,7 +808,11 @@ struct DenseWave {
     }
     dinv = t == 63 ? r : dinv;
     FB_DW_LAP(3);
-    if (emin == 0u || emax == 0x7ffu) {
+    // A pivot that is zero, denormal, infinite or NaN; or (order chosen per step) pivots that
+    // span more than spread_bits binary orders of magnitude: K is then so ill-conditioned
+    // that the iteration's course depends on HOW the rounding errors of the solve fall, and
+    // the caller takes the reference's elimination order.
+    if (emin == 0u || emax == 0x7ffu || (lay.order == 0 && (int)(emax - emin) > lay.spread_bits)) {
       FB_DW_LAPS_FLUSH(0);
       return false;
     }
@@ -864,14 +883,24 @@ struct DenseWave {
     d4 hd[10];
     load_hd(t, hd);  // (on its way while the gradients are formed)
     // PFB gradients (dense_cholesky_solver.cc:54-61)
-    for (int i = t; i < nv; i += 64) {
-      const double ys = y[i] + sigma * (v[i] - vb[i]);
-      double g0, g1;
-      pfb_gradient(ys, v[i], alpha, &g0, &g1);
-      const double mu = g1 + sigma * g0;
-      gam[i] = g0 / mu;
-      rvm[i] = -pfb(ys, v[i], alpha) / mu;
+    int nact = 0;  // rows with Gamma sigma > 2^-act_bits (wavefront-uniform)
+    const double act_thr = __hiloint2double((1023 - lay.act_bits) << 20, 0);
+    for (int i0 = 0; i0 < nv; i0 += 64) {
+      const int i = i0 + t;
+      bool act = false;
+      if (i < nv) {
+        const double ys = y[i] + sigma * (v[i] - vb[i]);
+        double g0, g1;
+        pfb_gradient(ys, v[i], alpha, &g0, &g1);
+        const double mu = g1 + sigma * g0;
+        const double g = g0 / mu;
+        gam[i] = g;
+        rvm[i] = -pfb(ys, v[i], alpha) / mu;
+        act = g * sigma > act_thr;
+      }
+      nact += __popcll(__ballot(act));
     }
+    if (lay.order == 0 && lay.act_bits > 0 && nact + nl >= nz) went_pivoted = true;
     c.sync();
     FB_WAVE_LAP(10);
     double Kr[64], dg, atr;
@@ -888,9 +917,13 @@ struct DenseWave {
       // (a NaN on the diagonal - an overflowed iterate - goes straight to the pivoted
       // path, which answers it the way Eigen does)
       const double x0 = x;
-      const bool take_static = lay.pivoted == 0 && __ballot(t < n && dg != dg) == 0ull;
+      const bool take_static = lay.order != 1 && !(lay.order == 0 && lay.sticky != 0 && went_pivoted) &&
+                               __ballot(t < n && dg != dg) == 0ull;
       if (take_static) solved = factor_solve_static(c, Kr, x);
+      if (!take_static && went_pivoted && nfallback != nullptr && t == 0) atomicAdd(nfallback + 1, 1);
       if (take_static && !solved) {
+        went_pivoted = true;
+        if (nfallback != nullptr && t == 0) atomicAdd(nfallback, 1);
         x = x0;
         load_hd(t, hd);
         assemble(c, hd, sigma, Kr, &dg, &atr);

@@ -2034,6 +2034,7 @@ struct MpcR16 {
     load_fwd(R0, cur);
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
+      FB_PHASE(fwd_top);
       double* R = R0 + (long)i * kRec;
       const int pnn = po[i + 2 <= N_ ? i + 2 : N_];
       stage_pack_s(c, P0, Lp, loff, pcur);
@@ -2084,7 +2085,9 @@ struct MpcR16 {
                         });
         r1 = (p[0] + p[1]) + (p[2] + p[3]);
       }
+      FB_PHASE(krhs_end);
       if (bnd) {
+        FB_PHASE(k_bounds);
         // one nonzero per constraint row: only the diagonal entry K[r][r] changes
         double s = 0.0;
         sfor<0, NS>([&](auto Cc) { s = (ro == decltype(Cc)::value) ? K[decltype(Cc)::value] : s; });
@@ -2095,6 +2098,7 @@ struct MpcR16 {
         });
         sfor<0, NS>([&](auto Cc) { K[decltype(Cc)::value] = (ro == decltype(Cc)::value) ? s : K[decltype(Cc)::value]; });
       } else {
+        FB_PHASE(k_general);
         sfor<0, NC>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
           const double gc = bcr<RQ, (k % LPQ)>(Gam[k / LPQ]) * Cc_[k];  // Gamma_k C[k][r]
@@ -2183,6 +2187,7 @@ struct MpcR16 {
       thp = -bc_dot<0, NS, RQ>(W, tvec);
       if (i < N_) {
         FB_SB();
+        FB_PHASE(wwt);
         // ---- Pi(i+1) = sigma I + W W' ; L = chol ; inv(Pi) = T'T, T = inv(L).
         // (Measured and dropped: the two symmetric products with the other lanes'
         // rows read as 16-byte LDS broadcasts instead of DPP moves - 96 + 42
@@ -2201,9 +2206,11 @@ struct MpcR16 {
         ok = chol_rows<NX, RQ>(Pn, ro, sigma) && ok;
         if (!ok) { lds_off = loff; return false; }
         FB_SB();
+        FB_PHASE(tinv12);
         double T[NX];
         tri_inv_cols<NX, RQ>(Pn, T, ro);
         FB_SB();
+        FB_PHASE(ttt);
         // inv(Pi)[r][cc] = sum_k T[k][r] T[k][cc], T[k][cc] = lane cc's T[k] (zero for k < cc)
         sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
         sfor<0, NX>([&](auto Kk) {
@@ -2217,6 +2224,7 @@ struct MpcR16 {
       }
       pcur = pnxt;
       pnxt = pnn;
+      FB_PHASE(fwd_end);
     }
 
     // ============ backward sweep (:267-341), fused with dv, A dz, W and the
@@ -2246,6 +2254,7 @@ struct MpcR16 {
       load_bwd(R, bin);
     }
     for (int i = N_; i >= 0; i--) {
+      FB_PHASE(bwd_top);
       double* R = R0 + (long)i * kRec;
       const double* Rp = i > 0 ? R - kRec : R;  // the stage fetched next (stage 0 once more at the end)
       stage_pack_s(c, P0, Lp, loff, pcur);
@@ -2397,6 +2406,7 @@ struct MpcR16 {
       lrn = cu.lr;
       lbn = cu.bb[1];
       FB_STAMP_LAP(10);
+      FB_PHASE(bwd_end);
     }
     lds_off = loff;
     *trial_inner2 = qp_reduce<RQ, OpSum16>(s_in);

@@ -9,16 +9,30 @@
 // (FBstabMpc::Solve, fbstab/fbstab_mpc.h:181-195).
 //
 // RCCL is bound with dlopen at the first gather: the library carries no link-time
-// dependency on it, and a process that has RCCL loaded already (PyTorch brings its own
-// copy) keeps exactly one.
+// dependency on it - nor a build-time one: the handful of types and prototypes used are
+// declared below, so that a ROCm install without the RCCL headers still builds the library
+// - and a process that has RCCL loaded already (PyTorch brings its own copy) keeps exactly
+// one: the loaded copy is looked up first (RTLD_NOLOAD).
+//
+// State of verification: groups of ONE physical device have run on hardware (one shard;
+// two shards on the same device through the test-only switch below, which exercises the
+// offsets `first`, the per-shard pieces and the log offsets of the sweep; the RCCL leg as a
+// self-send).  ncclCommInitAll over two or more devices and sends between devices have NOT
+// run: no multi-GPU node was available to any round of this build.
 #pragma once
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <thread>
 
 namespace {
+
+// The part of <rccl/rccl.h> this file uses (RCCL 2.x ABI: opaque communicator, int-sized enums).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclChar = 0;  // ncclInt8
 
 struct RcclApi {
   void* so = nullptr;
@@ -31,9 +45,14 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   int load() {
     if (so) return FBSTAB_HIP_OK;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* name : names) {  // a copy the process has loaded already
+      so = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
       if (so) break;
+    }
+    for (const char* name : names) {
+      if (so) break;
+      so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!so) return fail(FBSTAB_HIP_ERR_DEVICE, std::string("librccl.so not found: ") + dlerror());
     bool ok = true;
@@ -54,6 +73,7 @@ struct RcclApi {
 
 struct fbstab_shard_group {
   std::vector<int> devices;
+  bool repeated = false;  // (test-only) a physical device carries more than one shard
   std::vector<ncclComm_t> comms;  // created by the first gather that needs them
   RcclApi rccl;
   long long gathers = 0, rccl_ops = 0;  // (diagnostics: collectives issued, send/recv pairs in them)
@@ -95,7 +115,14 @@ int solution_pieces(const long long var_len[4], const fbstab_var_batch_t& x, con
     return FBSTAB_HIP_OK;
   }
   if (record) {
-    out->push_back({x.base[0], rx.base[0] + first * rx.stride[0], sizeof(double) * (size_t)x.stride[0] * count});
+    // From z of the shard's first QP to the end of y of its last: whatever the caller keeps
+    // between y of one record and z of the next travels along and lands in the same columns
+    // of the root's records (the caller's own layout on both sides); nothing before the
+    // first z or behind the last y is touched, wherever z sits inside the record.
+    const long long span = var_len[0] + var_len[1] + var_len[2] + var_len[3];
+    if (count > 0)
+      out->push_back({x.base[0], rx.base[0] + first * rx.stride[0],
+                      sizeof(double) * (size_t)(x.stride[0] * (count - 1) + span)});
     return FBSTAB_HIP_OK;
   }
   return fail(FBSTAB_HIP_ERR_UNSUPPORTED,
@@ -105,37 +132,56 @@ int solution_pieces(const long long var_len[4], const fbstab_var_batch_t& x, con
 
 // ONE collective: every piece of every shard to the root, fused between ncclGroupStart and
 // ncclGroupEnd; sends ride on the shard's stream (behind its solve), receives on the
-// root's.  The root's own shard is a device-to-device copy (FBSTAB_HIP_SHARD_SELF_SEND=1
-// sends it through RCCL as well: the one-GPU rehearsal of the path).
+// root's.  A shard that lives on the root's own physical device is a device-to-device copy
+// on the shard's stream (FBSTAB_HIP_SHARD_SELF_SEND=1 sends the root's shard through RCCL
+// as well: the one-GPU rehearsal of the path; ignored for groups with a repeated device,
+// over which RCCL cannot build communicators).  An error inside the group still closes it.
 int shard_gather(fbstab_shard_group* g, int root, const std::vector<std::vector<GatherPiece>>& pieces,
                  const std::vector<hipStream_t>& streams) {
   const int ndev = (int)g->devices.size();
   const char* self_env = getenv("FBSTAB_HIP_SHARD_SELF_SEND");
-  const bool self_send = self_env && atoi(self_env) != 0;
-  const bool need_rccl = ndev > 1 || self_send;
+  const bool self_send = self_env && atoi(self_env) != 0 && !g->repeated;
+  auto local = [&](int d) { return g->devices[d] == g->devices[root] && !self_send; };
+  bool need_rccl = false;
+  for (int d = 0; d < ndev; d++) need_rccl = need_rccl || !local(d);
+  if (need_rccl && g->repeated)
+    return fail(FBSTAB_HIP_ERR_UNSUPPORTED, "a group with a repeated device (test-only) must live on ONE device");
   if (need_rccl && g->comms.empty()) {
     int rc = g->rccl.load();
     if (rc != FBSTAB_HIP_OK) return rc;
     g->comms.assign(ndev, nullptr);
-    RCCL_TRY(g, g->rccl.CommInitAll(g->comms.data(), ndev, g->devices.data()));
+    ncclResult_t r = g->rccl.CommInitAll(g->comms.data(), ndev, g->devices.data());
+    if (r != ncclSuccess) {
+      g->comms.clear();
+      return fail(FBSTAB_HIP_ERR_DEVICE, std::string("RCCL: ncclCommInitAll: ") + g->rccl.GetErrorString(r));
+    }
   }
   g->gathers++;
   if (need_rccl) RCCL_TRY(g, g->rccl.GroupStart());
-  for (int d = 0; d < ndev; d++) {
-    for (const GatherPiece& p : pieces[d]) {
-      if (p.bytes == 0) continue;
-      if (d == root && !self_send) {
-        HIP_TRY(hipSetDevice(g->devices[root]));
-        HIP_TRY(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToDevice, streams[root]));
-      } else {
-        RCCL_TRY(g, g->rccl.Send(p.src, p.bytes, ncclChar, root, g->comms[d], streams[d]));
-        RCCL_TRY(g, g->rccl.Recv(p.dst, p.bytes, ncclChar, d, g->comms[root], streams[root]));
-        g->rccl_ops++;
+  auto queue = [&]() -> int {
+    for (int d = 0; d < ndev; d++) {
+      for (const GatherPiece& p : pieces[d]) {
+        if (p.bytes == 0) continue;
+        if (local(d)) {
+          HIP_TRY(hipSetDevice(g->devices[d]));
+          HIP_TRY(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToDevice, streams[d]));
+        } else {
+          RCCL_TRY(g, g->rccl.Send(p.src, p.bytes, ncclChar, root, g->comms[d], streams[d]));
+          RCCL_TRY(g, g->rccl.Recv(p.dst, p.bytes, ncclChar, d, g->comms[root], streams[root]));
+          g->rccl_ops++;
+        }
       }
     }
+    return FBSTAB_HIP_OK;
+  };
+  const int rc = queue();
+  const std::string msg = rc != FBSTAB_HIP_OK ? std::string(fbstab_hip_last_error()) : std::string();
+  if (need_rccl) {
+    const ncclResult_t r = g->rccl.GroupEnd();  // (always: an open group would swallow the thread's next RCCL calls)
+    if (rc == FBSTAB_HIP_OK && r != ncclSuccess)
+      return fail(FBSTAB_HIP_ERR_DEVICE, std::string("RCCL: ncclGroupEnd: ") + g->rccl.GetErrorString(r));
   }
-  if (need_rccl) RCCL_TRY(g, g->rccl.GroupEnd());
-  return FBSTAB_HIP_OK;
+  return rc != FBSTAB_HIP_OK ? fail(rc, msg) : FBSTAB_HIP_OK;
 }
 
 int sync_all(fbstab_shard_group* g, const std::vector<hipStream_t>& streams) {
@@ -144,6 +190,13 @@ int sync_all(fbstab_shard_group* g, const std::vector<hipStream_t>& streams) {
     HIP_TRY(hipStreamSynchronize(streams[d]));
   }
   return FBSTAB_HIP_OK;
+}
+// A failure after the first shard was queued: nothing may be left in flight when the call
+// returns (the caller is free to release its buffers); the first error is what is reported.
+int drain_and_fail(fbstab_shard_group* g, const std::vector<hipStream_t>& streams, int rc) {
+  const std::string msg = fbstab_hip_last_error();
+  (void)sync_all(g, streams);
+  return fail(rc, msg);
 }
 
 template <class Handle>
@@ -158,6 +211,8 @@ int check_shards(fbstab_shard_group* g, Handle* const* handles, const int* count
       return fail(FBSTAB_HIP_ERR_ARGUMENT, "handles[d] must live on the group's device d");
     if (counts[d] < 0 || counts[d] > handles[d]->max_batch)
       return fail(FBSTAB_HIP_ERR_ARGUMENT, "shard exceeds the max_batch its handle was created with");
+    for (int e = 0; e < d; e++)
+      if (handles[e] == handles[d]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "a solver handle serves one shard");
     for (int i = 0; i < 4; i++)
       if (handles[d]->var_len[i] != handles[0]->var_len[i])
         return fail(FBSTAB_HIP_ERR_ARGUMENT, "the shards' handles must have one problem size");
@@ -177,14 +232,25 @@ int fbstab_hip_shard_group_create(int ndev, const int* devices, fbstab_shard_gro
   int have = 0;
   if (hipGetDeviceCount(&have) != hipSuccess || have <= 0)
     return fail(FBSTAB_HIP_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+  // FBSTAB_HIP_SHARD_ALLOW_REPEATED_DEVICE=1 (tests): several shards on ONE physical device,
+  // each with its own handle and stream, gathered by device copies - the index arithmetic of
+  // the sharded entries (offsets of the shards on the root, per-shard pieces, log offsets)
+  // on a box with a single GPU.
+  const char* rep_env = getenv("FBSTAB_HIP_SHARD_ALLOW_REPEATED_DEVICE");
+  const bool allow_rep = rep_env && atoi(rep_env) != 0;
+  bool repeated = false;
   for (int d = 0; d < ndev; d++) {
     if (devices[d] < 0 || devices[d] >= have) return fail(FBSTAB_HIP_ERR_ARGUMENT, "bad device index");
     for (int e = 0; e < d; e++)
-      if (devices[e] == devices[d]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "a device appears twice in the group");
+      if (devices[e] == devices[d]) {
+        if (!allow_rep) return fail(FBSTAB_HIP_ERR_ARGUMENT, "a device appears twice in the group");
+        repeated = true;
+      }
   }
   fbstab_shard_group* g = new (std::nothrow) fbstab_shard_group();
   if (!g) return fail(FBSTAB_HIP_ERR_DEVICE, "out of host memory");
   g->devices.assign(devices, devices + ndev);
+  g->repeated = repeated;
   *group = g;
   return FBSTAB_HIP_OK;
 }
@@ -216,21 +282,39 @@ int fbstab_hip_mpc_solve_batch_sharded(fbstab_shard_group_t g, const fbstab_mpc_
   std::vector<hipStream_t> streams(ndev);
   std::vector<std::vector<GatherPiece>> pieces(ndev);
   long long first = 0;
+  // every shard's arguments are checked before the first shard is queued (an empty shard
+  // needs no arrays and is skipped)
   for (int d = 0; d < ndev; d++) {
     streams[d] = handles[d]->stream;
-    rc = solution_pieces(handles[d]->var_len, x[d], *root_x, first, counts[d], &pieces[d]);
-    if (rc != FBSTAB_HIP_OK) return rc;
-    pieces[d].push_back({out[d], root_out + first, sizeof(fbstab_solver_out_t) * (size_t)counts[d]});
+    if (counts[d] == 0) continue;
+    if (!out[d]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null SolverOut pointer of a non-empty shard");
+    for (int i = 0; i < FBSTAB_MPC_NSEQ; i++)
+      if (!data[d].base[i] && handles[d]->arr_len[i] > 0)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer of a non-empty shard");
+    for (int i = 0; i < 4; i++)
+      if (!x[d].base[i] && handles[d]->var_len[i] > 0)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer of a non-empty shard");
+  }
+  for (int i = 0; i < 4; i++)
+    if (!root_x->base[i] && handles[0]->var_len[i] > 0 && total > 0)
+      return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer on the root");
+  for (int d = 0; d < ndev; d++) {
+    if (counts[d] > 0) {
+      rc = solution_pieces(handles[d]->var_len, x[d], *root_x, first, counts[d], &pieces[d]);
+      if (rc != FBSTAB_HIP_OK) return rc;
+      pieces[d].push_back({out[d], root_out + first, sizeof(fbstab_solver_out_t) * (size_t)counts[d]});
+    }
     first += counts[d];
   }
   // every shard is queued on its device (nothing waits for another device), then the gather
   for (int d = 0; d < ndev; d++) {
+    if (counts[d] == 0) continue;
     rc = fbstab_hip_mpc_solve_batch(handles[d], counts[d], &data[d], &x[d], out[d],
                                     FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_ASYNC, nullptr);
-    if (rc != FBSTAB_HIP_OK) return rc;
+    if (rc != FBSTAB_HIP_OK) return drain_and_fail(g, streams, rc);
   }
   rc = shard_gather(g, root, pieces, streams);
-  if (rc != FBSTAB_HIP_OK) return rc;
+  if (rc != FBSTAB_HIP_OK) return drain_and_fail(g, streams, rc);
   return sync_all(g, streams);
 }
 
@@ -246,20 +330,38 @@ int fbstab_hip_dense_solve_batch_sharded(fbstab_shard_group_t g, const fbstab_de
   std::vector<hipStream_t> streams(ndev);
   std::vector<std::vector<GatherPiece>> pieces(ndev);
   long long first = 0;
+  // every shard's arguments are checked before the first shard is queued (an empty shard
+  // needs no arrays and is skipped)
   for (int d = 0; d < ndev; d++) {
     streams[d] = handles[d]->stream;
-    rc = solution_pieces(handles[d]->var_len, x[d], *root_x, first, counts[d], &pieces[d]);
-    if (rc != FBSTAB_HIP_OK) return rc;
-    pieces[d].push_back({out[d], root_out + first, sizeof(fbstab_solver_out_t) * (size_t)counts[d]});
+    if (counts[d] == 0) continue;
+    if (!out[d]) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null SolverOut pointer of a non-empty shard");
+    for (int i = 0; i < FBSTAB_DENSE_NARR; i++)
+      if (!data[d].base[i] && handles[d]->arr_len[i] > 0)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "null problem data pointer of a non-empty shard");
+    for (int i = 0; i < 4; i++)
+      if (!x[d].base[i] && handles[d]->var_len[i] > 0)
+        return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer of a non-empty shard");
+  }
+  for (int i = 0; i < 4; i++)
+    if (!root_x->base[i] && handles[0]->var_len[i] > 0 && total > 0)
+      return fail(FBSTAB_HIP_ERR_ARGUMENT, "null variable pointer on the root");
+  for (int d = 0; d < ndev; d++) {
+    if (counts[d] > 0) {
+      rc = solution_pieces(handles[d]->var_len, x[d], *root_x, first, counts[d], &pieces[d]);
+      if (rc != FBSTAB_HIP_OK) return rc;
+      pieces[d].push_back({out[d], root_out + first, sizeof(fbstab_solver_out_t) * (size_t)counts[d]});
+    }
     first += counts[d];
   }
   for (int d = 0; d < ndev; d++) {
+    if (counts[d] == 0) continue;
     rc = fbstab_hip_dense_solve_batch(handles[d], counts[d], &data[d], &x[d], out[d],
                                       FBSTAB_HIP_DEVICE_POINTERS | FBSTAB_HIP_ASYNC, nullptr);
-    if (rc != FBSTAB_HIP_OK) return rc;
+    if (rc != FBSTAB_HIP_OK) return drain_and_fail(g, streams, rc);
   }
   rc = shard_gather(g, root, pieces, streams);
-  if (rc != FBSTAB_HIP_OK) return rc;
+  if (rc != FBSTAB_HIP_OK) return drain_and_fail(g, streams, rc);
   return sync_all(g, streams);
 }
 
@@ -288,6 +390,7 @@ int fbstab_hip_mpc_receding_sweep_sharded(fbstab_shard_group_t g, const fbstab_m
     std::vector<std::thread> th;
     for (int d = 0; d < ndev; d++)
       th.emplace_back([&, d]() {
+        if (counts[d] == 0) return;  // (an empty shard: nothing to sweep, nothing to gather)
         rcs[d] = fbstab_hip_mpc_receding_sweep(handles[d], counts[d], &data[d], &x[d], out[d], &plants[d], steps,
                                                retire, u_log[d], st[d].data(), nullptr, nullptr);
         if (rcs[d] != FBSTAB_HIP_OK) errs[d] = fbstab_hip_last_error();  // (the message is per thread)
@@ -315,7 +418,7 @@ int fbstab_hip_mpc_receding_sweep_sharded(fbstab_shard_group_t g, const fbstab_m
     first += counts[d];
   }
   rc = shard_gather(g, root, pieces, streams);
-  if (rc != FBSTAB_HIP_OK) return rc;
+  if (rc != FBSTAB_HIP_OK) return drain_and_fail(g, streams, rc);
   return sync_all(g, streams);
 }
 

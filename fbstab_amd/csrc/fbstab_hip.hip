@@ -34,6 +34,9 @@ using namespace fbk;
 constexpr int kMpcThreads = 64;     // one wavefront per MPC QP
 constexpr int kDenseThreads = 256;  // four wavefronts per dense QP
 constexpr int kLdsLimitBytes = 160 * 1024;
+// word of the queue block (kQueueBytes, zeroed before every launch) in which the one-wavefront
+// dense kernel counts the Newton steps it handed to the pivoted factorisation
+constexpr int kDenseFallbackSlot = 4;
 
 struct MpcBatchArgs {
   const double* base[FBSTAB_MPC_NSEQ];
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64, 2) void fbstab_dense_wave_kernel(DenseWaveLayou
     D.b = data.base[FBSTAB_DENSE_b] + q * data.stride[FBSTAB_DENSE_b];
     DenseWave p;
     p.bind(lay, D, x.base[0] + q * x.stride[0], x.base[1] + q * x.stride[1], x.base[2] + q * x.stride[2],
-           x.base[3] + q * x.stride[3], lds, ws);
+           x.base[3] + q * x.stride[3], lds, ws, counter + kDenseFallbackSlot);
     if constexpr (DBG) {
       newton_probe(p, ctx, opts, dbg);
       break;
@@ -1049,11 +1052,19 @@ int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
     const char* th = getenv("FBSTAB_HIP_DENSE_THREADS");
     if (th && atoi(th) == 256) s->wave = false;
     if (th && atoi(th) == 64 && nz + nl <= 64) { s->threads = 64; s->wave = false; }
-    // FBSTAB_HIP_DENSE_PIVOTED=1: the one-wavefront kernel factors by Eigen's pivoting
-    // rule every time instead of in the natural order (same systems, the reference's
-    // rounding: 1.5 x the time of a launch on BASELINE configs[1])
-    const char* pv = getenv("FBSTAB_HIP_DENSE_PIVOTED");
-    s->wlay.pivoted = (pv && atoi(pv) != 0) ? 1 : 0;
+    // Initial value of what fbstab_hip_dense_set_factorisation sets per handle (developer
+    // switches; the default is the reference's order): FBSTAB_HIP_DENSE_ORDER=pivoted | auto |
+    // natural, FBSTAB_HIP_DENSE_SPREAD_BITS, FBSTAB_HIP_DENSE_ACT_BITS, FBSTAB_HIP_DENSE_STICKY.
+    const char* od = getenv("FBSTAB_HIP_DENSE_ORDER");
+    if (od && !strcmp(od, "auto")) s->wlay.order = FBSTAB_HIP_DENSE_ORDER_AUTO;
+    if (od && !strcmp(od, "natural")) s->wlay.order = FBSTAB_HIP_DENSE_ORDER_NATURAL;
+    if (od && !strcmp(od, "pivoted")) s->wlay.order = FBSTAB_HIP_DENSE_ORDER_PIVOTED;
+    const char* sb = getenv("FBSTAB_HIP_DENSE_SPREAD_BITS");
+    if (sb && atoi(sb) > 0) s->wlay.spread_bits = atoi(sb);
+    const char* sk = getenv("FBSTAB_HIP_DENSE_STICKY");
+    if (sk) s->wlay.sticky = atoi(sk) != 0 ? 1 : 0;
+    const char* ab = getenv("FBSTAB_HIP_DENSE_ACT_BITS");
+    if (ab && atoi(ab) >= 0 && atoi(ab) < 1000) s->wlay.act_bits = atoi(ab);
   }
   s->lay.init(nz, nl, nv, s->threads);
   if (s->threads == 64 && (s->lay.k_global || !s->lay.a_lds)) {  // does not fit that way
@@ -1188,7 +1199,7 @@ static int dense_solve_impl(fbstab_dense_handle_t h, int batch, const fbstab_den
     }
     d_out = h->d_out;
   }
-  HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(h->counter, 0, kQueueBytes, s));  // (the queue word and the kDenseFallbackSlot counters)
   int grid = h->workgroups < batch ? h->workgroups : batch;
   HIP_TRY(hipEventRecord(h->ev0, s));
   if (d_trace && h->lay.v_global) {
@@ -1355,6 +1366,37 @@ int fbstab_hip_dense_debug_newton(fbstab_dense_handle_t h, const fbstab_dense_ba
 }
 
 double fbstab_hip_dense_last_kernel_ms(fbstab_dense_handle_t h) { return h ? h->last_kernel_ms() : -1.0; }
+
+int fbstab_hip_dense_set_factorisation(fbstab_dense_handle_t h, int order, int spread_bits) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  if (order != FBSTAB_HIP_DENSE_ORDER_AUTO && order != FBSTAB_HIP_DENSE_ORDER_PIVOTED &&
+      order != FBSTAB_HIP_DENSE_ORDER_NATURAL)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "fbstab_hip_dense_set_factorisation: unknown elimination order");
+  if (spread_bits < 0 || spread_bits > 2046)
+    return fail(FBSTAB_HIP_ERR_ARGUMENT, "fbstab_hip_dense_set_factorisation: spread_bits out of range");
+  h->wlay.order = order;
+  if (spread_bits > 0) h->wlay.spread_bits = spread_bits;
+  return FBSTAB_HIP_OK;
+}
+
+int fbstab_hip_dense_get_factorisation(fbstab_dense_handle_t h, int* order, int* spread_bits,
+                                       long long* pivoted_steps) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  // (handles that run the four-wavefront kernels always pivot)
+  if (order) *order = h->wave ? h->wlay.order : FBSTAB_HIP_DENSE_ORDER_PIVOTED;
+  if (spread_bits) *spread_bits = h->wlay.spread_bits;
+  if (pivoted_steps) {
+    *pivoted_steps = -1;
+    if (h->wave && h->timed) {
+      HIP_TRY(hipSetDevice(h->device));
+      HIP_TRY(hipEventSynchronize(h->ev1));
+      int n[2] = {0, 0};  // natural-order attempts handed on; steps of QPs that stayed pivoted after one
+      HIP_TRY(hipMemcpy(n, h->counter + kDenseFallbackSlot, sizeof(n), hipMemcpyDeviceToHost));
+      *pivoted_steps = (long long)n[0] + n[1];
+    }
+  }
+  return FBSTAB_HIP_OK;
+}
 
 int fbstab_hip_dense_query(fbstab_dense_handle_t h, long long* scratch_bytes, int* lds_bytes,
                            int* workgroups, int* threads) {

@@ -85,14 +85,42 @@ class _Plant(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("stride_A", C.c_longlong), ("stride_B", C.c_longlong)]
 
 
-_lib = None
+_libs: Dict[str, C.CDLL] = {}
+_current = LIB_PATH  # the library new solver objects bind to (see `library`)
+
+# Variant builds of the same sources that live beside the product library (tests):
+#   "pattern"  every automatic variable initialised to a bit pattern
+#              (-ftrivial-auto-var-init=pattern, `make -C fbstab_amd/csrc pattern`): a read
+#              of a value the code never set gives the same garbage in every build instead
+#              of whatever the optimiser resolved `undef` to
+VARIANTS = {"pattern": os.path.join(_HERE, "libfbstab_hip_pattern.so")}
+if os.environ.get("FBSTAB_HIP_VARIANT"):
+    _current = VARIANTS[os.environ["FBSTAB_HIP_VARIANT"]]
+
+
+class library:
+    """``with hip_api.library("pattern"):`` - solver objects created inside bind to the named
+    variant build (or a path); both libraries can be in use in one process."""
+
+    def __init__(self, which: str):
+        self.path = VARIANTS.get(which, which)
+
+    def __enter__(self):
+        global _current
+        self.prev, _current = _current, self.path
+        return load_library()
+
+    def __exit__(self, *exc):
+        global _current
+        _current = self.prev
+        return False
 
 
 def load_library() -> C.CDLL:
     """Load libfbstab_hip.so; raises (never falls back) when it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    LIB_PATH = _current
+    if LIB_PATH in _libs:
+        return _libs[LIB_PATH]
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C fbstab_amd/csrc` "
@@ -134,7 +162,9 @@ def load_library() -> C.CDLL:
                                                           C.c_void_p, C.c_void_p]
     lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
     lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
-    _lib = lib
+    lib.fbstab_hip_dense_set_factorisation.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fbstab_hip_dense_get_factorisation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _libs[LIB_PATH] = lib
     return lib
 
 
@@ -149,6 +179,7 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_batch_final",
     "fbstab_hip_dense_solve_traced",
     "fbstab_hip_dense_debug_newton", "fbstab_hip_dense_last_kernel_ms", "fbstab_hip_dense_query",
+    "fbstab_hip_dense_set_factorisation", "fbstab_hip_dense_get_factorisation",
     "fbstab_hip_shard_group_create", "fbstab_hip_shard_group_destroy", "fbstab_hip_shard_group_stats",
     "fbstab_hip_mpc_solve_batch_sharded", "fbstab_hip_mpc_receding_sweep_sharded",
     "fbstab_hip_dense_solve_batch_sharded")
@@ -458,6 +489,21 @@ class FBstabDenseBatch(_SolverBase):
         return self._solve(_DenseBatch(), DENSE_ARR, self.arr_len, data,
                            (self.nz, self.nl, self.nv, self.nv), z, l, v, y, out,
                            stream, async_)
+
+    ORDER_AUTO, ORDER_PIVOTED, ORDER_NATURAL = 0, 1, 2
+
+    def SetFactorisation(self, order: int = 0, spread_bits: int = 0):
+        """fbstab_hip_dense_set_factorisation: elimination order of the LDL' of the KKT
+        matrix (dense_cholesky_solver.cc:70-79); ``spread_bits`` 0 keeps the current value."""
+        _check(self._lib, self._lib.fbstab_hip_dense_set_factorisation(self._h, order, spread_bits))
+
+    def Factorisation(self) -> Dict[str, int]:
+        """Settings in force and the number of Newton steps of the last batch that went to
+        the pivoted factorisation behind a natural-order attempt (-1: does not apply)."""
+        o, b, n = C.c_int(), C.c_int(), C.c_longlong()
+        _check(self._lib, self._lib.fbstab_hip_dense_get_factorisation(
+            self._h, C.byref(o), C.byref(b), C.byref(n)))
+        return dict(order=o.value, spread_bits=b.value, pivoted_steps=n.value)
 
     def SolveFinal(self, data, z, l, v, y, out=None, stream: int = 0, async_: bool = False):
         """As FBstabMpcBatch.SolveFinal (fbstab_hip_dense_solve_batch_final)."""

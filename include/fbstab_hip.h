@@ -257,15 +257,53 @@ int fbstab_hip_mpc_receding_sweep_sharded(fbstab_shard_group_t group, const fbst
                                           unsigned long long* stats);
 
 /* ---- dense -------------------------------------------------------------- */
-/* Environment read by fbstab_hip_dense_create (developer / comparison switches; the defaults
- * are what is benchmarked):
- *   FBSTAB_HIP_DENSE_PIVOTED=1   nz + nl <= 64: factor by Eigen's pivoting rule
- *                                (dense_cholesky_solver.cc:70-79) every time instead of in the
- *                                natural order - the reference's rounding, 1.6 x the time
+/* Environment read by fbstab_hip_dense_create (developer / comparison switches):
+ *   FBSTAB_HIP_DENSE_ORDER=pivoted|auto|natural   initial value of fbstab_hip_dense_set_factorisation's `order`
+ *   FBSTAB_HIP_DENSE_SPREAD_BITS, _ACT_BITS       the two thresholds of the AUTO order
  *   FBSTAB_HIP_DENSE_THREADS=256 the four-wavefront kernel (always pivoted) for every shape */
 int fbstab_hip_dense_create(int nz, int nl, int nv, int max_batch, int device,
                             fbstab_dense_handle_t* handle);
 int fbstab_hip_dense_destroy(fbstab_dense_handle_t handle);
+/* Elimination order of the LDL' factorisation of the Newton system's KKT matrix
+ * (DenseCholeskySolver::Initialize, dense_cholesky_solver.cc:70-79: Eigen::LDLT, symmetric
+ * pivoting on the largest remaining |diagonal|).
+ *   FBSTAB_HIP_DENSE_ORDER_PIVOTED (default)  Eigen's rule at every Newton step: the
+ *       reference's order of rounding errors.  Exit flags, proximal and Newton counts equal
+ *       the CPU restatement's on every QP of every test and of three fuzz families built to
+ *       be degenerate (tools/fuzz_dense.py, 3017 QPs; profiles/r04_a_dense_order_choice.txt).
+ *   FBSTAB_HIP_DENSE_ORDER_NATURAL  handles with nz + nl <= 64 (one wavefront per QP, the
+ *       matrix in registers) eliminate in the natural order instead: K is quasi-definite,
+ *       every order factors it, and a compile-time order is 1.6 x faster per launch on
+ *       BASELINE configs[1].  The systems are the same, the rounding is not: a step's error
+ *       in the directions where K is small grows with the spread of the pivots, and about
+ *       one per cent of the QPs of the degenerate fuzz families then take a different
+ *       number of proximal or Newton iterations (same solutions to the tolerance; none of
+ *       the 4096 QPs of configs[1] differs).  A zero, denormal, infinite or NaN pivot still
+ *       goes to the pivoted path, whose verdict is Eigen's.
+ *   FBSTAB_HIP_DENSE_ORDER_AUTO  natural order until a QP shows itself ill-conditioned, then
+ *       Eigen's rule for the rest of that QP's solve: at the first Newton step whose
+ *       natural-order pivots span more than `spread_bits` binary orders of magnitude
+ *       (max |d_k| / min |d_k| >= 2^spread_bits; that step is factored again), or at whose
+ *       iterate at least nz - nl inequality rows carry a barrier weight above
+ *       2^-act_bits / sigma (more active rows than free variables: a degenerate vertex).
+ *       At the defaults (32, 20) configs[1] runs at the natural order's speed and the
+ *       degenerate families differ on 0.4 % of their QPs; spread_bits = 30 costs configs[1]
+ *       12 % and leaves 0.13 %.  No threshold that keeps the speed closes the gap - the
+ *       sensitive steps have the pivot spread of ordinary ones - which is why the default
+ *       is the reference's order and this one is the caller's choice.
+ * spread_bits: 1..2046, or 0 to keep the current value.  Handles on the four-wavefront
+ * kernels (nz + nl > 64) always pivot; the call is accepted and has no effect there. */
+enum fbstab_hip_dense_order {
+  FBSTAB_HIP_DENSE_ORDER_AUTO = 0,
+  FBSTAB_HIP_DENSE_ORDER_PIVOTED = 1,
+  FBSTAB_HIP_DENSE_ORDER_NATURAL = 2
+};
+int fbstab_hip_dense_set_factorisation(fbstab_dense_handle_t handle, int order, int spread_bits);
+/* The settings in force and (pivoted_steps, may be NULL; waits for the handle's last launch)
+ * the number of Newton steps of the most recent solve_batch call that AUTO handed to the
+ * pivoted factorisation; -1 where that does not apply. */
+int fbstab_hip_dense_get_factorisation(fbstab_dense_handle_t handle, int* order, int* spread_bits,
+                                       long long* pivoted_steps);
 int fbstab_hip_dense_set_options(fbstab_dense_handle_t handle, const fbstab_options_t* options);
 int fbstab_hip_dense_get_options(fbstab_dense_handle_t handle, fbstab_options_t* options);
 int fbstab_hip_dense_solve_batch(fbstab_dense_handle_t handle, int batch,

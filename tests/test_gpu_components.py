@@ -201,6 +201,75 @@ def test_random_shapes_on_every_mpc_instance(hip, oracle, idx):
         assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
 
 
+def _solve_on(hipmod, which, p, o, shape):
+    """One batch through the C-ABI of the product library (which = None) or of a variant
+    build (hip_api.library), host pointers."""
+    import contextlib
+    N, nx, nu, nc = shape
+    B = p.batch
+    with (hipmod.library(which) if which else contextlib.nullcontext()):
+        s = hipmod.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    kern = s.kernel_name()
+    s.UpdateOptions(_opts(hipmod, o))
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    s.close()
+    return kern, z, l, v, y, out
+
+
+@pytest.mark.parametrize("inst", range(5))
+def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, oracle, inst):
+    """VERDICT r3 item 5.  The record kernels' cooperative passes read EVERY lane's policy
+    object (v_readlane of rec, pack, lpo, N ...), also of rows that hold no QP; a member
+    that no code path has set is `undef` in the IR, which the optimiser may resolve
+    differently from build to build (the <12,4,32> episode).  The
+    variant library `libfbstab_hip_pattern.so` is the same sources compiled with
+    -ftrivial-auto-var-init=pattern (and -Wuninitialized -Wconditional-uninitialized,
+    clean): every automatic variable starts from a fixed bit pattern, so such a read gives
+    the same garbage every time - and a result that depends on it differs from the product
+    build's.  For each of the five record instances: its four fuzz shapes of
+    test_random_shapes_on_every_mpc_instance plus batches of 1, 2, 3, 5 and 7 QPs (rows
+    and whole wavefront halves without a QP) on an exact and a padded shape - outputs of
+    the two builds bitwise equal, and at parity with the oracle."""
+    import os
+    if not os.path.exists(hip.VARIANTS["pattern"]):
+        pytest.fail("fbstab_amd/libfbstab_hip_pattern.so is missing: `make -C fbstab_amd/csrc pattern` "
+                    "(__graft_entry__.build() builds it)")
+    cases = []
+    for j in range(4):
+        idx = 4 * inst + j
+        shape, kern = _MPC_SHAPES[idx]
+        rng = np.random.default_rng(7000 + idx)
+        B = int(rng.integers(2, 12))
+        o = default_options()
+        if idx % 3 == 2:
+            o = default_options(max_linesearch_iters=int(rng.integers(1, 12)),
+                                nonmonotone_linesearch=int(rng.random() < 0.5))
+        cases.append((shape, kern, fx.random_ltv_mpc(rng, B, *shape), o))
+    for j in (0, 1):  # exact and padded shape of the instance, tiny batches
+        shape, kern = _MPC_SHAPES[4 * inst + j]
+        for B in (1, 2, 3, 5, 7):
+            rng = np.random.default_rng(9000 + 100 * inst + 10 * j + B)
+            cases.append((shape, kern, fx.random_ltv_mpc(rng, B, *shape), default_options()))
+    for shape, kern, p, o in cases:
+        a = _solve_on(hip, None, p, o, shape)
+        b = _solve_on(hip, "pattern", p, o, shape)
+        assert a[0] == kern and b[0] == kern, (a[0], b[0], kern)
+        for x, y_ in zip(a[1:5], b[1:5]):
+            assert np.array_equal(x, y_), (shape, p.batch)
+        for f in ("eflag", "residual", "newton_iters", "prox_iters", "initial_residual"):
+            assert np.array_equal(a[5][f], b[5][f]), (shape, p.batch, f)
+        c = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+        oc = c[4]
+        assert np.array_equal(a[5]["eflag"], oc["eflag"]), (shape, p.batch)
+        assert np.array_equal(a[5]["prox_iters"], oc["prox_iters"]), (shape, p.batch)
+        assert np.abs(a[5]["newton_iters"].astype(int) - oc["newton_iters"].astype(int)).max() <= 2
+        good = oc["eflag"] == 0
+        if good.any():
+            scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+            assert (np.abs(a[1] - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
+
+
 # (nz, nl, nv) -> threads per QP of the kernel that must run it (one wavefront for
 # nz + nl <= 64, four beyond; the K-in-global-memory layout above ~140)
 _DENSE_SHAPES = [
@@ -369,3 +438,67 @@ def test_overflowed_and_nan_guesses_end_where_the_reference_ends(hip, oracle, mo
     for q, r in ref.items():
         assert out["newton_iters"][q] == r[4]["newton_iters"][0] and out["prox_iters"][q] == r[4]["prox_iters"][0]
         assert np.abs(z[q] - r[0][0]).max() <= 1e-5 * (1 + np.abs(r[0][0]).max())
+
+
+# ---- the degenerate dense family --------------------------------------
+# tools/fuzz_dense.py 200 <seed> 64: random shapes with up to 239 inequality rows over at
+# most 64 variables.  The shapes below are the ones on which the NATURAL elimination order
+# of the one-wavefront kernel took a different number of proximal or Newton iterations than
+# the oracle (seed 11: the seven shapes of profiles/r03_af_dense_factorisation_orders.txt;
+# seeds 12 and 13: profiles/r04_a_dense_order_choice.txt); the instances are regenerated from
+# the tool's own random stream.
+_DEGENERATE_SHAPES = {11: [(38, 20, 172), (46, 16, 205), (52, 11, 226), (36, 6, 196), (41, 22, 200), (31, 15, 106),
+                           (25, 5, 170)],
+                      12: [(30, 2, 130), (35, 17, 144), (31, 12, 170), (41, 19, 179), (40, 20, 152), (34, 3, 205),
+                           (42, 17, 137)],
+                      13: [(38, 20, 109), (41, 22, 87), (45, 19, 167), (51, 12, 234), (43, 6, 231), (35, 17, 168),
+                           (33, 14, 232), (34, 15, 171)]}
+
+
+def _fuzz_dense_instances(seed, wanted, n=200, kmax=64):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nz = int(rng.integers(1, 160)); nl = int(rng.integers(0, min(nz, 24) + 1)); nv = int(rng.integers(1, 240))
+        nz = int(rng.integers(1, kmax + 1)); nl = int(rng.integers(0, min(nz, 24, kmax - nz) + 1))
+        B = int(rng.integers(1, 10))
+        first_id = int(rng.integers(0, 1 << 20))
+        if (nz, nl, nv) in wanted:
+            out.append((nz, nl, nv, B, first_id))
+    return out
+
+
+@pytest.mark.parametrize("seed", sorted(_DEGENERATE_SHAPES))
+def test_degenerate_dense_shapes_in_the_default_order(hip, oracle, seed):
+    """The default (Eigen's) elimination order on the shapes where the natural order parts
+    from the oracle: exit flags, proximal AND Newton counts equal on every QP, solutions
+    and multipliers' image G'l + A'v within the parity tolerance.  The opt-in orders on the
+    same QPs: same exit flags (all converge) and the same z to the tolerance - their
+    iteration counts are allowed to differ, that is what the option's documentation says."""
+    inst = _fuzz_dense_instances(seed, set(_DEGENERATE_SHAPES[seed]))
+    assert len(inst) == len(_DEGENERATE_SHAPES[seed]), inst
+    o = default_options()
+    handed_over = 0
+    for nz, nl, nv, B, first_id in inst:
+        p = fx.synthetic_dense_batch(B, nz, nl, nv, first_id=first_id)
+        c = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
+        oc = c[4]
+        for order in (None, "auto", "natural"):
+            s = hip.FBstabDenseBatch(nz, nl, nv, max_batch=B)
+            assert s.query()["threads"] == 64
+            if order:
+                s.SetFactorisation(s.ORDER_AUTO if order == "auto" else s.ORDER_NATURAL)
+            z = np.zeros((B, nz)); l = np.zeros((B, nl)); v = np.zeros((B, nv)); y = np.zeros((B, nv))
+            out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+            fac = s.Factorisation()
+            s.close()
+            assert np.array_equal(out["eflag"], oc["eflag"]), (nz, nl, nv, order)
+            scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+            assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all(), (nz, nl, nv, order)
+            if order is None:
+                assert fac["order"] == s.ORDER_PIVOTED
+                assert np.array_equal(out["prox_iters"], oc["prox_iters"]), (nz, nl, nv)
+                assert np.array_equal(out["newton_iters"], oc["newton_iters"]), (nz, nl, nv)
+            elif order == "auto":
+                handed_over += fac["pivoted_steps"]
+    assert handed_over > 0  # (AUTO does hand steps of these QPs to the pivoted path)

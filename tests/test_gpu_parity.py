@@ -46,8 +46,10 @@ def _solve_mpc_host(hip, p, opts, guess=None):
     return z, l, v, y, out
 
 
-def _solve_dense_host(hip, p, opts, guess=None):
+def _solve_dense_host(hip, p, opts, guess=None, order=None):
     s = hip.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=p.batch)
+    if order is not None:  # fbstab_hip_dense_set_factorisation (default: the reference's order)
+        s.SetFactorisation({"pivoted": s.ORDER_PIVOTED, "auto": s.ORDER_AUTO, "natural": s.ORDER_NATURAL}[order])
     s.UpdateOptions(_opts(hip, opts))
     B = p.batch
     z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.full((B, p.nv), 7.0)
@@ -65,8 +67,10 @@ def _unique_duals(dense, vc, act_tol=1e-7):
     linearly independent.  Elsewhere (l, v) is any point of a face - FBstab returns the
     one its proximal path runs into, which depends on the rounding of every Newton solve
     in the directions where K's eigenvalues are of the size of sigma (cond(K) ~ 1e16):
-    the one-wavefront kernel, which eliminates in the natural order, and the oracle,
-    which pivots like Eigen, then agree in z, y and G'l + A'v but not in l and v."""
+    the one-wavefront kernel in its opt-in NATURAL / AUTO elimination orders
+    (fbstab_hip_dense_set_factorisation) and the oracle, which pivots like Eigen, then
+    agree in z, y and G'l + A'v but not in l and v.  (The default order is Eigen's and is
+    compared entry by entry.)"""
     nz, nl, nv = dense.nz, dense.nl, dense.nv
     B = vc.shape[0]
     uniq = np.zeros(B, dtype=bool)
@@ -373,27 +377,30 @@ def test_dense_synthetic_batch_parity(hip, oracle):
         o = default_options()
         gpu = _solve_dense_host(hip, p, o)
         cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
-        _assert_parity(gpu, cpu, o.abs_tol, dense=p)
+        _assert_parity(gpu, cpu, o.abs_tol, exact_frac=1.0, max_dn=0)
         assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("order", ["natural", "pivoted"])
+@pytest.mark.parametrize("order", ["default", "auto", "natural"])
 @pytest.mark.parametrize("shape", [(7, 0, 9), (16, 3, 20), (33, 5, 61), (30, 20, 64), (64, 0, 128), (48, 16, 131)])
 def test_dense_odd_shapes(hip, oracle, monkeypatch, shape, order):
     """Dense kernel paths by shape: no equalities, nz not a multiple of 16, nv not
     a multiple of 4 (scalar K assembly instead of MFMA), A too large for LDS,
-    nz + nl == 64 (largest register-resident solve).  Both factorisations of the
-    one-wavefront kernel: the natural order (default; multipliers of dual-degenerate QPs
-    compared through G'l + A'v) and Eigen's pivoting rule (FBSTAB_HIP_DENSE_PIVOTED=1:
-    the oracle's rounding, every multiplier compared entry by entry)."""
+    nz + nl == 64 (largest register-resident solve).  The default elimination order of the
+    one-wavefront kernel is Eigen's (dense_cholesky_solver.cc:70-79): iteration counts equal
+    the oracle's on every QP and every multiplier is compared entry by entry.  The opt-in
+    AUTO and NATURAL orders solve the same systems with differently ordered rounding
+    errors: same flags and counts on these shapes, multipliers of dual-degenerate QPs
+    ((30, 20, 64): 23 of 48) compared through G'l + A'v."""
     nz, nl, nv = shape
-    if order == "pivoted":
-        monkeypatch.setenv("FBSTAB_HIP_DENSE_PIVOTED", "1")
     p = fx.synthetic_dense_batch(48, nz, nl, nv, first_id=7000 + nz)
     o = default_options()
-    gpu = _solve_dense_host(hip, p, o)
+    gpu = _solve_dense_host(hip, p, o, order=None if order == "default" else order)
     cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
-    _assert_parity(gpu, cpu, o.abs_tol, dense=p if order == "natural" else None)
+    if order == "default":
+        _assert_parity(gpu, cpu, o.abs_tol, exact_frac=1.0, max_dn=0)
+    else:
+        _assert_parity(gpu, cpu, o.abs_tol, dense=p)
     assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
@@ -421,8 +428,9 @@ def test_dense_one_wavefront_kernel_is_selected_and_agrees_with_the_four_wavefro
     four = _solve_dense_host(hip, p, o)
     monkeypatch.delenv("FBSTAB_HIP_DENSE_THREADS")
     cpu = oracle.solve_dense(p, opts=o, nthreads=oracle.num_threads())
-    _assert_parity(wave, cpu, o.abs_tol, dense=p)
-    _assert_parity(wave, four, o.abs_tol, dense=p)
+    # (both kernels pivot like Eigen by default: every multiplier entry by entry)
+    _assert_parity(wave, cpu, o.abs_tol, exact_frac=1.0, max_dn=0)
+    _assert_parity(wave, four, o.abs_tol, exact_frac=1.0, max_dn=0)
 
 
 def test_dense_many_constraints_fall_back_to_the_four_wavefront_kernel(hip, oracle):

@@ -229,3 +229,87 @@ def test_sharded_entries_on_one_device_equal_the_plain_calls(monkeypatch, self_s
     assert np.array_equal(st[:, 0].astype(np.int64), r["stats"]["newton_sum"])
     s.close()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("counts,root", [((40, 24), 1), ((0, 48), 0), ((17, 30, 17), 2)])
+def test_several_shards_on_one_physical_device_equal_one_plain_call(monkeypatch, counts, root):
+    """The index arithmetic of the sharded entries with MORE THAN ONE shard, on the one GPU a
+    test box has: FBSTAB_HIP_SHARD_ALLOW_REPEATED_DEVICE=1 (test-only) lets a group name the
+    same device several times; every shard has its own handle, stream and arrays and reaches
+    the root through device copies.  Offsets of the shards on the root (`first`), packed and
+    one-record-per-QP layouts, an empty shard, a root that is not shard 0, and the log offsets
+    of the sharded sweep - all bitwise equal to ONE plain call over the whole batch.  (What
+    this cannot cover is ncclCommInitAll over several devices and the sends between them.)"""
+    import torch
+    from fbstab_amd import hip_api
+    from tools import fixtures as fx
+    monkeypatch.setenv("FBSTAB_HIP_SHARD_ALLOW_REPEATED_DEVICE", "1")
+    dev = torch.device("cuda:0")
+    n = len(counts)
+    B = sum(counts)
+    first = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+    up = lambda p: {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    g = hip_api.ShardGroup([0] * n)
+    for kind, p in (("mpc", fx.synthetic_mpc_batch(B, first_id=4100)), ("dense", fx.synthetic_dense_batch(B, 30, 6, 70, first_id=11))):
+        mk = (lambda mb: hip_api.FBstabMpcBatch(*p.sizes(), max_batch=mb)) if kind == "mpc" else \
+            (lambda mb: hip_api.FBstabDenseBatch(p.nz, p.nl, p.nv, max_batch=mb))
+        data = up(p)
+        z = lambda rows, w: torch.zeros((rows, w), dtype=torch.float64, device=dev)
+        plain = mk(B)
+        ref = (z(B, p.nz), z(B, p.nl), z(B, p.nv), z(B, p.nv))
+        out_ref = hip_api.out_to_numpy(plain.Solve(data, *ref))
+        plain.close()
+        solvers = [mk(max(c, 1)) for c in counts]
+        shard_data = [{k: a[first[d]:first[d + 1]].contiguous() if a.shape[0] == B else a for k, a in data.items()}
+                      for d in range(n)]
+        # an empty shard still needs (B_d = 0)-row tensors for the binding; the library skips it
+        nvar = p.nz + p.nl + 2 * p.nv
+        cut = lambda r: (r[:, :p.nz], r[:, p.nz:p.nz + p.nl], r[:, p.nz + p.nl:p.nz + p.nl + p.nv], r[:, p.nz + p.nl + p.nv:nvar])
+        for layout in ("packed", "record"):
+            if layout == "packed":
+                xs = [(z(c, p.nz), z(c, p.nl), z(c, p.nv), z(c, p.nv)) for c in counts]
+                root_x = (z(B, p.nz) + 7, z(B, p.nl) + 7, z(B, p.nv) + 7, z(B, p.nv) + 7)
+            else:
+                recs = [z(c, nvar + 3) for c in counts]
+                xs = [cut(r) for r in recs]
+                rroot = z(B, nvar + 3) + 3
+                root_x = cut(rroot)
+            outs = [torch.zeros((c, 40), dtype=torch.uint8, device=dev) for c in counts]
+            root_out = torch.zeros((B, 40), dtype=torch.uint8, device=dev)
+            before = g.stats()
+            g.Solve(solvers, shard_data, xs, outs, root, root_x, root_out)
+            after = g.stats()
+            assert after["gathers"] == before["gathers"] + 1 and after["rccl_ops"] == before["rccl_ops"]
+            for a, b in zip(root_x, ref):
+                assert torch.equal(a, b), (kind, layout)
+            o = hip_api.out_to_numpy(root_out)
+            for f in ("eflag", "residual", "newton_iters", "prox_iters", "initial_residual"):
+                assert np.array_equal(o[f], out_ref[f]), f
+            if layout == "record":  # the root's columns behind y of the LAST record are the caller's
+                assert float(rroot[B - 1, nvar:].min()) == 3.0
+        for s in solvers:
+            s.close()
+    # configs[4]: shard d's [steps][counts[d]][nu] log at root_u_log + steps * nu * first[d]
+    steps = 5
+    p = fx.synthetic_mpc_batch(B, first_id=77)
+    A, Bm = fx.quadrotor_model()
+    z = lambda rows, w: torch.zeros((rows, w), dtype=torch.float64, device=dev)
+    s = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B)
+    r = s.RecedingSweep(up(p), z(B, p.nz), z(B, p.nl), z(B, p.nv), z(B, p.nv), A, Bm, steps, retire=True, log_inputs=True)
+    s.close()
+    data = up(p)
+    shard_data = [{k: a[first[d]:first[d + 1]].contiguous() for k, a in data.items()} for d in range(n)]
+    solvers = [hip_api.FBstabMpcBatch(*p.sizes(), max_batch=max(c, 1)) for c in counts]
+    us = [torch.zeros((steps, c, p.nu), dtype=torch.float64, device=dev) for c in counts]
+    ru = torch.full((steps * B * p.nu,), 5.0, dtype=torch.float64, device=dev)
+    outs = [torch.zeros((c, 40), dtype=torch.uint8, device=dev) for c in counts]
+    xs = [(z(c, p.nz), z(c, p.nl), z(c, p.nv), z(c, p.nv)) for c in counts]
+    st = g.RecedingSweep(solvers, shard_data, xs, outs, A, Bm, steps, True, us, root, ru)
+    for d in range(n):
+        blk = ru[steps * p.nu * first[d]: steps * p.nu * first[d + 1]].reshape(steps, counts[d], p.nu)
+        assert torch.equal(blk, r["u"][:, first[d]:first[d + 1], :]), d
+    assert np.array_equal(st[:, 0].astype(np.int64), r["stats"]["newton_sum"])
+    for s in solvers:
+        s.close()
+    g.close()
