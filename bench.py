@@ -100,28 +100,48 @@ def cgroup_cpu_quota():
     return None
 
 
+def library_sha256():
+    """sha256 of the solver library this process runs (the counter summaries record the same)."""
+    import hashlib
+    from fbstab_amd import hip_api
+    try:
+        with open(hip_api.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def stored_traffic(batch: int):
-    """HBM bytes per launch of the record kernel from the newest committed
-    rocprofv3 --pmc summary for this batch size (FETCH_SIZE and WRITE_SIZE in
-    separate passes; bench.py cannot run the profiler on itself, so the figure is
-    REPLAYED from profiles/, not measured in this run).  Returns a dict:
-    corrected bytes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies the
-    16-byte-per-lane reads of the records at half their bytes on gfx950, so the read
-    side is doubled; WRITE_SIZE is exact), the raw counter sum, the regime the
-    counters were taken in, and the source file."""
+    """HBM bytes per launch of the record kernel from a committed rocprofv3 --pmc summary for
+    this batch size (FETCH_SIZE and WRITE_SIZE in separate passes; bench.py cannot run the
+    profiler on itself, so the figure is REPLAYED from profiles/, not measured in this run).
+    The summary taken on THIS build (library_sha256 recorded by tools/pmc_lib.sh) is preferred;
+    failing that the newest one by name, marked as another build's.  Returns a dict: corrected
+    bytes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies the 16-byte-per-lane reads of
+    the records at half their bytes on gfx950, so the read side is doubled - an estimate the
+    slot-by-slot ledger of DESIGN.md 4.1 supports; WRITE_SIZE is exact), the raw counter sum,
+    the regime the counters were taken in, and the source file."""
     import glob
+    sha = library_sha256()
+    found = []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if t.get("batch") == batch:
-                return {"corrected": t["hbm_bytes_per_launch_fetch_doubled"], "raw": t["hbm_bytes_per_launch_raw"],
-                        "regime": t.get("regime", "one launch at a time (rocprofv3 --pmc over tools/variant_bench.py)"),
-                        "source": "profiles/" + os.path.basename(path) + " (replayed; build " +
-                                  str(t.get("build", "unrecorded")) + ")"}
+                same = sha is not None and t.get("library_sha256") == sha
+                found.append((same, {
+                    "corrected": t["hbm_bytes_per_launch_fetch_doubled"], "raw": t["hbm_bytes_per_launch_raw"],
+                    "regime": t.get("regime", "one launch at a time (rocprofv3 --pmc over tools/variant_bench.py)"),
+                    "build_matches": same,
+                    "source": "profiles/" + os.path.basename(path) + " (replayed; build " +
+                              str(t.get("build", "unrecorded")) + ("" if same else "; NOT the library of this run") + ")"}))
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    for same, t in found:
+        if same:
+            return t
+    return found[0][1] if found else None
 
 
 def main():
@@ -319,6 +339,7 @@ def main():
                          "traffic_ratio": (traffic / (ALG_BYTES_PER_QP * B)) if traffic else None,
                          "traffic_regime": tr["regime"] if tr else None,
                          "traffic_source": tr["source"] if tr else None,
+                         "traffic_build_matches": tr["build_matches"] if tr else None,
                          "traffic_per_step_GBps": (traffic / per_step_s / 1e9) if traffic else None,
                          "kernel": head["kernel"], "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B,
@@ -344,8 +365,7 @@ def main():
             if "latency" in rec:
                 cpu_ms = 1e3 / rec["cpu_baseline"]["single_thread_value"]
                 lat = rec["latency"]
-                lat["cpu_single_thread_ms_per_qp"] = cpu_ms
-                lat["gpu_batch1_over_cpu_single_thread"] = lat["device_pointers"]["1"]["ms_median"] / cpu_ms
+                lat["cpu_single_thread_ms_per_qp_mean_over_sample"] = cpu_ms
         elif world > 1:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))
@@ -414,10 +434,13 @@ def bench_dense(torch, dev, fx, hip_api, batch=4096, steps=24, lanes=8, order=No
         try:
             with open(path) as f:
                 t = json.load(f)
+            if t.get("order", "natural") != order:  # (summaries older than round 4: the natural order)
+                continue
             traffic_raw = t["derived"]["hbm_bytes_per_launch_raw"]
             # corrected: the read side doubled (16-byte-per-lane reads, MI355X_MICROARCH.md HBM section)
             traffic = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
-            traffic_src = "profiles/" + os.path.basename(path) + " (replayed; one launch at a time under rocprofv3 --pmc)"
+            traffic_src = ("profiles/" + os.path.basename(path) + " (replayed; one launch at a time under rocprofv3 --pmc; " +
+                           ("this build" if t.get("library_sha256") == library_sha256() else "NOT the library of this run") + ")")
             break
         except (OSError, ValueError, KeyError):
             pass
@@ -471,6 +494,22 @@ def bench_latency(torch, dev, fx, hip_api, batches=(1, 16, 256, 2048), repeats=7
             "kernel_ms_median": float(np.median(kms[1:])), "qps_per_sec": b / (1e-3 * float(np.median(ms[1:]))),
             "max_newton_iters": int(o["newton_iters"].max()), "all_converged": bool((o["eflag"] == 0).all())}
         s.close()
+    # the CPU restatement on the SAME QP (instance 0, the batch-of-one above), one thread
+    try:
+        from oracle.oracle_py import Oracle
+        orc = Oracle(False)
+        p1 = fx.synthetic_mpc_batch(1)
+        orc.solve_mpc(p1, nthreads=1)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            oo = orc.solve_mpc(p1, nthreads=1)[4]
+            ts.append(1e3 * (time.perf_counter() - t0))
+        res["cpu_same_qp_single_thread"] = {"ms_median": float(np.median(ts)), "ms_min": float(np.min(ts)),
+                                            "newton_iters": int(oo["newton_iters"][0]), "kind": "port"}
+        res["gpu_batch1_over_cpu_same_qp"] = res["device_pointers"]["1"]["ms_median"] / float(np.median(ts))
+    except Exception as e:  # (the oracle is a checker: its absence does not stop the bench)
+        res["cpu_same_qp_single_thread"] = {"error": str(e)}
     exe = os.path.join(ROOT, "tools", "cpp", "facade_latency")
     if os.path.exists(exe):
         p = fx.synthetic_mpc_batch(1)

@@ -54,7 +54,7 @@ namespace fbk {
 // Sub-phase cycles of the factorisation loop (diagnostic builds): summed in registers,
 // one atomic per factorisation (an atomic per lap would be most of what is measured).
 // (-DFB_DW_NO_INNER_LAPS keeps the phase laps of newton_step only: the laps inside the unrolled
-// factorisation cost it registers, tools/dense_variant.sh var_dstamp -DFB_CLOCKSTAMP -DFB_DW_NO_INNER_LAPS)
+// factorisation cost it registers, tools/dense_variant.sh var_dstamp -DFB_CLOCKSTAMP -DFB_DW_NO_INNER_LAPS -> tools/_build/)
 #if (defined(FB_STAMP) || defined(FB_CLOCKSTAMP)) && !defined(FB_DW_NO_INNER_LAPS)
 #define FB_DW_LAPS_DECL long long dw_acc_[4] = {0, 0, 0, 0}; long long dw_t_ = __builtin_readcyclecounter()
 #define FB_DW_LAP(i) do { const long long n_ = __builtin_readcyclecounter(); dw_acc_[i] += n_ - dw_t_; dw_t_ = n_; } while (0)

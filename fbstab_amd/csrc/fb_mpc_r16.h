@@ -920,6 +920,7 @@ struct MpcR16 {
       wln_in = ld(stage_ptr(q > 0 ? q - 1 : 0), sWLN);
     }
     for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
+      FB_PHASE(trip_top);
       if constexpr (FB_R16_TRIAL_AHEAD == 0) {
         load_trial(stage_ptr(i), in);
         wln_in = ld(stage_ptr(i > 0 ? i - 1 : 0), sWLN);
@@ -959,6 +960,7 @@ struct MpcR16 {
           s[K + k] = live ? fma(pn, pn, s[K + k]) : s[K + k];
         });
       });
+      FB_PHASE(trip_end);
     }
     TrialNorms<K> out;
     sfor<0, 2 * K>([&](auto Kk) {
@@ -1358,6 +1360,7 @@ struct MpcR16 {
       in.hn = ld(Rn, sH);
     };
     for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
+      FB_PHASE(trip_top);
       const bool live = i <= N_;
       const int ii = live ? i : N_;
       const bool has_next = ii < N_;
@@ -1423,6 +1426,7 @@ struct MpcR16 {
         s_vo += vo;
         s_vi += vi;
       }
+      FB_PHASE(trip_end);
     }
     OpenSums o;
     o.nat = rows_sum(s_nat);
@@ -1486,6 +1490,7 @@ struct MpcR16 {
       }
     };
     for (int i = q; i - q <= N_; i += QW) {
+      FB_PHASE(trip_top);
       const bool live = i <= N_;
       const int ii = live ? i : N_;
       const bool has_next = ii < N_;
@@ -1596,6 +1601,7 @@ struct MpcR16 {
         s_fdz += l_fdz;
         s_p2 += l_p2;
       }
+      FB_PHASE(trip_end);
     }
     CloseSums o;
     o.dx2 = rows_sum(s_dx);
@@ -1710,6 +1716,7 @@ struct MpcR16 {
       }
     };
     for (int i = qr; i - qr <= N_; i += QW) {  // (the same trip count in every row)
+      FB_PHASE(trip_top);
       const bool live = i <= N_;
       const int ii = live ? i : N_;
       double* R = R0 + (long)ii * kRec;
@@ -1790,6 +1797,7 @@ struct MpcR16 {
           st2(R, sDV + 2 * sl, 0.0, 0.0);
         });
       }
+      FB_PHASE(trip_end);
     }
     LoadSums o;
     o.c2m = rows_max(c2m);
@@ -1855,6 +1863,7 @@ struct MpcR16 {
     // 518 k against 520 k QP/s.  The stores here are fire-and-forget and the next stage's
     // loads do not wait for them.)
     for (int i = 0; i <= N_; i++) {
+      FB_PHASE(write_top);
       const double* R = R0 + (long)i * kRec;
       const double zz = ld(R, WHICH == 0 ? sZ : (WHICH == 1 ? sZB : sDZ));
       const double ll = ld(R, WHICH == 0 ? sL : (WHICH == 1 ? sLB : sDL));

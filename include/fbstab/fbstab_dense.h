@@ -197,6 +197,17 @@ class FBstabDense {
   static Options DefaultOptions() { Options o; o.DefaultParameters(); return o; }
   static Options ReliableOptions() { Options o; o.ReliableParameters(); return o; }
 
+  // Not in the reference: the elimination order of the KKT factorisation
+  // (fbstab_hip_dense_set_factorisation).  PIVOTED - Eigen::LDLT's rule,
+  // dense_cholesky_solver.cc:70-79 - is the default and reproduces the reference's iteration
+  // counts; NATURAL and AUTO are faster and may take a different number of iterations on
+  // ill-conditioned QPs (same solutions to the tolerance).
+  enum class FactorisationOrder { AUTO = 0, PIVOTED = 1, NATURAL = 2 };
+  void SetFactorisationOrder(FactorisationOrder order, int spread_bits = 0) {
+    if (fbstab_hip_dense_set_factorisation(h_, static_cast<int>(order), spread_bits) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabDense::SetFactorisationOrder: ") + fbstab_hip_last_error());
+  }
+
  private:
   int nz_, nl_, nv_;
   Options opts_;
@@ -218,6 +229,10 @@ class FBstabDenseBatch {
     o.ValidateOptions();
     fbstab_options_t c = o.ToC();
     fbstab_hip_dense_set_options(h_, &c);
+  }
+  void SetFactorisationOrder(FBstabDense::FactorisationOrder order, int spread_bits = 0) {
+    if (fbstab_hip_dense_set_factorisation(h_, static_cast<int>(order), spread_bits) != FBSTAB_HIP_OK)
+      throw std::runtime_error(std::string("In FBstabDenseBatch::SetFactorisationOrder: ") + fbstab_hip_last_error());
   }
   void Solve(int batch, const fbstab_dense_batch_t& data, const fbstab_var_batch_t& x,
              fbstab_solver_out_t* out, int flags = FBSTAB_HIP_HOST_POINTERS, void* stream = nullptr) {

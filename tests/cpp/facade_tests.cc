@@ -70,6 +70,34 @@ static void FeasibleQPwithEQ() {
   EXPECT_NEAR(x0.z(1), 0.75, 1e-8);
 }
 
+// Not in the reference: the opt-in elimination orders give the same solution
+// (FBstabDense::SetFactorisationOrder -> fbstab_hip_dense_set_factorisation).
+static void FactorisationOrders() {
+  const int n = 2, m = 1, q = 2;
+  FBstabDense::ProblemData data(n, m, q);
+  data.H = {4, 1, 1, 2};
+  data.f = {1, 1};
+  data.G = {1, 1};
+  data.h = {1};
+  data.A = {-1, 0, 0, -1};
+  data.b = {0, 0};
+  const FBstabDense::FactorisationOrder orders[3] = {FBstabDense::FactorisationOrder::PIVOTED,
+                                                     FBstabDense::FactorisationOrder::AUTO,
+                                                     FBstabDense::FactorisationOrder::NATURAL};
+  for (int k = 0; k < 3; k++) {
+    FBstabDense::Variable x0(n, m, q);
+    FBstabDense solver(n, m, q);
+    solver.UpdateOptions(DenseOpts());
+    solver.SetFactorisationOrder(orders[k]);
+    SolverOut out = solver.Solve(data, &x0);
+    EXPECT_TRUE(out.eflag == ExitFlag::SUCCESS);
+    EXPECT_NEAR(x0.z(0), 0.25, 1e-8);
+    EXPECT_NEAR(x0.z(1), 0.75, 1e-8);
+  }
+  FBstabDense solver(n, m, q);
+  EXPECT_THROW(solver.SetFactorisationOrder(static_cast<FBstabDense::FactorisationOrder>(7)));
+}
+
 static void DegenerateQP() {
   const int n = 2, m = 0, q = 5;
   std::unique_ptr<double[]> zmem(new double[n]), lmem(new double[1]), vmem(new double[q]), ymem(new double[q]);
@@ -514,6 +542,7 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "display") return DisplayMode();
   FeasibleQP();
   FeasibleQPwithEQ();
+  FactorisationOrders();
   DegenerateQP();
   InfeasibleAndUnboundedQP();
   DoubleIntegrator();

@@ -86,7 +86,56 @@ def main():
         print(f"{ph:22s}" + "".join(f"{cnt.get(n, 0):10d}" for n in names) + f"{valu:8d}{sum(cnt.values()):8d}")
         tot.update(cnt)
     valu = sum(v for k, v in tot.items() if k in VALU)
-    print(f"{'sum (static)':22s}" + "".join(f"{tot.get(n, 0):10d}" for n in names) + f"{valu:8d}{sum(tot.values()):8d}")
+    print(f"{'sum_static':22s}" + "".join(f"{tot.get(n, 0):10d}" for n in names) + f"{valu:8d}{sum(tot.values()):8d}")
+
+    # ---- the cooperative passes (real calls: functions of their own in the assembly) ----
+    def scan(fn_substr):
+        st = next((i for i, l in enumerate(lines) if fn_substr in l.split(";")[0] and l.split(";")[0].rstrip().endswith(":")
+                   and "ILi12ELi4ELi20ELb1ELb0ELi1EE" in l), None)
+        if st is None:
+            return None
+        en = next(i for i in range(st, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+        inside, body, rest = False, collections.Counter(), collections.Counter()
+        for l in lines[st:en]:
+            t = l.strip()
+            m = re.match(r"; FBPHASE (\w+)", t)
+            if m:
+                inside = m.group(1) == "trip_top"
+                continue
+            if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+                continue
+            (body if inside else rest)[classify(t.split()[0], t.split(";")[0])] += 1
+        return body, rest
+    v = lambda c: sum(n for k, n in c.items() if k in VALU)
+    passes = {}
+    print("\ncooperative passes (EXACT instance): VALU / all instructions per trip (between the trip markers) and outside the loop")
+    for name in ("trial_pass_coop", "open_pass_coop", "close_pass_coop", "load_pass_coop"):
+        r = scan(name)
+        if r is None:
+            print(f"  {name}: not found")
+            continue
+        body, rest = r
+        passes[name] = (v(body), v(rest))
+        print(f"  {name:18s} per trip {v(body):5d} VALU / {sum(body.values()):5d} all ({body.get('fma_f64', 0)} fma, {body.get('dpp_move', 0)} dpp moves, "
+              f"{body.get('vmem', 0)} vmem); outside the loop {v(rest):5d} VALU / {sum(rest.values()):5d} all")
+
+    # ---- dynamic estimate for the 8192-QP BASELINE batch (call counts: profiles/r03_zzz_r16_wave_time_shares.txt) ----
+    calls = {"newton_step": 47571, "trial_pass_coop": 184539, "open_pass_coop": 26813, "close_pass_coop": 18621,
+             "load_pass_coop": 8192}
+    N1, trips = 31, 8
+    fwd = [ph for ph in table if ph.startswith(f"{row_copy}:") and ph.split(":")[1] not in
+           ("k_general", "bwd_top", "9", "10", "bwd_end", "fwd_end")]
+    bwd = [f"{row_copy}:bwd_top", f"{row_copy}:9", f"{row_copy}:10"]
+    vf = sum(v(table[ph]) for ph in fwd)
+    vb = sum(v(table[ph]) for ph in bwd if ph in table)
+    est = {"newton_step (forward + backward stage, bounds path, row form)": calls["newton_step"] * N1 * (vf + vb)}
+    for name, (vbody, vrest) in passes.items():
+        est[name] = calls[name] * (trips * vbody + vrest)
+    total = sum(est.values())
+    print(f"\nforward stage {vf} VALU, backward stage {vb} VALU per wavefront (four QPs)")
+    for k, n in est.items():
+        print(f"  {k:70s} {n / 1e9:6.3f} G")
+    print(f"  {'sum':70s} {total / 1e9:6.3f} G   (SQ_INSTS_VALU of the same batch, profiles/r03_zzz_r16_sq_counters.json: 5.151 G)")
 
 
 if __name__ == "__main__":

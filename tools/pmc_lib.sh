@@ -32,6 +32,8 @@ for f in sorted(glob.glob("$OUT/p*.json")):
         if r["dispatch_id"]==last:
             tot[r["counter"]]=r["value"]; tot.setdefault("kernel_ms_under_pmc",[]).append(round(r["duration_ns"]/1e6,3))
 tot["kernel_ms_under_pmc"]=sorted(set(tot.get("kernel_ms_under_pmc",[])))
+import hashlib, os
+tot["library_sha256"]=hashlib.sha256(open(os.environ["FBSTAB_HIP_LIB"],"rb").read()).hexdigest()
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     tot["hbm_bytes_per_launch_raw"]=(tot["FETCH_SIZE"]+tot["WRITE_SIZE"])*1024
     tot["hbm_bytes_per_launch_fetch_doubled"]=(2*tot["FETCH_SIZE"]+tot["WRITE_SIZE"])*1024

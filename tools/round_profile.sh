@@ -2,9 +2,9 @@
 # Developer tool (GPU box): the measurements a round's profiles/ entries come from.
 #   tools/round_profile.sh <tag>      results under gpurun_out/<tag>/
 T=$1; O=gpurun_out/$T; mkdir -p $O; R=$PWD
-if [ -f fbstab_amd/var_stamp.so ]; then
-  FBSTAB_HIP_LIB=fbstab_amd/var_stamp.so timeout 300 python tools/stamp_report.py 8192 2>&1 | grep -v amdgpu > $O/mpc_wave_time_shares.txt
-  FBSTAB_HIP_LIB=fbstab_amd/var_stamp.so timeout 300 python tools/dense_stamp.py 2>&1 | grep -v amdgpu > $O/dense_wave_time_shares.txt
+if [ -f tools/_build/var_stamp.so ]; then
+  FBSTAB_HIP_LIB=tools/_build/var_stamp.so timeout 300 python tools/stamp_report.py 8192 2>&1 | grep -v amdgpu > $O/mpc_wave_time_shares.txt
+  FBSTAB_HIP_LIB=tools/_build/var_stamp.so timeout 300 python tools/dense_stamp.py 2>&1 | grep -v amdgpu > $O/dense_wave_time_shares.txt
   tail -8 $O/mpc_wave_time_shares.txt; tail -24 $O/dense_wave_time_shares.txt
 fi
 bash tools/pmc_lib.sh $O/pmc_mpc fbstab_amd/libfbstab_hip.so 8192 > $O/pmc_mpc.log 2>&1; tail -1 $O/pmc_mpc.log | cut -c1-400

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: per-phase cycle shares of the MPC kernel from a -DFB_STAMP
-build (FBSTAB_HIP_LIB=fbstab_amd/var_stamp.so).  argv: batch [wgs_per_cu]."""
+build (FBSTAB_HIP_LIB=tools/_build/var_stamp.so; per-phase lines need -DFB_STAMP, the
+wave-level shares -DFB_CLOCKSTAMP).  argv: batch [wgs_per_cu]."""
 import ctypes as C
 import os
 import sys
@@ -28,15 +29,17 @@ for rep in range(2):
 lib.fbstab_hip_debug_stamps(st, 1)
 newton = max(int(st[31]), 1)   # newton steps executed by row 0 of each wave
 stages = newton * 31
-print("backtracking trials per newton step (row 0):", st[30] / newton)
+if st[30]:
+    print("backtracking trials per newton step (row 0):", st[30] / newton)
 names = {0: "fwd loads+pfb", 1: "K build", 2: "rhs/h", 3: "chol16", 4: "tri_inv16", 5: "transpose+t+stores",
          6: "AB load + W", 7: "WW'", 8: "chol12+T+Pinv", 9: "bwd solve", 10: "bwd post+trial",
          16: "loop top", 17: "newton_step total", 18: "linesearch"}
 print(f"batch={B} kernel_ms={ms:.2f} newton_total={newton} q={s.query()}")
-for k in sorted(names):
-    per = st[k] / stages if k < 16 else st[k] / newton
-    unit = "cyc/stage" if k < 16 else "cyc/newton-iter"
-    print(f"   [{k:2d}] {names[k]:22s} {per:12.0f} {unit}")
+if any(st[k] for k in names):  # (a -DFB_CLOCKSTAMP build carries the wave-level counters only)
+    for k in sorted(names):
+        per = st[k] / stages if k < 16 else st[k] / newton
+        unit = "cyc/stage" if k < 16 else "cyc/newton-iter"
+        print(f"   [{k:2d}] {names[k]:22s} {per:12.0f} {unit}")
 
 if st[27]:
     useful = int(out["newton_iters"].sum())

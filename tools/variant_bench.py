@@ -15,6 +15,8 @@ from tools import fixtures as fx  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 p = fx.synthetic_mpc_batch(B)
+if os.environ.get("FB_WORKLOAD") == "ltv":  # the bench line's ltv_dense_rows block: per-stage matrices, dense rows
+    p = fx.synthetic_mpc_ltv_batch(B)
 same = os.environ.get("FB_SAME")
 if same is not None:
     # every QP of the batch is a physical copy of instance `same` (no divergence
