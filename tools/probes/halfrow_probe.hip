@@ -1,0 +1,321 @@
+// Developer probe: the arithmetic core of the record kernel's forward stage
+//   Lc = chol(K + sigma I);  X = inv(Lc) by columns and W = [A B] inv(Lc)' from the same pass;
+//   Pi+ = sigma I + W W';  L = chol(Pi+);  T = inv(L);  inv(Pi+) = T'T      (fb_row16.h, fb_mpc_r16.h)
+// in two layouts, timed and compared:
+//   ROW   the kernel's: four QPs per wavefront, one per 16-lane DPP row, lane r holds row r of every
+//         16 x 16 stage matrix (16 doubles per array) - what needs ~500 registers in the kernel and
+//         therefore ONE wavefront per SIMD;
+//   HALF  two QPs per wavefront, TWO lanes per matrix row: lane (h, r), h = the DPP row of the pair,
+//         holds the columns 2 m + h of row r (8 doubles per array) - half the registers, so TWO
+//         wavefronts per SIMD.  The other half's values come through v_permlane16_swap (spread<2>), a
+//         one-lane row shift makes ONE row_newbcast:c serve both halves, sums over a row's columns are
+//         formed per half and added.
+// Both run the same number of QP-stages (1024 x 4 against 2048 x 2 per pass); occupancy is set by the
+// dynamic LDS size (40 KB: four workgroups per CU, 20 KB: eight).  Prints the largest difference of the
+// results and the time per pass of each layout at each occupancy.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../fbstab_amd/csrc -o halfrow_probe halfrow_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "fb_row16.h"
+
+using namespace fbk;
+
+constexpr int NS = 16, NX = 12;
+constexpr double kSigma = 1e-8;
+
+// ---------------------------------------------------------------- ROW layout (the kernel's code)
+__device__ __forceinline__ void stage_row(const double (&Hrow)[NS], const double (&ABrow)[NS], double (&Pinv)[NX], int r,
+                                          double& chk) {
+  const bool rx = r < NX;
+  double K[NS];
+  sfor<0, NS>([&](auto C_) {
+    constexpr int c = decltype(C_)::value;
+    K[c] = Hrow[c];
+    if constexpr (c < NX) K[c] += Pinv[c];
+  });
+  chol_rows<NS, 1>(K, r, kSigma);
+  double XC[NS], W[NS];
+  sfor<0, NS>([&](auto C_) { W[decltype(C_)::value] = ABrow[decltype(C_)::value]; });
+  tri_inv_cols_solve<NS, 1>(K, XC, W, r);
+  double Pn[NX];
+  sfor<0, NX>([&](auto C_) { Pn[decltype(C_)::value] = 0.0; });
+  sfor<0, NS>([&](auto K_) {
+    constexpr int k = decltype(K_)::value;
+    const Spread<1> wks = spread<1>(W[k]);
+    bc_pipeline<NX>([&](auto I) { return bcs<1, decltype(I)::value>(wks); },
+                    [&](auto I, double t) { Pn[decltype(I)::value] = fma(W[k], t, Pn[decltype(I)::value]); });
+  });
+  sfor<0, NX>([&](auto C_) { Pn[decltype(C_)::value] = rx ? Pn[decltype(C_)::value] : 0.0; });
+  chol_rows<NX, 1>(Pn, r, kSigma);
+  double T[NX];
+  tri_inv_cols<NX, 1>(Pn, T, r);
+  sfor<0, NX>([&](auto C_) { Pinv[decltype(C_)::value] = 0.0; });
+  sfor<0, NX>([&](auto K_) {
+    constexpr int k = decltype(K_)::value;
+    const Spread<1> tks = spread<1>(T[k]);
+    bc_pipeline<k + 1>([&](auto I) { return bcs<1, decltype(I)::value>(tks); },
+                       [&](auto I, double t) { Pinv[decltype(I)::value] = fma(T[k], t, Pinv[decltype(I)::value]); });
+  });
+  sfor<0, NX>([&](auto C_) { Pinv[decltype(C_)::value] = rx ? Pinv[decltype(C_)::value] : 0.0; });
+  chk += XC[r & 15 ? 1 : 0];
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void row_kernel_t(const double* H, const double* AB, double* out, int iters) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  const long qp = ((long)blockIdx.x * 4 + (lane >> 4)) & 4095;  // (the timed runs reuse the 4096 problems)
+  double Hrow[NS], ABrow[NS], Pinv[NX];
+  for (int c = 0; c < NS; c++) {
+    Hrow[c] = H[(qp * NS + r) * NS + c];
+    ABrow[c] = r < NX ? AB[(qp * NX + r) * NS + c] : 0.0;
+  }
+  for (int c = 0; c < NX; c++) Pinv[c] = (r < NX && r == c) ? 1.0 / kSigma : 0.0;
+  double chk = 0.0;
+  for (int it = 0; it < iters; it++) stage_row(Hrow, ABrow, Pinv, r, chk);
+  if (r < NX)
+    for (int c = 0; c < NX; c++) out[(qp * NX + r) * NX + c] = Pinv[c];
+  if (chk == 12345.678 && smem[lane] == 1.0) out[0] = chk;  // (keeps XC and the LDS allocation alive)
+}
+
+// (WAVES = 2: the same code held to 256 registers - the core alone fits, the kernel's whole stage does not -
+// to see what a second wavefront WOULD buy the row layout)
+#define row_kernel row_kernel_t<1>
+#define row_kernel2 row_kernel_t<2>
+
+// ---------------------------------------------------------------- HALF layout
+// lane (h, r): register m of an N-column row-held matrix holds column 2 m + h of row r.
+template <int CTRL>
+__device__ __forceinline__ double dppd(double x) { return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xf, 0xf, true); }
+// lane n of the result holds lane n + 1's x in the odd half, lane n's in the even half
+__device__ __forceinline__ double shift_for_half(double x, bool hh) {
+  const double s = dppd<0x101>(x);  // row_shl:1
+  return hh ? s : x;
+}
+// column j of a matrix held in the half layout, as a vector indexed by the lane within the row (both halves)
+template <int J, int NM>
+__device__ __forceinline__ double column(const double (&a)[NM]) {
+  const Spread<2> s = spread<2>(a[J >> 1]);
+  return (J & 1) ? s.hi : s.lo;
+}
+// sum of the two halves' values, the same bits in both
+__device__ __forceinline__ double both(double x) {
+  const Spread<2> s = spread<2>(x);
+  return s.lo + s.hi;
+}
+
+// In-place Cholesky as chol_rows: on return a holds L (strictly lower part) and 1 / L[r][r] on the diagonal.
+template <int N>
+__device__ __forceinline__ bool chol_half(double (&a)[N / 2], int r, bool hh, double diag_add) {
+  bool ok = true;
+  sfor<0, N>([&](auto J_) {
+    constexpr int j = decltype(J_)::value, hj = j & 1, mj = j >> 1;
+    const double colv = column<j>(a);
+    const double d = bc<j>(colv) + diag_add;
+    ok = ok && d > 0.0;
+    const double q = rsqrt_full(d);
+    const double lj = colv * q, nlj = -lj;
+    const double ljs = shift_for_half(lj, hh);
+    const double wb = (r == j) ? q : lj;
+    if constexpr (hj == 0) {  // half 0: the pivot column (write back); half 1: column j + 1 (update)
+      const double upd = fma(nlj, bc<2 * mj>(ljs), a[mj]);
+      a[mj] = hh ? upd : wb;
+    } else {                  // half 1: the pivot column; half 0: column j - 1, finished
+      a[mj] = hh ? wb : a[mj];
+    }
+    sfor<mj + 1, N / 2>([&](auto M_) {
+      constexpr int m = decltype(M_)::value;
+      a[m] = fma(nlj, bc<2 * m>(ljs), a[m]);
+    });
+  });
+  return ok;
+}
+
+// Column r of inv(L) (x[m] = inv(L)[2 m + h][r]) and, fused, w <- w inv(L)' for a second matrix held the same
+// way (tri_inv_cols_solve of fb_row16.h).  WITH_W = false: the inverse alone.
+template <int N, bool WITH_W>
+__device__ __forceinline__ void tri_inv_half(const double (&a)[N / 2], double (&x)[N / 2], double (&w)[N / 2], int r, bool hh) {
+  sfor<0, N / 2>([&](auto M_) {
+    constexpr int m = decltype(M_)::value;
+    x[m] = (r == 2 * m + (hh ? 1 : 0)) ? 1.0 : 0.0;
+  });
+  sfor<0, N>([&](auto K_) {
+    constexpr int k = decltype(K_)::value, hk = k & 1, mk = k >> 1;
+    const double colv = column<k>(a);    // L[.][k], the reciprocal of the pivot on its diagonal
+    const double dg = bc<k>(colv);
+    // entry k of this lane's column of X (and of its row of W): final after the scaling; both halves need it
+    const double xk_own = x[mk] * dg;
+    [[maybe_unused]] double wk_own = 0.0;
+    if constexpr (WITH_W) wk_own = w[mk] * dg;
+    if (hh == (hk != 0)) {
+      x[mk] = xk_own;
+      if constexpr (WITH_W) w[mk] = wk_own;
+    }
+    const Spread<2> sx = spread<2>(xk_own);
+    const double nx = -(hk ? sx.hi : sx.lo);
+    [[maybe_unused]] double nw = 0.0;
+    if constexpr (WITH_W) {
+      const Spread<2> sw = spread<2>(wk_own);
+      nw = -(hk ? sw.hi : sw.lo);
+    }
+    const double ls = shift_for_half(colv, hh);
+    // rows 2 m + h > k
+    if constexpr (hk == 0 && mk < N / 2) {  // m = mk: row k + 1 in the odd half only
+      const double t = bc<2 * mk>(ls);
+      x[mk] = hh ? fma(t, nx, x[mk]) : x[mk];
+      if constexpr (WITH_W) w[mk] = hh ? fma(t, nw, w[mk]) : w[mk];
+    }
+    sfor<mk + 1, N / 2>([&](auto M_) {
+      constexpr int m = decltype(M_)::value;
+      const double t = bc<2 * m>(ls);
+      x[m] = fma(t, nx, x[m]);
+      if constexpr (WITH_W) w[m] = fma(t, nw, w[m]);
+    });
+  });
+}
+
+__device__ __forceinline__ void stage_half(const double (&Hh)[NS / 2], const double (&ABh)[NS / 2], double (&Pinvh)[NX / 2],
+                                           int r, bool hh, double& chk) {
+  const bool rx = r < NX;
+  double K[NS / 2];
+  sfor<0, NS / 2>([&](auto M_) {
+    constexpr int m = decltype(M_)::value;
+    K[m] = Hh[m];
+    if constexpr (m < NX / 2) K[m] += Pinvh[m];
+  });
+  chol_half<NS>(K, r, hh, kSigma);
+  double X[NS / 2], W[NS / 2];
+  sfor<0, NS / 2>([&](auto M_) { W[decltype(M_)::value] = ABh[decltype(M_)::value]; });
+  tri_inv_half<NS, true>(K, X, W, r, hh);
+  // Pi+ = W W': this lane sums over ITS columns k = 2 m + h for every output column c, the halves are added
+  double Pn[NX];
+  sfor<0, NX>([&](auto C_) { Pn[decltype(C_)::value] = 0.0; });
+  sfor<0, NS / 2>([&](auto M_) {
+    constexpr int m = decltype(M_)::value;
+    sfor<0, NX>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      Pn[c] = fma(W[m], bc<c>(W[m]), Pn[c]);
+    });
+  });
+  double Ph[NX / 2];
+  sfor<0, NX / 2>([&](auto M_) {
+    constexpr int m = decltype(M_)::value;
+    const double e = both(Pn[2 * m]), o = both(Pn[2 * m + 1]);
+    const double v = hh ? o : e;
+    Ph[m] = rx ? v : 0.0;
+  });
+  chol_half<NX>(Ph, r, hh, kSigma);
+  double T[NX / 2], dummy[NX / 2];
+  tri_inv_half<NX, false>(Ph, T, dummy, r, hh);
+  // inv(Pi+)[r][c] = sum_k T[k][r] T[k][c]: again per half over its own k, then added
+  double Pv[NX];
+  sfor<0, NX>([&](auto C_) { Pv[decltype(C_)::value] = 0.0; });
+  sfor<0, NX / 2>([&](auto M_) {
+    constexpr int m = decltype(M_)::value;
+    sfor<0, NX>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      if constexpr (c <= 2 * m + 1) Pv[c] = fma(T[m], bc<c>(T[m]), Pv[c]);
+    });
+  });
+  sfor<0, NX / 2>([&](auto M_) {
+    constexpr int m = decltype(M_)::value;
+    const double e = both(Pv[2 * m]), o = both(Pv[2 * m + 1]);
+    const double v = hh ? o : e;
+    Pinvh[m] = rx ? v : 0.0;
+  });
+  chk += X[1];
+}
+
+__global__ __launch_bounds__(64, 2) void half_kernel(const double* H, const double* AB, double* out, int iters) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  const bool hh = ((lane >> 4) & 1) != 0;
+  const int h = hh ? 1 : 0;
+  const long qp = ((long)blockIdx.x * 2 + (lane >> 5)) & 4095;
+  double Hh[NS / 2], ABh[NS / 2], Pinvh[NX / 2];
+  for (int m = 0; m < NS / 2; m++) {
+    Hh[m] = H[(qp * NS + r) * NS + 2 * m + h];
+    ABh[m] = r < NX ? AB[(qp * NX + r) * NS + 2 * m + h] : 0.0;
+  }
+  for (int m = 0; m < NX / 2; m++) Pinvh[m] = (r < NX && r == 2 * m + h) ? 1.0 / kSigma : 0.0;
+  double chk = 0.0;
+  for (int it = 0; it < iters; it++) stage_half(Hh, ABh, Pinvh, r, hh, chk);
+  if (r < NX)
+    for (int m = 0; m < NX / 2; m++) out[(qp * NX + r) * NX + 2 * m + h] = Pinvh[m];
+  if (chk == 12345.678 && smem[lane] == 1.0) out[0] = chk;
+}
+
+__global__ void shl_check(int* o) {
+  o[threadIdx.x] = __builtin_amdgcn_update_dpp(-1, (int)threadIdx.x, 0x101, 0xf, 0xf, true);
+}
+
+int main() {
+  const int nqp = 4096;
+  std::vector<double> H((size_t)nqp * NS * NS), AB((size_t)nqp * NX * NS);
+  unsigned long long s = 12345;
+  auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0; };
+  for (int q = 0; q < nqp; q++) {
+    double M[NS][NS];
+    for (int i = 0; i < NS; i++) for (int j = 0; j < NS; j++) M[i][j] = rnd();
+    for (int i = 0; i < NS; i++)
+      for (int j = 0; j < NS; j++) {
+        double a = 0;
+        for (int k = 0; k < NS; k++) a += M[k][i] * M[k][j];
+        H[((size_t)q * NS + i) * NS + j] = a / NS + (i == j ? 1.0 : 0.0);
+      }
+    for (int i = 0; i < NX; i++) for (int j = 0; j < NS; j++) AB[((size_t)q * NX + i) * NS + j] = 0.5 * rnd() + (i == j ? 1.0 : 0.0);
+  }
+  double *dH, *dAB, *o1, *o2;
+  int* di;
+  (void)hipMalloc(&dH, H.size() * 8); (void)hipMalloc(&dAB, AB.size() * 8);
+  (void)hipMalloc(&o1, (size_t)nqp * NX * NX * 8); (void)hipMalloc(&o2, (size_t)nqp * NX * NX * 8); (void)hipMalloc(&di, 64 * 4);
+  (void)hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dAB, AB.data(), AB.size() * 8, hipMemcpyHostToDevice);
+  shl_check<<<1, 64>>>(di);
+  int hi[64];
+  (void)hipMemcpy(hi, di, sizeof(hi), hipMemcpyDeviceToHost);
+  printf("row_shl:1 of the lane id: lane 0 <- %d, lane 14 <- %d, lane 15 <- %d, lane 16 <- %d (expect 1, 15, 0 (bound_ctrl), 17)\n", hi[0], hi[14], hi[15], hi[16]);
+  for (auto k : {(const void*)row_kernel, (const void*)half_kernel})
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  // results after 3 stages of the recursion
+  row_kernel<<<nqp / 4, 64, 40 * 1024>>>(dH, dAB, o1, 3);
+  half_kernel<<<nqp / 2, 64, 20 * 1024>>>(dH, dAB, o2, 3);
+  (void)hipDeviceSynchronize();
+  std::vector<double> a((size_t)nqp * NX * NX), b(a.size());
+  (void)hipMemcpy(a.data(), o1, a.size() * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(b.data(), o2, b.size() * 8, hipMemcpyDeviceToHost);
+  double md = 0, mx = 0;
+  for (size_t i = 0; i < a.size(); i++) { md = fmax(md, fabs(a[i] - b[i])); mx = fmax(mx, fabs(a[i])); }
+  printf("inv(Pi) after three stages, 4096 QPs: largest |row - half| = %.3e (largest entry %.3e)%s\n", md, mx,
+         (md <= 1e-9 * mx) ? "" : "  <-- DIFFERENT");
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int iters = 200;
+  (void)hipFuncSetAttribute((const void*)row_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  struct Cfg { const char* name; int half; int lds_kb; };
+  const Cfg cfgs[] = {{"ROW  layout, one wavefront per SIMD (40 KB LDS)", 0, 40},
+                      {"ROW  layout held to 256 registers, one per SIMD (40 KB)", 2, 40},
+                      {"ROW  layout held to 256 registers, two per SIMD (20 KB) - hypothetical", 2, 20},
+                      {"HALF layout, one wavefront per SIMD (40 KB LDS)", 1, 40}, {"HALF layout, two per SIMD (20 KB LDS)", 1, 20},
+                      {"HALF layout, three per SIMD (13 KB LDS)", 1, 13}, {"HALF layout, four per SIMD (10 KB LDS)", 1, 10}};
+  const int nt = 4 * nqp;  // 16,384 QPs per timed pass: every occupancy up to four wavefronts per SIMD is filled
+  for (const Cfg& c : cfgs) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+      (void)hipEventRecord(e0);
+      if (c.half == 1) half_kernel<<<nt / 2, 64, c.lds_kb * 1024>>>(dH, dAB, o2, iters);
+      else if (c.half == 2) row_kernel2<<<nt / 4, 64, c.lds_kb * 1024>>>(dH, dAB, o1, iters);
+      else row_kernel<<<nt / 4, 64, c.lds_kb * 1024>>>(dH, dAB, o1, iters);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    printf("%-66s %8.3f ms for %d stages of %d QPs = %6.2f ns per QP-stage\n", c.name, best, iters, nt, 1e6 * best / iters / nt);
+  }
+  return 0;
+}
