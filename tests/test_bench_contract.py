@@ -85,3 +85,30 @@ def test_algorithmic_bytes_match_the_survey_figure():
     per_qp = data + 8 * (nz + nl + nv) + 8 * (nz + nl + 2 * nv) + 40
     assert per_qp == 217736
     assert r["roofline"]["algorithmic_bytes_per_launch"] == per_qp * r["config"]["batch_per_gpu"]
+
+
+def test_round4_blocks_of_the_bench_line():
+    """the dense block is quoted in the DEFAULT (Eigen's) elimination
+    order with the opt-in orders beside it, and the line says what ONE caller sees - ms per cold
+    solve of small batches and of one FBstabMpc::Solve through the C++ facade, next to the CPU
+    restatement on the same QP.  (Lines older than round 4 carry neither block.)"""
+    r, path = _latest_line()
+    if "latency" not in r:
+        return
+    d = r["dense"]
+    assert d["factorisation_order"].startswith("pivoted") and d["pivoted_steps_per_launch"] in (0, -1)
+    for k in ("auto", "natural"):
+        o = d["opt_in_orders"][k]
+        assert o["value"] > 0 and o["all_converged"] and o["mean_newton_iters"] == d["mean_newton_iters"], (path, k)
+    lat = r["latency"]
+    for b in ("1", "16", "256", "2048"):
+        e = lat["device_pointers"][b]
+        assert e["ms_median"] >= e["ms_min"] > 0 and e["all_converged"], (path, b)
+    assert lat["device_pointers"]["1"]["ms_median"] <= lat["device_pointers"]["2048"]["ms_median"]
+    f = lat["facade_host_pointers"]
+    assert "error" not in f and f["median_ms"] > 0 and f["eflag"] == 0, (path, f)
+    c = lat["cpu_same_qp_single_thread"]
+    assert "error" not in c and c["ms_median"] > 0 and c["newton_iters"] == f["newton_iters"]
+    assert abs(lat["gpu_batch1_over_cpu_same_qp"] - lat["device_pointers"]["1"]["ms_median"] / c["ms_median"]) < 1e-9
+    if r["roofline"]["traffic"] is not None:
+        assert isinstance(r["roofline"]["traffic_build_matches"], bool)

@@ -371,6 +371,20 @@ def test_rows_that_never_get_a_qp_join_the_cooperative_passes(hip, oracle, batch
         assert (cpu[4]["eflag"] == 0).all() and (cpu[4]["newton_iters"] > 3).all()
 
 
+def test_time_varying_stages_with_sparse_dense_rows_match_the_oracle(hip, oracle):
+    """The bench line's `ltv_dense_rows` workload (tools/fixtures.py: synthetic_mpc_ltv_batch):
+    every stage its own matrices, every constraint row two or three nonzeros of order one.
+    No matrix copy is shared between stages, the bound-constraint path of the barrier term
+    does not apply and the costate step takes the reference's form (choose_costate_form).
+    Exit flags, proximal and Newton counts against the oracle."""
+    p = fx.synthetic_mpc_ltv_batch(96, first_id=500)
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+    assert (cpu[4]["eflag"] == 0).all()
+
+
 def test_dense_synthetic_batch_parity(hip, oracle):
     for (nz, nl, nv, B) in ((20, 5, 40, 64), (50, 10, 100, 256)):
         p = fx.synthetic_dense_batch(B, nz, nl, nv)
