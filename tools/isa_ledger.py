@@ -119,8 +119,8 @@ def main():
         print(f"  {name:18s} per trip {v(body):5d} VALU / {sum(body.values()):5d} all ({body.get('fma_f64', 0)} fma, {body.get('dpp_move', 0)} dpp moves, "
               f"{body.get('vmem', 0)} vmem); outside the loop {v(rest):5d} VALU / {sum(rest.values()):5d} all")
 
-    # ---- dynamic estimate for the 8192-QP BASELINE batch (call counts: profiles/r03_zzz_r16_wave_time_shares.txt) ----
-    calls = {"newton_step": 47571, "trial_pass_coop": 184539, "open_pass_coop": 26813, "close_pass_coop": 18621,
+    # ---- dynamic estimate for the 8192-QP BASELINE batch (call counts: profiles/r04_z_r16_wave_time_shares.txt) ----
+    calls = {"newton_step": 47634, "trial_pass_coop": 184539, "open_pass_coop": 26813, "close_pass_coop": 18621,
              "load_pass_coop": 8192}
     N1, trips = 31, 8
     fwd = [ph for ph in table if ph.startswith(f"{row_copy}:") and ph.split(":")[1] not in
@@ -135,7 +135,13 @@ def main():
     print(f"\nforward stage {vf} VALU, backward stage {vb} VALU per wavefront (four QPs)")
     for k, n in est.items():
         print(f"  {k:70s} {n / 1e9:6.3f} G")
-    print(f"  {'sum':70s} {total / 1e9:6.3f} G   (SQ_INSTS_VALU of the same batch, profiles/r03_zzz_r16_sq_counters.json: 5.151 G)")
+    import glob
+    import json
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_r16_sq_counters.json")))[-1]
+    measured = json.load(open(newest))["SQ_INSTS_VALU"]
+    print(f"  {'sum':70s} {total / 1e9:6.3f} G   (SQ_INSTS_VALU of the same batch, profiles/{os.path.basename(newest)}: "
+          f"{measured / 1e9:.3f} G; the call counts above are the DIAGNOSTIC build's - how many wavefront-level Newton steps "
+          f"the rows' 155,251 make depends on the build's timing)")
 
 
 if __name__ == "__main__":
