@@ -88,12 +88,12 @@ class _Plant(C.Structure):
 _libs: Dict[str, C.CDLL] = {}
 _current = LIB_PATH  # the library new solver objects bind to (see `library`)
 
-# Variant builds of the same sources that live beside the product library (tests):
+# Variant builds of the same sources (test artefacts under tests/_build/, not in this package):
 #   "pattern"  every automatic variable initialised to a bit pattern
 #              (-ftrivial-auto-var-init=pattern, `make -C fbstab_amd/csrc pattern`): a read
 #              of a value the code never set gives the same garbage in every build instead
 #              of whatever the optimiser resolved `undef` to
-VARIANTS = {"pattern": os.path.join(_HERE, "libfbstab_hip_pattern.so")}
+VARIANTS = {"pattern": os.path.join(os.path.dirname(_HERE), "tests", "_build", "libfbstab_hip_pattern.so")}
 if os.environ.get("FBSTAB_HIP_VARIANT"):
     _current = VARIANTS[os.environ["FBSTAB_HIP_VARIANT"]]
 

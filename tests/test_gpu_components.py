@@ -223,7 +223,7 @@ def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, 
     object (v_readlane of rec, pack, lpo, N ...), also of rows that hold no QP; a member
     that no code path has set is `undef` in the IR, which the optimiser may resolve
     differently from build to build (the <12,4,32> episode).  The
-    variant library `libfbstab_hip_pattern.so` is the same sources compiled with
+    variant library `tests/_build/libfbstab_hip_pattern.so` is the same sources compiled with
     -ftrivial-auto-var-init=pattern (and -Wuninitialized -Wconditional-uninitialized,
     clean): every automatic variable starts from a fixed bit pattern, so such a read gives
     the same garbage every time - and a result that depends on it differs from the product
@@ -233,7 +233,7 @@ def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, 
     the two builds bitwise equal, and at parity with the oracle."""
     import os
     if not os.path.exists(hip.VARIANTS["pattern"]):
-        pytest.fail("fbstab_amd/libfbstab_hip_pattern.so is missing: `make -C fbstab_amd/csrc pattern` "
+        pytest.fail("tests/_build/libfbstab_hip_pattern.so is missing: `make -C fbstab_amd/csrc pattern` "
                     "(__graft_entry__.build() builds it)")
     cases = []
     for j in range(4):
