@@ -18,17 +18,20 @@
 //     copy of A exists (40 KB per QP at 50/10/100: a third of the scratch a resident
 //     QP used to hold); the tiles reach the row layout through a 64 x 16 staging
 //     panel in LDS, one column block at a time;
+//   * LDL' by Eigen::LDLT's pivoting rule (largest |diagonal| of what is left, the first
+//     maximum wins; dense_cholesky_solver.cc:70-79), the DEFAULT since round 4: it
+//     eliminates in place without swapping anything and keeps its multipliers in a 64 x 64
+//     global scratch.  Same elimination order as the reference, same iteration counts on
+//     every QP tried ("which order is the default");
 //   * LDL' in the NATURAL order, unrolled over its steps and fused with both
-//     substitutions (factor_solve_static, round 3): K is quasi-definite, every
-//     elimination order factors it, and a compile-time order makes every register
-//     index an immediate - no pivot search, no pick of a run-time column, half the
-//     trailing updates, the multipliers used where they are formed and the backward
-//     sweep a lane-local dot product;
-//   * the pivoted LDL' (Eigen::LDLT's rule: largest |diagonal| of what is left,
-//     the first maximum wins; dense_cholesky_solver.cc:70-79), which eliminates in
-//     place without swapping anything and keeps its multipliers in a 64 x 64 global
-//     scratch, stays behind it for the matrices the natural order cannot take (a
-//     zero, denormal, infinite or NaN pivot): there the verdict is Eigen's;
+//     substitutions (factor_solve_static, round 3), a per-handle option
+//     (fbstab_hip_dense_set_factorisation: NATURAL, or AUTO = natural until a QP shows
+//     itself ill-conditioned): K is quasi-definite, every elimination order factors it,
+//     and a compile-time order makes every register index an immediate - no pivot search,
+//     no pick of a run-time column, half the trailing updates, the multipliers used where
+//     they are formed and the backward sweep a lane-local dot product; 1.6 x faster per
+//     launch, differently ordered rounding errors (a zero, denormal, infinite or NaN pivot
+//     still goes to the pivoted path, whose verdict is Eigen's);
 //   * right-hand side and solution of the substitutions stay in a register
 //     (lane t owns entry t), solved entries are handed round by v_readlane.
 //
@@ -38,8 +41,10 @@
 // path is the same factorisation as Eigen's up to rounding (right-looking here,
 // left-looking there; the pivot order is the same rule); the natural-order path
 // solves the same systems with a different rounding, which shows where the
-// answer is not unique: the multipliers of dual-degenerate QPs (tests/
-// test_gpu_parity.py, _unique_duals).
+// answer is not unique - the multipliers of dual-degenerate QPs (tests/
+// test_gpu_parity.py, _unique_duals) - and where a convergence test is decided by the
+// last digits: about one per cent of heavily degenerate QPs take a different number of
+// iterations (profiles/r04_a_dense_order_choice.txt).
 #pragma once
 
 #include <float.h>
