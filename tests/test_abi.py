@@ -67,3 +67,50 @@ def test_argument_validation_without_gpu(lib):
         # no shape is refused for its size (stages wider than the LDS run from global
         # scratch): what stops this call here is the missing device
         assert lib.fbstab_hip_mpc_create(30, 80, 4, 20, 1, 0, C.byref(h)) == 2
+
+
+def test_factorisation_option_of_the_dense_handle_without_gpu(lib):
+    """fbstab_hip_dense_set_factorisation / _get_factorisation (round 4): the enum of the
+    header, the binding's constants and the argument checks agree; the variant library of the
+    GPU tests is a test artefact outside the product package."""
+    from fbstab_amd import hip_api
+    hdr = open(os.path.join(ROOT, "include", "fbstab_hip.h")).read()
+    enum = dict(re.findall(r"FBSTAB_HIP_DENSE_ORDER_(\w+) = (\d)", hdr))
+    assert enum == {"AUTO": "0", "PIVOTED": "1", "NATURAL": "2"}
+    S = hip_api.FBstabDenseBatch
+    assert (S.ORDER_AUTO, S.ORDER_PIVOTED, S.ORDER_NATURAL) == (0, 1, 2)
+    assert lib.fbstab_hip_dense_set_factorisation(None, 1, 0) == 1          # null handle
+    assert lib.fbstab_hip_dense_get_factorisation(None, None, None, None) == 1
+    assert b"null solver handle" in lib.fbstab_hip_last_error()
+    pat = hip_api.VARIANTS["pattern"]
+    assert os.path.dirname(pat) == os.path.join(ROOT, "tests", "_build")
+    assert not any(f.endswith(".so") and f != "libfbstab_hip.so" for f in os.listdir(os.path.join(ROOT, "fbstab_amd")))
+    if os.path.exists(pat):  # both libraries load side by side and export the same interface
+        with hip_api.library("pattern") as v:
+            assert v is not lib
+            for name in hip_api.EXPORTED_SYMBOLS:
+                assert getattr(v, name) is not None
+        assert hip_api.load_library() is lib
+
+
+def test_replayed_traffic_prefers_the_summary_of_this_build(tmp_path, monkeypatch):
+    """bench.py replays counter bytes from profiles/ (it cannot profile itself): the summary
+    whose library_sha256 is the running library's wins over a newer-named one of another
+    build, and the line says which it was."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    mine = bench.library_sha256()
+    assert mine is not None and len(mine) == 64
+    base = {"batch": 8192, "hbm_bytes_per_launch_fetch_doubled": 7.0e10, "hbm_bytes_per_launch_raw": 5.0e10}
+    (prof / "r09_z_r16_traffic.json").write_text(json.dumps(dict(base, build="other", library_sha256="0" * 64)))
+    (prof / "r04_a_r16_traffic.json").write_text(json.dumps(dict(base, build="this", library_sha256=mine,
+                                                                  hbm_bytes_per_launch_raw=4.9e10)))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t = bench.stored_traffic(8192)
+    assert t["build_matches"] and t["raw"] == 4.9e10 and "r04_a_r16_traffic.json" in t["source"]
+    (prof / "r04_a_r16_traffic.json").unlink()
+    t = bench.stored_traffic(8192)
+    assert not t["build_matches"] and "NOT the library of this run" in t["source"]
+    assert bench.stored_traffic(4096) is None
