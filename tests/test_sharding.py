@@ -313,3 +313,44 @@ def test_several_shards_on_one_physical_device_equal_one_plain_call(monkeypatch,
     for s in solvers:
         s.close()
     g.close()
+
+
+@pytest.mark.gpu
+def test_sharded_entry_rejects_a_bad_shard_before_anything_is_queued(monkeypatch):
+    """a failure of shard d > 0 must not leave earlier shards' kernels in flight.  A null
+    data pointer in the SECOND shard is found by the checks that run before the first launch: the
+    call returns FBSTAB_HIP_ERR_ARGUMENT, the first shard's arrays are untouched, and the same
+    group and handles solve the corrected call afterwards."""
+    import ctypes as C
+    import torch
+    from fbstab_amd import hip_api
+    from tools import fixtures as fx
+    monkeypatch.setenv("FBSTAB_HIP_SHARD_ALLOW_REPEATED_DEVICE", "1")
+    dev = torch.device("cuda:0")
+    B = 16
+    p = fx.synthetic_mpc_batch(2 * B, first_id=3)
+    data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+    shard = [{k: a[d * B:(d + 1) * B].contiguous() for k, a in data.items()} for d in range(2)]
+    z = lambda rows, w: torch.zeros((rows, w), dtype=torch.float64, device=dev)
+    xs = [(z(B, p.nz) + 9, z(B, p.nl), z(B, p.nv), z(B, p.nv)) for _ in range(2)]
+    outs = [torch.zeros((B, 40), dtype=torch.uint8, device=dev) for _ in range(2)]
+    root_x = (z(2 * B, p.nz), z(2 * B, p.nl), z(2 * B, p.nv), z(2 * B, p.nv))
+    root_out = torch.zeros((2 * B, 40), dtype=torch.uint8, device=dev)
+    g = hip_api.ShardGroup([0, 0])
+    solvers = [hip_api.FBstabMpcBatch(*p.sizes(), max_batch=B) for _ in range(2)]
+    kind, bs, vs, counts, hs, op, var_lens = g._shards(solvers, hip_api.MPC_SEQ, solvers[0].seq_len, shard, xs, outs)
+    rv = hip_api._VarBatch()
+    hip_api._fill_var(rv, root_x, var_lens)
+    lib = hip_api.load_library()
+    bs[1].base[3] = None  # shard 1's q sequence
+    rc = lib.fbstab_hip_mpc_solve_batch_sharded(g._g, hs, counts, bs, vs, op, 0, C.byref(rv), C.c_void_p(root_out.data_ptr()))
+    assert rc == 1 and b"non-empty shard" in lib.fbstab_hip_last_error()
+    torch.cuda.synchronize()
+    assert float(xs[0][0].min()) == 9.0 and float(root_x[0].abs().max()) == 0.0  # nothing ran, nothing was gathered
+    assert g.stats()["gathers"] == 0
+    g.Solve(solvers, shard, [(z(B, p.nz), z(B, p.nl), z(B, p.nv), z(B, p.nv)) for _ in range(2)], outs, 0, root_x, root_out)
+    o = hip_api.out_to_numpy(root_out)
+    assert (o["eflag"] == 0).all() and float(root_x[0].abs().max()) > 0.0
+    for s_ in solvers:
+        s_.close()
+    g.close()
