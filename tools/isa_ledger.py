@@ -90,17 +90,18 @@ def main():
 
     # ---- the cooperative passes (real calls: functions of their own in the assembly) ----
     def scan(fn_substr):
+        # (the trip loop of a pass is one natural loop: the assembler's block comments say which
+        # blocks belong to it - the phase markers do not bracket it, the loop is laid out rotated)
         st = next((i for i, l in enumerate(lines) if fn_substr in l.split(";")[0] and l.split(";")[0].rstrip().endswith(":")
                    and "ILi12ELi4ELi20ELb1ELb0ELi1EE" in l), None)
         if st is None:
             return None
         en = next(i for i in range(st, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
         inside, body, rest = False, collections.Counter(), collections.Counter()
-        for l in lines[st:en]:
+        for l in lines[st + 1:en]:
             t = l.strip()
-            m = re.match(r"; FBPHASE (\w+)", t)
-            if m:
-                inside = m.group(1) == "trip_top"
+            if re.match(r"\.LBB\d+_\d+:", t):
+                inside = "Loop" in t
                 continue
             if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
                 continue
@@ -108,7 +109,7 @@ def main():
         return body, rest
     v = lambda c: sum(n for k, n in c.items() if k in VALU)
     passes = {}
-    print("\ncooperative passes (EXACT instance): VALU / all instructions per trip (between the trip markers) and outside the loop")
+    print("\ncooperative passes (EXACT instance): VALU / all instructions per trip (the blocks of the trip loop) and outside the loop")
     for name in ("trial_pass_coop", "open_pass_coop", "close_pass_coop", "load_pass_coop"):
         r = scan(name)
         if r is None:
@@ -128,7 +129,8 @@ def main():
     bwd = [f"{row_copy}:bwd_top", f"{row_copy}:9", f"{row_copy}:10"]
     vf = sum(v(table[ph]) for ph in fwd)
     vb = sum(v(table[ph]) for ph in bwd if ph in table)
-    est = {"newton_step (forward + backward stage, bounds path, row form)": calls["newton_step"] * N1 * (vf + vb)}
+    last = sum(v(table[ph]) for ph in fwd if ph.split(":")[1] in ("wwt", "7", "tinv12", "ttt", "8"))  # skipped at the last stage
+    est = {"newton_step (forward + backward stage, bounds path, row form)": calls["newton_step"] * (N1 * (vf + vb) - last)}
     for name, (vbody, vrest) in passes.items():
         est[name] = calls[name] * (trips * vbody + vrest)
     total = sum(est.values())
