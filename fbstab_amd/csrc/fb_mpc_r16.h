@@ -742,11 +742,7 @@ struct MpcR16 {
       s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
       {
         double p[4] = {s, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(vs[decltype(I)::value / LPQ]); },
-                        [&](auto I, double t) {
-                          constexpr int k = decltype(I)::value;
-                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
-                        });
+        bc_cols_dot<NC, RQ>(Cc, vs, p);
         s = (p[0] + p[1]) + (p[2] + p[3]);
       }
       st(R, sRZ, s);  // zero where there is no row: every term is
@@ -1127,11 +1123,7 @@ struct MpcR16 {
         m_dz = fmax(m_dz, fabs(cur.dz));
         {
           double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? cur.dl : 0.0), 0.0, 0.0, 0.0};
-          bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
-                          [&](auto I, double tt) {
-                            constexpr int k = decltype(I)::value;
-                            p[k & 3] = fma(Cc[k], tt, p[k & 3]);
-                          });
+          bc_cols_dot<NC, RQ>(Cc, dvs, p);
           m_atv = fmax(m_atv, fabs((p[0] + p[1]) + (p[2] + p[3])));
         }
         s_fdz = fma(fh[0], cur.dz, s_fdz);
@@ -1231,11 +1223,11 @@ struct MpcR16 {
       s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
       {
         double p[4] = {s, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(vy[decltype(I)::value / LPQ][0]); },
-                        [&](auto I, double t) {
-                          constexpr int k = decltype(I)::value;
-                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
-                        });
+        {
+          double vv[KS];
+          sfor<0, KS>([&](auto S_) { vv[decltype(S_)::value] = vy[decltype(S_)::value][0]; });
+          bc_cols_dot<NC, RQ>(Cc, vv, p);
+        }
         s = (p[0] + p[1]) + (p[2] + p[3]);
       }
       st(R, sRZ, s);
@@ -1388,11 +1380,11 @@ struct MpcR16 {
       s += dot4<NX>(ABc, lnb) - (rx ? ll : 0.0);
       {
         double p[4] = {s, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(vy[decltype(I)::value / LPQ][0]); },
-                        [&](auto I, double t) {
-                          constexpr int k = decltype(I)::value;
-                          p[k & 3] = fma(Cc[k], t, p[k & 3]);
-                        });
+        {
+          double vv[KS];
+          sfor<0, KS>([&](auto S_) { vv[decltype(S_)::value] = vy[decltype(S_)::value][0]; });
+          bc_cols_dot<NC, RQ>(Cc, vv, p);
+        }
         s = (p[0] + p[1]) + (p[2] + p[3]);
       }
       const double rl0 = rx ? fh[1] + zz : 0.0;
@@ -1551,11 +1543,7 @@ struct MpcR16 {
         l_dz = fabs(cur.dz);
         {
           double p[4] = {dot4<NX>(ABc, dlnb) - (rx ? cur.dl : 0.0), 0.0, 0.0, 0.0};
-          bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
-                          [&](auto I, double tt) {
-                            constexpr int k = decltype(I)::value;
-                            p[k & 3] = fma(Cc[k], tt, p[k & 3]);
-                          });
+          bc_cols_dot<NC, RQ>(Cc, dvs, p);
           l_atv = fabs((p[0] + p[1]) + (p[2] + p[3]));
         }
         l_fdz = fh[0] * cur.dz;
@@ -2087,11 +2075,7 @@ struct MpcR16 {
       sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] += Pinv[decltype(Cc)::value]; });
       {
         double p[4] = {r1, 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(Rvm[decltype(I)::value / LPQ]); },
-                        [&](auto I, double rk) {
-                          constexpr int k = decltype(I)::value;
-                          p[k & 3] = fma(-Cc_[k], rk, p[k & 3]);
-                        });
+        bc_cols_dot<NC, RQ, true>(Cc_, Rvm, p);
         r1 = (p[0] + p[1]) + (p[2] + p[3]);
       }
       FB_PHASE(krhs_end);
@@ -2111,9 +2095,13 @@ struct MpcR16 {
         sfor<0, NC>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
           const double gc = bcr<RQ, (k % LPQ)>(Gam[k / LPQ]) * Cc_[k];  // Gamma_k C[k][r]
+          if constexpr (kFmacDpp<RQ>) {
+            sfor<0, NS>([&](auto I) { fmac_bc<decltype(I)::value, decltype(I)::value == 0>(K[decltype(I)::value], Cc_[k], gc); });
+          } else {
           const Spread<RQ> cks = spread<RQ>(Cc_[k]);
           bc_pipeline<NS>([&](auto I) { return bcs<RQ, decltype(I)::value>(cks); },
                           [&](auto I, double t) { K[decltype(I)::value] = fma(gc, t, K[decltype(I)::value]); });
+          }
         });
       }
       FB_SB();
@@ -2205,9 +2193,13 @@ struct MpcR16 {
         sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = 0.0; });
         sfor<0, NS>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
+          if constexpr (kFmacDpp<RQ>) {
+            sfor<0, NX>([&](auto I) { fmac_bc<decltype(I)::value, decltype(I)::value == 0>(Pn[decltype(I)::value], W[k], W[k]); });
+          } else {
           const Spread<RQ> wks = spread<RQ>(W[k]);
           bc_pipeline<NX>([&](auto I) { return bcs<RQ, decltype(I)::value>(wks); },
                           [&](auto I, double t) { Pn[decltype(I)::value] = fma(W[k], t, Pn[decltype(I)::value]); });
+          }
         });
         sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = rx ? Pn[decltype(Cc)::value] : 0.0; });
         FB_SB();
@@ -2224,9 +2216,13 @@ struct MpcR16 {
         sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = 0.0; });
         sfor<0, NX>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
+          if constexpr (kFmacDpp<RQ>) {
+            sfor<0, k + 1>([&](auto I) { fmac_bc<decltype(I)::value, decltype(I)::value == 0>(Pinv[decltype(I)::value], T[k], T[k]); });
+          } else {
           const Spread<RQ> tks = spread<RQ>(T[k]);
           bc_pipeline<k + 1>([&](auto I) { return bcs<RQ, decltype(I)::value>(tks); },
                              [&](auto I, double t) { Pinv[decltype(I)::value] = fma(T[k], t, Pinv[decltype(I)::value]); });
+          }
         });
         sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = rx ? Pinv[decltype(Cc)::value] : 0.0; });
         FB_STAMP_LAP(8);
@@ -2368,11 +2364,7 @@ struct MpcR16 {
       double w;
       {
         double p[4] = {dot4<NS>(Hr, dzb) + (ROW ? u : u - dli), 0.0, 0.0, 0.0};
-        bc_pipeline<NC>([&](auto I) { return bcr<RQ, (decltype(I)::value % LPQ)>(dvs[decltype(I)::value / LPQ]); },
-                        [&](auto I, double t) {
-                          constexpr int k = decltype(I)::value;
-                          p[k & 3] = fma(Cc_[k], t, p[k & 3]);
-                        });
+        bc_cols_dot<NC, RQ>(Cc_, dvs, p);
         w = (p[0] + p[1]) + (p[2] + p[3]);
         if constexpr (ROW) {
           // form (b): the state rows of (H + sigma I) dz + G'dl + A'dv = -(rz + sigma (z - zbar))

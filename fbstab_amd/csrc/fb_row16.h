@@ -182,6 +182,50 @@ FB_DEV void bc_pipeline(Mov&& mov, Use&& use) {
   }
 }
 
+// ---- the broadcast fused into the FMA (round 4) -------------------------------------------
+// v_fmac_f64_dpp acc, src row_newbcast:J, mult  =  acc += (lane J of this row's src) * mult: the
+// pair v_mov_b64_dpp + v_fma_f64 of the streams above as ONE instruction, bitwise the same
+// result.  In the forward stage's arithmetic core (tools/probes/halfrow_probe.hip) it is
+// 18 % faster than the hand-pipelined pairs - no temporaries, no 17-cycle move-to-use distance
+// to schedule round - where the isolated instruction had measured 10 % (round 3).  One row per
+// QP only (R = 1: the 64-bit DPP forms exist for row_newbcast alone, a row PAIR needs the
+// spread).  Inline assembly is outside the compiler's hazard recognizer, so the two rules a DPP
+// operand brings are kept by hand:
+//   * two wait states between the VALU instruction that writes `src` and the first reader:
+//     the FIRST instruction of every group carries an s_nop 1 (all members of a group read the
+//     same src), and a scheduling barrier behind every member pins the group's order (a token
+//     operand would too - and makes the compiler put an s_nop between any two members: it treats
+//     a register an asm statement defines as a possible partial write);
+//   * five wait states behind a VALU write of EXEC: the only such writes are the v_cmpx of the
+//     hand-written LDS image blocks, which end with s_nop 4.
+// tools/check_dpp_hazards.py verifies both on the assembly of the record instances.
+#ifndef FB_FMAC_DPP
+#define FB_FMAC_DPP 1
+#endif
+// (NEG: acc -= ...: the source modifier of the multiplier, no instruction of its own)
+template <int J, bool FIRST, bool NEG = false>
+FB_DEV void fmac_bc(double& acc, double src, double mult) {
+  if constexpr (FIRST && NEG)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  else if constexpr (FIRST)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  else if constexpr (NEG)
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  else
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  FB_SB();
+}
+template <int R>
+constexpr bool kFmacDpp = FB_FMAC_DPP != 0 && R == 1;
+#ifndef FB_FMAC_DPP_DOT
+#define FB_FMAC_DPP_DOT 1   // the broadcast dot products (bc_dot) too
+#endif
+#ifndef FB_FMAC_DPP_SOLVE
+#define FB_FMAC_DPP_SOLVE 1 // tri_inv_cols_solve, where one broadcast feeds two FMAs (measured: +1.3 % on top)
+#endif
+
 // 1/sqrt(d) to full double precision: v_rsq_f64 seed (~2^-24 relative) and one
 // third-order step r(1 + e/2 + 3e^2/8), e = 1 - d r^2 (error ~e^3): four
 // dependent levels instead of the six of two Newton steps.  Split into stages
@@ -242,6 +286,14 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
     constexpr int j = decltype(J)::value;
     constexpr int cnt = N - j - 1;
     const double nljj = nlj;  // this pivot's column (lj is rewritten by level 6)
+    if constexpr (kFmacDpp<R>) {
+      const double src = lj;
+      sfor<0, cnt>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        fmac_bc<j + 1 + i, i == 0>(a[j + 1 + i], src, nljj);
+        if constexpr (i < kLevels) level(std::integral_constant<int, j + 1>{}, I);
+      });
+    } else {
     const Spread<R> ljs = spread<R>(lj);
     // column j + 1 first: the next pivot's chain hangs on it
     bc_pipeline<cnt>(
@@ -254,6 +306,7 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
             level(std::integral_constant<int, j + 1>{}, I);
           }
         });
+    }
     if constexpr (j + 1 < N) {
       sfor<(cnt < kLevels ? cnt : kLevels), kLevels>(
           [&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
@@ -274,6 +327,17 @@ FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
     if constexpr (k == 0) x[0] *= dg;
     const double nx = -x[k];
     if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
+    if constexpr (kFmacDpp<R>) {
+      FB_SB();
+      sfor<0, N - k - 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        fmac_bc<k + 1 + i, i == 0>(x[k + 1 + i], a[k], nx);
+        if constexpr (i == 0) {
+          x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
+          FB_SB();
+        }
+      });
+    } else {
     const Spread<R> aks = spread<R>(a[k]);
     FB_SB();
     bc_pipeline<N - k - 1>(
@@ -286,6 +350,7 @@ FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
             x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
           }
         });
+    }
   });
 }
 
@@ -307,6 +372,20 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
     }
     const double nx = -x[k], nw = -w[k];
     if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
+    if constexpr (kFmacDpp<R> && FB_FMAC_DPP_SOLVE != 0) {
+      FB_SB();
+      sfor<0, N - k - 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        fmac_bc<k + 1 + i, i == 0>(x[k + 1 + i], a[k], nx);
+        fmac_bc<k + 1 + i, false>(w[k + 1 + i], a[k], nw);
+        if constexpr (i == 0) {
+          x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
+          w[k + 1] *= dg;
+          FB_SB();
+        }
+      });
+      return;
+    }
     const Spread<R> aks = spread<R>(a[k]);
     FB_SB();
     bc_pipeline<N - k - 1>(
@@ -329,6 +408,13 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
 template <int B, int E, int R = 1, int N>
 FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
   double p[4] = {init, 0.0, 0.0, 0.0};
+  if constexpr (kFmacDpp<R> && FB_FMAC_DPP_DOT != 0) {
+    sfor<0, E - B>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      fmac_bc<B + i, i == 0>(p[i & 3], v, m[B + i]);
+    });
+    return (p[0] + p[1]) + (p[2] + p[3]);
+  }
   const Spread<R> vs = spread<R>(v);
   bc_pipeline<E - B>([&](auto I) { return bcs<R, B + decltype(I)::value>(vs); },
                      [&](auto I, double t) {
@@ -336,6 +422,26 @@ FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
                        p[i & 3] = fma(m[B + i], t, p[i & 3]);
                      });
   return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// p[k & 3] += (NEG: -=) C[k] * (lane k % (16 R) of src[k / (16 R)]), k in [0, NC): a column of the
+// constraint matrix against a vector that lives one entry per lane (v, dv, rv / mu, ...), four
+// partial sums as in bc_dot.
+template <int NC, int R, bool NEG = false, int NSRC>
+FB_DEV void bc_cols_dot(const double (&C)[NC], const double (&src)[NSRC], double (&p)[4]) {
+  constexpr int LPQ = 16 * R;
+  if constexpr (kFmacDpp<R> && FB_FMAC_DPP_DOT != 0) {
+    sfor<0, NC>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      fmac_bc<k % LPQ, (k % LPQ) == 0, NEG>(p[k & 3], src[k / LPQ], C[k]);
+    });
+  } else {
+    bc_pipeline<NC>([&](auto I) { return bcr<R, (decltype(I)::value % LPQ)>(src[decltype(I)::value / LPQ]); },
+                    [&](auto I, double t) {
+                      constexpr int k = decltype(I)::value;
+                      p[k & 3] = fma(NEG ? -C[k] : C[k], t, p[k & 3]);
+                    });
+  }
 }
 
 // out[c] = lane c's v, c in [0, N)

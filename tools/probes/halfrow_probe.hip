@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <vector>
 
+#define FB_FMAC_DPP 0  // (the library routines as hand-pipelined pairs: the fused forms are spelled out below)
 #include "fb_row16.h"
 
 using namespace fbk;
@@ -86,6 +87,141 @@ __global__ __launch_bounds__(64, WAVES) void row_kernel_t(const double* H, const
 // to see what a second wavefront WOULD buy the row layout)
 #define row_kernel row_kernel_t<1>
 #define row_kernel2 row_kernel_t<2>
+
+
+// ---------------------------------------------------------------- ROW layout, broadcast fused into the FMA
+// v_fmac_f64_dpp acc, src row_newbcast:J, mult  =  acc += (lane J of this row's src) * mult: the pair
+// v_mov_b64_dpp + v_fma_f64 as ONE instruction (two passes through the pipe).  Inline assembly is outside the
+// compiler's hazard recognizer: a DPP operand needs two wait states behind the VALU write of its source, so
+// the first instruction of every group carries an s_nop 1 and a token operand chains the group in order.
+// (A token operand chaining the group would also keep its order - and makes the compiler put an s_nop between
+// any two of them: it treats a VGPR an inline-assembly statement defines as a possible partial write that the
+// next reader must wait for.  A scheduling barrier behind every instruction pins the order for free.)
+template <int J, bool FIRST>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double mult, int&) {
+  if constexpr (FIRST)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  else
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  FB_SB();
+}
+
+template <int N>
+__device__ __forceinline__ bool chol_rows_f(double (&a)[N], int r, double diag_add) {
+  bool ok = true;
+  RsqrtChain ch;
+  double lj, nlj;
+  constexpr int kLevels = RsqrtChain::kStages + 2;
+  auto level = [&](auto J, auto S) {
+    constexpr int j = decltype(J)::value;
+    constexpr int lv = decltype(S)::value;
+    if constexpr (lv == 0) {
+      ch.d = bc<j>(a[j]) + diag_add;
+      ok = ok && (ch.d > 0.0);
+    } else if constexpr (lv <= RsqrtChain::kStages) {
+      ch.template stage<lv - 1>();
+    } else {
+      lj = a[j] * ch.q;
+      nlj = -lj;
+      a[j] = (r == j) ? ch.q : lj;
+    }
+    FB_SB();
+  };
+  sfor<0, kLevels>([&](auto S) { level(std::integral_constant<int, 0>{}, S); });
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int cnt = N - j - 1;
+    const double nljj = nlj, src = lj;
+    int tok = 0;
+    sfor<0, cnt>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      fmac_bc<j + 1 + i, i == 0>(a[j + 1 + i], src, nljj, tok);
+      if constexpr (i < kLevels) {
+        FB_SB();
+        level(std::integral_constant<int, j + 1>{}, I);
+      }
+    });
+    if constexpr (j + 1 < N) {
+      sfor<(cnt < kLevels ? cnt : kLevels), kLevels>([&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
+    }
+  });
+  return ok;
+}
+
+template <int N>
+__device__ __forceinline__ void tri_inv_cols_f(const double (&a)[N], double (&x)[N], int r) {
+  sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
+  double dg = bc<0>(a[0]);
+  sfor<0, N>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    if constexpr (k == 0) x[0] *= dg;
+    const double nx = -x[k];
+    if constexpr (k + 1 < N) dg = bc<k + 1>(a[k + 1]);
+    int tok = 0;
+    sfor<0, N - k - 1>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      fmac_bc<k + 1 + i, i == 0>(x[k + 1 + i], a[k], nx, tok);
+      if constexpr (i == 0) x[k + 1] *= dg;
+    });
+  });
+}
+
+__device__ __forceinline__ void stage_rowf(const double (&Hrow)[NS], const double (&ABrow)[NS], double (&Pinv)[NX], int r,
+                                           double& chk) {
+  const bool rx = r < NX;
+  double K[NS];
+  sfor<0, NS>([&](auto C_) {
+    constexpr int c = decltype(C_)::value;
+    K[c] = Hrow[c];
+    if constexpr (c < NX) K[c] += Pinv[c];
+  });
+  chol_rows_f<NS>(K, r, kSigma);
+  double XC[NS], W[NS];
+  sfor<0, NS>([&](auto C_) { W[decltype(C_)::value] = ABrow[decltype(C_)::value]; });
+  tri_inv_cols_solve<NS, 1>(K, XC, W, r);  // (one broadcast feeds two FMAs there: left as it is)
+  double Pn[NX];
+  sfor<0, NX>([&](auto C_) { Pn[decltype(C_)::value] = 0.0; });
+  sfor<0, NS>([&](auto K_) {
+    constexpr int k = decltype(K_)::value;
+    int tok = 0;
+    sfor<0, NX>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      fmac_bc<c, c == 0>(Pn[c], W[k], W[k], tok);
+    });
+  });
+  sfor<0, NX>([&](auto C_) { Pn[decltype(C_)::value] = rx ? Pn[decltype(C_)::value] : 0.0; });
+  chol_rows_f<NX>(Pn, r, kSigma);
+  double T[NX];
+  tri_inv_cols_f<NX>(Pn, T, r);
+  sfor<0, NX>([&](auto C_) { Pinv[decltype(C_)::value] = 0.0; });
+  sfor<0, NX>([&](auto K_) {
+    constexpr int k = decltype(K_)::value;
+    int tok = 0;
+    sfor<0, k + 1>([&](auto C_) {
+      constexpr int c = decltype(C_)::value;
+      fmac_bc<c, c == 0>(Pinv[c], T[k], T[k], tok);
+    });
+  });
+  sfor<0, NX>([&](auto C_) { Pinv[decltype(C_)::value] = rx ? Pinv[decltype(C_)::value] : 0.0; });
+  chk += XC[r & 15 ? 1 : 0];
+}
+
+__global__ __launch_bounds__(64, 1) void rowf_kernel(const double* H, const double* AB, double* out, int iters) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  const long qp = ((long)blockIdx.x * 4 + (lane >> 4)) & 4095;
+  double Hrow[NS], ABrow[NS], Pinv[NX];
+  for (int c = 0; c < NS; c++) {
+    Hrow[c] = H[(qp * NS + r) * NS + c];
+    ABrow[c] = r < NX ? AB[(qp * NX + r) * NS + c] : 0.0;
+  }
+  for (int c = 0; c < NX; c++) Pinv[c] = (r < NX && r == c) ? 1.0 / kSigma : 0.0;
+  double chk = 0.0;
+  for (int it = 0; it < iters; it++) stage_rowf(Hrow, ABrow, Pinv, r, chk);
+  if (r < NX)
+    for (int c = 0; c < NX; c++) out[(qp * NX + r) * NX + c] = Pinv[c];
+  if (chk == 12345.678 && smem[lane] == 1.0) out[0] = chk;
+}
 
 // ---------------------------------------------------------------- HALF layout
 // lane (h, r): register m of an N-column row-held matrix holds column 2 m + h of row r.
@@ -292,12 +428,25 @@ int main() {
   for (size_t i = 0; i < a.size(); i++) { md = fmax(md, fabs(a[i] - b[i])); mx = fmax(mx, fabs(a[i])); }
   printf("inv(Pi) after three stages, 4096 QPs: largest |row - half| = %.3e (largest entry %.3e)%s\n", md, mx,
          (md <= 1e-9 * mx) ? "" : "  <-- DIFFERENT");
+  {
+    double* o3;
+    (void)hipMalloc(&o3, (size_t)nqp * NX * NX * 8);
+    (void)hipFuncSetAttribute((const void*)rowf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    rowf_kernel<<<nqp / 4, 64, 40 * 1024>>>(dH, dAB, o3, 3);
+    (void)hipDeviceSynchronize();
+    std::vector<double> c(a.size());
+    (void)hipMemcpy(c.data(), o3, c.size() * 8, hipMemcpyDeviceToHost);
+    size_t nd = 0;
+    for (size_t i = 0; i < a.size(); i++) nd += a[i] != c[i];
+    printf("ROW with v_fmac_f64_dpp against ROW: %zu of %zu entries differ in any bit\n", nd, a.size());
+  }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 200;
   (void)hipFuncSetAttribute((const void*)row_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   struct Cfg { const char* name; int half; int lds_kb; };
   const Cfg cfgs[] = {{"ROW  layout, one wavefront per SIMD (40 KB LDS)", 0, 40},
+                      {"ROW  layout, broadcasts fused into the FMAs (v_fmac_f64_dpp), one per SIMD", 3, 40},
                       {"ROW  layout held to 256 registers, one per SIMD (40 KB)", 2, 40},
                       {"ROW  layout held to 256 registers, two per SIMD (20 KB) - hypothetical", 2, 20},
                       {"HALF layout, one wavefront per SIMD (40 KB LDS)", 1, 40}, {"HALF layout, two per SIMD (20 KB LDS)", 1, 20},
@@ -309,6 +458,7 @@ int main() {
       (void)hipEventRecord(e0);
       if (c.half == 1) half_kernel<<<nt / 2, 64, c.lds_kb * 1024>>>(dH, dAB, o2, iters);
       else if (c.half == 2) row_kernel2<<<nt / 4, 64, c.lds_kb * 1024>>>(dH, dAB, o1, iters);
+      else if (c.half == 3) rowf_kernel<<<nt / 4, 64, c.lds_kb * 1024>>>(dH, dAB, o1, iters);
       else row_kernel<<<nt / 4, 64, c.lds_kb * 1024>>>(dH, dAB, o1, iters);
       (void)hipEventRecord(e1);
       (void)hipEventSynchronize(e1);
