@@ -2096,7 +2096,8 @@ struct MpcR16 {
           constexpr int k = decltype(Kk)::value;
           const double gc = bcr<RQ, (k % LPQ)>(Gam[k / LPQ]) * Cc_[k];  // Gamma_k C[k][r]
           if constexpr (kFmacDpp<RQ>) {
-            sfor<0, NS>([&](auto I) { fmac_bc<decltype(I)::value, decltype(I)::value == 0>(K[decltype(I)::value], Cc_[k], gc); });
+            const Spread<RQ> cks = spread<RQ>(Cc_[k]);
+            sfor<0, NS>([&](auto I) { fmac_bcs<RQ, decltype(I)::value, 0>(K[decltype(I)::value], cks, gc); });
           } else {
           const Spread<RQ> cks = spread<RQ>(Cc_[k]);
           bc_pipeline<NS>([&](auto I) { return bcs<RQ, decltype(I)::value>(cks); },
@@ -2194,7 +2195,8 @@ struct MpcR16 {
         sfor<0, NS>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
           if constexpr (kFmacDpp<RQ>) {
-            sfor<0, NX>([&](auto I) { fmac_bc<decltype(I)::value, decltype(I)::value == 0>(Pn[decltype(I)::value], W[k], W[k]); });
+            const Spread<RQ> wks = spread<RQ>(W[k]);
+            sfor<0, NX>([&](auto I) { fmac_bcs<RQ, decltype(I)::value, 0>(Pn[decltype(I)::value], wks, W[k]); });
           } else {
           const Spread<RQ> wks = spread<RQ>(W[k]);
           bc_pipeline<NX>([&](auto I) { return bcs<RQ, decltype(I)::value>(wks); },
@@ -2217,7 +2219,8 @@ struct MpcR16 {
         sfor<0, NX>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
           if constexpr (kFmacDpp<RQ>) {
-            sfor<0, k + 1>([&](auto I) { fmac_bc<decltype(I)::value, decltype(I)::value == 0>(Pinv[decltype(I)::value], T[k], T[k]); });
+            const Spread<RQ> tks = spread<RQ>(T[k]);
+            sfor<0, k + 1>([&](auto I) { fmac_bcs<RQ, decltype(I)::value, 0>(Pinv[decltype(I)::value], tks, T[k]); });
           } else {
           const Spread<RQ> tks = spread<RQ>(T[k]);
           bc_pipeline<k + 1>([&](auto I) { return bcs<RQ, decltype(I)::value>(tks); },

@@ -202,6 +202,9 @@ FB_DEV void bc_pipeline(Mov&& mov, Use&& use) {
 #ifndef FB_FMAC_DPP
 #define FB_FMAC_DPP 1
 #endif
+#ifndef FB_FMAC_DPP_R2
+#define FB_FMAC_DPP_R2 1  // row pairs too: the spread halves are ordinary registers, each its own group
+#endif
 // (NEG: acc -= ...: the source modifier of the multiplier, no instruction of its own)
 template <int J, bool FIRST, bool NEG = false>
 FB_DEV void fmac_bc(double& acc, double src, double mult) {
@@ -218,7 +221,21 @@ FB_DEV void fmac_bc(double& acc, double src, double mult) {
   FB_SB();
 }
 template <int R>
-constexpr bool kFmacDpp = FB_FMAC_DPP != 0 && R == 1;
+constexpr bool kFmacDpp = FB_FMAC_DPP != 0 && (R == 1 || FB_FMAC_DPP_R2 != 0);
+// The same for a spread source: lane J of the QP is lane J of the value itself (R = 1), or lane
+// J & 15 of the even row's copy (J < 16) / of the odd row's (J >= 16), which spread() left in
+// both rows of the pair.  J0: the lane the group starts at - the first reader of each copy is
+// the one that waits (FIRST_OK = false: a second accumulator fed by the same lane, never first).
+template <int R, int J, int J0, bool NEG = false, bool FIRST_OK = true>
+FB_DEV void fmac_bcs(double& acc, const Spread<R>& s, double mult) {
+  if constexpr (R == 1) {
+    fmac_bc<J, FIRST_OK && J == J0, NEG>(acc, s.v, mult);
+  } else {
+    constexpr bool first = FIRST_OK && (J == J0 || (J == 16 && J0 < 16));
+    if constexpr (J < 16) fmac_bc<J, first, NEG>(acc, s.lo, mult);
+    else fmac_bc<J - 16, first, NEG>(acc, s.hi, mult);
+  }
+}
 #ifndef FB_FMAC_DPP_DOT
 #define FB_FMAC_DPP_DOT 1   // the broadcast dot products (bc_dot) too
 #endif
@@ -270,6 +287,8 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
     if constexpr (lv == 0) {
       // the caller's "+ diag_add * I" is applied here, at pivot time: no per-lane
       // (r == j) selects, which the compiler would otherwise hoist and keep live
+      // (the pivot's broadcast fused as diag_add + 1.0 * pivot - only v_fmac_f64 has a DPP form among
+      // the f64 instructions - changed nothing: 580 k against 583 k, gpurun of round 4)
       ch.d = bcr<R, j>(a[j]) + diag_add;
       ok = ok && (ch.d > 0.0);
     } else if constexpr (lv <= RsqrtChain::kStages) {
@@ -287,10 +306,10 @@ FB_DEV bool chol_rows(double (&a)[N], int r, double diag_add) {
     constexpr int cnt = N - j - 1;
     const double nljj = nlj;  // this pivot's column (lj is rewritten by level 6)
     if constexpr (kFmacDpp<R>) {
-      const double src = lj;
+      const Spread<R> src = spread<R>(lj);
       sfor<0, cnt>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        fmac_bc<j + 1 + i, i == 0>(a[j + 1 + i], src, nljj);
+        fmac_bcs<R, j + 1 + i, j + 1>(a[j + 1 + i], src, nljj);
         if constexpr (i < kLevels) level(std::integral_constant<int, j + 1>{}, I);
       });
     } else {
@@ -328,10 +347,11 @@ FB_DEV void tri_inv_cols(const double (&a)[N], double (&x)[N], int r) {
     const double nx = -x[k];
     if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
     if constexpr (kFmacDpp<R>) {
+      const Spread<R> aks = spread<R>(a[k]);
       FB_SB();
       sfor<0, N - k - 1>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        fmac_bc<k + 1 + i, i == 0>(x[k + 1 + i], a[k], nx);
+        fmac_bcs<R, k + 1 + i, k + 1>(x[k + 1 + i], aks, nx);
         if constexpr (i == 0) {
           x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
           FB_SB();
@@ -373,11 +393,12 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
     const double nx = -x[k], nw = -w[k];
     if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
     if constexpr (kFmacDpp<R> && FB_FMAC_DPP_SOLVE != 0) {
+      const Spread<R> aks = spread<R>(a[k]);
       FB_SB();
       sfor<0, N - k - 1>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        fmac_bc<k + 1 + i, i == 0>(x[k + 1 + i], a[k], nx);
-        fmac_bc<k + 1 + i, false>(w[k + 1 + i], a[k], nw);
+        fmac_bcs<R, k + 1 + i, k + 1>(x[k + 1 + i], aks, nx);
+        fmac_bcs<R, k + 1 + i, k + 1, false, false>(w[k + 1 + i], aks, nw);
         if constexpr (i == 0) {
           x[k + 1] *= dg;  // final: rows < k + 1 are all folded in
           w[k + 1] *= dg;
@@ -409,9 +430,10 @@ template <int B, int E, int R = 1, int N>
 FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
   double p[4] = {init, 0.0, 0.0, 0.0};
   if constexpr (kFmacDpp<R> && FB_FMAC_DPP_DOT != 0) {
+    const Spread<R> vs = spread<R>(v);
     sfor<0, E - B>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      fmac_bc<B + i, i == 0>(p[i & 3], v, m[B + i]);
+      fmac_bcs<R, B + i, B>(p[i & 3], vs, m[B + i]);
     });
     return (p[0] + p[1]) + (p[2] + p[3]);
   }
@@ -431,9 +453,13 @@ template <int NC, int R, bool NEG = false, int NSRC>
 FB_DEV void bc_cols_dot(const double (&C)[NC], const double (&src)[NSRC], double (&p)[4]) {
   constexpr int LPQ = 16 * R;
   if constexpr (kFmacDpp<R> && FB_FMAC_DPP_DOT != 0) {
-    sfor<0, NC>([&](auto Kk) {
-      constexpr int k = decltype(Kk)::value;
-      fmac_bc<k % LPQ, (k % LPQ) == 0, NEG>(p[k & 3], src[k / LPQ], C[k]);
+    sfor<0, (NC + LPQ - 1) / LPQ>([&](auto S_) {
+      constexpr int sl = decltype(S_)::value;
+      const Spread<R> ss = spread<R>(src[sl]);
+      sfor<LPQ * sl, (LPQ * (sl + 1) < NC ? LPQ * (sl + 1) : NC)>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        fmac_bcs<R, k % LPQ, 0, NEG>(p[k & 3], ss, C[k]);
+      });
     });
   } else {
     bc_pipeline<NC>([&](auto I) { return bcr<R, (decltype(I)::value % LPQ)>(src[decltype(I)::value / LPQ]); },

@@ -125,7 +125,7 @@ def main():
              "load_pass_coop": 8192}
     N1, trips = 31, 8
     fwd = [ph for ph in table if ph.startswith(f"{row_copy}:") and ph.split(":")[1] not in
-           ("k_general", "bwd_top", "9", "10", "bwd_end", "fwd_end")]
+           ("k_general", "bwd_top", "9", "10", "bwd_end", "fwd_end", "write_top")]
     bwd = [f"{row_copy}:bwd_top", f"{row_copy}:9", f"{row_copy}:10"]
     vf = sum(v(table[ph]) for ph in fwd)
     vb = sum(v(table[ph]) for ph in bwd if ph in table)
