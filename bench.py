@@ -207,7 +207,9 @@ def main():
             self.out = torch.zeros((p.batch, 40), dtype=torch.uint8, device=dev)
             self.grec = None
             if gather and rank == 0:
-                self.grec = [torch.empty_like(self.rec) for _ in range(world)]
+                # rank 0's own block is already where it has to be: its slot of the receive list IS its
+                # record (the gather then moves the other ranks' blocks only)
+                self.grec = [self.rec if g == rank else torch.empty_like(self.rec) for g in range(world)]
             self.events = []
 
     def run_mpc(p, data, P, steps, warmup, gather):

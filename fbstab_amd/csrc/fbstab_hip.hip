@@ -267,8 +267,11 @@ __global__ __launch_bounds__(NT, (NT > 64 ? 2 : 1)) void fbstab_dense_probe_kern
 // One wavefront per dense QP for every phase (fb_dense_wave.h; nz + nl <= 64): the KKT
 // matrix in registers, two wavefronts per SIMD.  scratch: one region of
 // lay.ws_doubles per workgroup (A' and the multipliers).  DBG: the Newton-step probe.
+#ifndef FB_DW_MIN_WAVES
+#define FB_DW_MIN_WAVES 2
+#endif
 template <bool DBG>
-__global__ __launch_bounds__(64, 2) void fbstab_dense_wave_kernel(DenseWaveLayout lay, DenseBatchArgs data,
+__global__ __launch_bounds__(64, FB_DW_MIN_WAVES) void fbstab_dense_wave_kernel(DenseWaveLayout lay, DenseBatchArgs data,
                                                                    VarBatchArgs x, fbstab_solver_out_t* out,
                                                                    fbstab_options_t opts, int* counter, int batch,
                                                                    double* scratch, double* dbg) {

@@ -40,7 +40,8 @@ def gather_solutions(x, out, dst: int = 0, record=None, gather_list: Optional[Li
     SolverOut) travel side by side in one ``(B, nvar + 5)`` float64 record per QP.
     ``record``: optional preallocated record buffer whose first columns ARE ``x``
     (then only the 40 bytes per QP of ``out`` are copied); ``gather_list``:
-    optional preallocated receive buffers on ``dst``.  Returns ``(X, O)`` stacked in
+    optional preallocated receive buffers on ``dst`` - ``gather_list[dst]`` may be ``record`` itself
+    (the root's own block is then not copied at all: it is resident where it was computed).  Returns ``(X, O)`` stacked in
     global instance order on ``dst`` (``O`` as uint8 ``(W*B, 40)``), ``(None,
     None)`` elsewhere.  ``stack=False`` (a caller that keeps its own receive
     buffers): no stacked copy is made on ``dst`` - at eight ranks that copy is

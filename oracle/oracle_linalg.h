@@ -153,6 +153,9 @@ struct Ldlt {
   bool compute(const double* A) {
     std::copy(A, A + (size_t)n * n, m.begin());
     ok = unblocked();
+#ifdef FBO_LDLT_OBSERVER  // studies of the elimination order (tools/cpp/ldlt_order_observer.h); never in liboracle.so
+    FBO_LDLT_OBSERVER(*this);
+#endif
     return ok;
   }
 

@@ -39,10 +39,15 @@ def _worker(rank, world, port, per_rank, q):
     # ... and without the stacked copy on rank 0 (bench.py: the receive buffers are kept)
     G3, none = sharding.gather_solutions(rec[:, :x.shape[1]], o, dst=0, record=rec, gather_list=glist, stack=False)
     assert none is None and (G3 is glist if rank == 0 else G3 is None)
+    # ... and with rank 0's slot of the receive list being its record itself (bench.py: the root's own
+    # block is not copied)
+    alias = [rec if g == 0 else torch.empty_like(rec) for g in range(world)] if rank == 0 else None
+    G4, _ = sharding.gather_solutions(rec[:, :x.shape[1]], o, dst=0, record=rec, gather_list=alias, stack=False)
     dist.gather = real_gather
-    assert len(calls) == 3, "one collective per batch"
+    assert len(calls) == 4, "one collective per batch"
     if rank == 0:
         assert torch.equal(X, X2) and torch.equal(O, O2)
+        assert G4[0] is rec and all(torch.equal(a, b) for a, b in zip(G4, glist))
         unpacked = np.concatenate([sharding.unpack_out(g) for g in glist])
         assert np.array_equal(unpacked["newton_iters"], np.frombuffer(O.numpy().tobytes(), dtype=out.dtype)["newton_iters"])
         q.put((X.numpy(), O.numpy()))
