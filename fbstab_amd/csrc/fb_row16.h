@@ -206,12 +206,26 @@ FB_DEV void bc_pipeline(Mov&& mov, Use&& use) {
 #define FB_FMAC_DPP_R2 1  // row pairs too: the spread halves are ordinary registers, each its own group
 #endif
 // (NEG: acc -= ...: the source modifier of the multiplier, no instruction of its own)
-template <int J, bool FIRST, bool NEG = false>
+// FB_FMAC_GUARD_NOP = 1: the first instruction of every group carries the s_nop 1 itself - safe by
+// construction, 155 s_nop per forward stage, 6 % of the arithmetic core's time
+// (tools/probes/halfrow_probe.hip -DPROBE_NO_NOP).  0 (the product build): no s_nop - in the code as it
+// is compiled the producer of a group's source is never among the two instructions before the group
+// (the pivot's scaling is followed by the negation and the diagonal select, a product's operands come
+// from an earlier phase), and tools/check_dpp_hazards.py PROVES that on the disassembly of the built
+// objects, every path into every fused instruction; `make` runs it and fails on a finding.
+#ifndef FB_FMAC_GUARD_NOP
+#define FB_FMAC_GUARD_NOP 0
+#endif
+// GUARD: the groups that keep their s_nop in every build - the source of a broadcast dot product
+// is as a rule the value just computed (theta + r, t - inv(Lc) u, ...), and a spread source comes
+// straight out of its v_permlane16_swap.
+template <int J, bool FIRST, bool NEG = false, bool GUARD = false>
 FB_DEV void fmac_bc(double& acc, double src, double mult) {
-  if constexpr (FIRST && NEG)
+  constexpr bool NOP = FIRST && (GUARD || FB_FMAC_GUARD_NOP != 0);
+  if constexpr (NOP && NEG)
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
         : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
-  else if constexpr (FIRST)
+  else if constexpr (NOP)
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
         : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
   else if constexpr (NEG)
@@ -226,14 +240,14 @@ constexpr bool kFmacDpp = FB_FMAC_DPP != 0 && (R == 1 || FB_FMAC_DPP_R2 != 0);
 // J & 15 of the even row's copy (J < 16) / of the odd row's (J >= 16), which spread() left in
 // both rows of the pair.  J0: the lane the group starts at - the first reader of each copy is
 // the one that waits (FIRST_OK = false: a second accumulator fed by the same lane, never first).
-template <int R, int J, int J0, bool NEG = false, bool FIRST_OK = true>
+template <int R, int J, int J0, bool NEG = false, bool FIRST_OK = true, bool GUARD = false>
 FB_DEV void fmac_bcs(double& acc, const Spread<R>& s, double mult) {
   if constexpr (R == 1) {
-    fmac_bc<J, FIRST_OK && J == J0, NEG>(acc, s.v, mult);
+    fmac_bc<J, FIRST_OK && J == J0, NEG, GUARD>(acc, s.v, mult);
   } else {
     constexpr bool first = FIRST_OK && (J == J0 || (J == 16 && J0 < 16));
-    if constexpr (J < 16) fmac_bc<J, first, NEG>(acc, s.lo, mult);
-    else fmac_bc<J - 16, first, NEG>(acc, s.hi, mult);
+    if constexpr (J < 16) fmac_bc<J, first, NEG, true>(acc, s.lo, mult);
+    else fmac_bc<J - 16, first, NEG, true>(acc, s.hi, mult);
   }
 }
 #ifndef FB_FMAC_DPP_DOT
@@ -433,7 +447,7 @@ FB_DEV double bc_dot(const double (&m)[N], double v, double init = 0.0) {
     const Spread<R> vs = spread<R>(v);
     sfor<0, E - B>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      fmac_bcs<R, B + i, B>(p[i & 3], vs, m[B + i]);
+      fmac_bcs<R, B + i, B, false, true, true>(p[i & 3], vs, m[B + i]);
     });
     return (p[0] + p[1]) + (p[2] + p[3]);
   }
@@ -458,7 +472,7 @@ FB_DEV void bc_cols_dot(const double (&C)[NC], const double (&src)[NSRC], double
       const Spread<R> ss = spread<R>(src[sl]);
       sfor<LPQ * sl, (LPQ * (sl + 1) < NC ? LPQ * (sl + 1) : NC)>([&](auto Kk) {
         constexpr int k = decltype(Kk)::value;
-        fmac_bcs<R, k % LPQ, 0, NEG>(p[k & 3], ss, C[k]);
+        fmac_bcs<R, k % LPQ, 0, NEG, true, true>(p[k & 3], ss, C[k]);
       });
     });
   } else {

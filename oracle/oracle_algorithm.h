@@ -170,7 +170,13 @@ class Algorithm {
           break;
         else
           t *= opts_.beta;
+#ifdef FBO_LINESEARCH_OBSERVER  // studies only (tools/cpp/ldlt_order_observer.h); never in liboracle.so
+        FBO_LINESEARCH_OBSERVER(0);
+#endif
       }
+#ifdef FBO_LINESEARCH_OBSERVER
+      FBO_LINESEARCH_OBSERVER(1);
+#endif
       x->axpy(t, *dx_);
     }
     x->ProjectDuals();

@@ -1,58 +1,174 @@
 #!/usr/bin/env python3
-"""Developer tool: the two hazards of the hand-written v_fmac_f64_dpp instructions (fb_row16.h,
-fmac_bc), which the compiler's hazard recognizer does not see inside inline assembly, checked on
-the assembly of the record instances that use them (one row per QP):
-  1. a VALU instruction that writes the DPP source register pair within the TWO wait states before
-     the instruction (s_nop n counts n + 1; any other instruction counts 1);
-  2. a VALU write of EXEC (v_cmpx*) within the FIVE wait states before it.
-Exit code 1 if either is found.  usage: tools/check_dpp_hazards.py [rec_12_4_20 rec_12_4_32 ...]"""
+"""Build check: the hazards of the hand-written v_fmac_f64_dpp instructions (fb_row16.h, fmac_bc), which
+the compiler's hazard recognizer does not see inside inline assembly, verified on the DISASSEMBLY OF THE
+BUILT OBJECTS (the code objects inside fbstab_amd/csrc/build/<lib>/rec_*.o or a shared library) - every
+path into every such instruction, through labels, loop back-edges and fall-throughs:
+  1. no VALU instruction writes the DPP source register pair within the TWO wait states before it
+     (s_nop n counts n + 1, any other instruction 1; v_swap / v_permlane*_swap write both operands);
+  2. no VALU write of EXEC (v_cmpx*) within the FIVE wait states before it;
+  3. no transcendental instruction (v_rsq / v_rcp / v_sqrt / v_exp / v_log / v_sin / v_cos) writes ANY of
+     its register operands in the ONE wait state before it (result forwarding of the trans unit);
+  4. a path that leaves the function (entry, a call's return point) before the wait states are
+     accounted for is reported as unverifiable.
+The fused instructions carry NO s_nop of their own (fb_row16.h: FB_FMAC_GUARD_NOP=0) - this check is what
+stands between the build and a stale operand, so `make` runs it and fails on a finding.
+usage: tools/check_dpp_hazards.py [objects or libraries ...]   (default: the product build's rec_*.o)"""
+import glob
 import os
 import re
+import shutil
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-units = sys.argv[1:] or ["rec_12_4_20", "rec_12_4_32"]
-bad = 0
-for u in units:
-    asm = f"/tmp/_hazard_{u}.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
-                           "--cuda-device-only", "-S", "-o", asm, u + ".hip"], cwd=os.path.join(ROOT, "fbstab_amd", "csrc"),
-                          stderr=subprocess.DEVNULL)
-    body = []
-    for l in open(asm):
-        t = l.split(";")[0].strip()
-        if not t or t.startswith((".", "//")) or t.endswith(":"):
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+TRANS = ("v_rsq_", "v_rcp_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+NOT_VGPR_WRITERS = ("v_cmp", "v_readlane", "v_readfirstlane", "v_nop")
+BOTH = ("v_swap_", "v_permlane16_swap", "v_permlane32_swap")
+
+
+def regs_of(tok):
+    m = re.fullmatch(r"[-|]*v\[(\d+):(\d+)\][|]*", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"[-|]*v(\d+)[|]*", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def operands(text):
+    parts = text.split(None, 1)
+    return [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+
+
+def vgpr_writes(text):
+    op = text.split()[0]
+    if not op.startswith("v_") or op.startswith(NOT_VGPR_WRITERS):
+        return set()
+    ops = operands(text)
+    if not ops:
+        return set()
+    w = regs_of(ops[0].split()[0])
+    if op.startswith(BOTH) and len(ops) > 1:
+        w |= regs_of(ops[1].split()[0])
+    return w
+
+
+def disassemble(path, tmp):
+    """Code objects of `path` (an offload bundle: .o / .so) -> list of disassembly texts."""
+    local = os.path.join(tmp, os.path.basename(path))
+    shutil.copy(path, local)
+    subprocess.check_call([OBJDUMP, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = []
+    for co in sorted(glob.glob(local + ".*amdgcn*")):
+        out.append(subprocess.check_output([OBJDUMP, "-d", "--symbolize-operands", "--no-show-raw-insn", co], text=True))
+    return out
+
+
+def functions(dis):
+    """-> [(name, [(label or None, text)])], one entry per function symbol."""
+    fns, cur, pending = [], None, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            if re.fullmatch(r"L\d+", m.group(1)):
+                pending = m.group(1)
+            else:
+                cur = []
+                fns.append((m.group(1), cur))
+                pending = None
             continue
-        body.append(t)
-    n = 0
-    for i, t in enumerate(body):
+        if cur is None or not line.startswith("\t"):
+            continue
+        text = line.split("//")[0].strip()
+        if not text:
+            continue
+        cur.append((pending, text))
+        pending = None
+    return fns
+
+
+def check_function(name, ins, unit):
+    label_at = {lab: i for i, (lab, _) in enumerate(ins) if lab}
+    jumps = {}
+    for i, (_, t) in enumerate(ins):
+        if t.startswith(("s_cbranch", "s_branch")):
+            jumps.setdefault(t.split()[-1], []).append(i)
+    findings, n = [], 0
+    for i, (_, t) in enumerate(ins):
         if not t.startswith("v_fmac_f64_dpp"):
             continue
         n += 1
-        regs = re.findall(r"v\[(\d+):(\d+)\]", t)
-        src = set(range(int(regs[1][0]), int(regs[1][1]) + 1))
-        waits, j = 0, i - 1
-        while j >= 0 and waits < 5:
-            p = body[j]
-            if p.startswith("s_nop"):
-                waits += int(p.split()[1]) + 1
+        ops = operands(t)
+        src = regs_of(ops[1].split()[0])
+        allr = set().union(*(regs_of(o.split()[0]) for o in ops[:3]))
+        seen = set()
+
+        def walk(j, waits):
+            """instruction j is the next one BEFORE the point reached with `waits` wait states behind it"""
+            while waits < 5:
+                if j < 0:
+                    if waits < 2:
+                        findings.append(f"{unit}: {name}: function entry {waits} wait states before `{t}` (unverifiable)")
+                    return
+                if (j, waits) in seen:
+                    return
+                seen.add((j, waits))
+                lab, p = ins[j]
+                op = p.split()[0]
+                if op in ("s_endpgm",) or op.startswith("s_setpc") or (op == "s_branch"):
+                    return  # nothing falls through these (s_setpc: a return; what follows it starts at a label)
+                if op.startswith("s_swappc"):
+                    if waits < 2:
+                        findings.append(f"{unit}: {name}: a call returns {waits} wait states before `{t}` (unverifiable)")
+                    return
+                if op == "s_nop":
+                    w = int(p.split()[1]) + 1
+                else:
+                    w = 1
+                    if op.startswith("v_cmpx"):
+                        findings.append(f"{unit}: {name}: EXEC written by `{p}` {waits} wait states before `{t}`")
+                    wr = vgpr_writes(p)
+                    if waits < 2 and wr & src:
+                        findings.append(f"{unit}: {name}: DPP source written by `{p}` {waits} wait states before `{t}`")
+                    if waits < 1 and op.startswith(TRANS) and wr & allr:
+                        findings.append(f"{unit}: {name}: operand written by `{p}` (trans) directly before `{t}`")
+                waits += w
+                if lab:  # other ways into this instruction
+                    for b in jumps.get(lab, []):
+                        walk(b, waits)
                 j -= 1
-                continue
-            if re.match(r"v_cmpx", p):
-                print(f"{u}: EXEC written by `{p}` {waits} wait states before `{t}`")
-                bad += 1
-            if waits < 2 and p.startswith("v_") and not p.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
-                m = re.match(r"v_\w+\s+(v\[(\d+):(\d+)\]|v(\d+))", p)
-                if m:
-                    dst = set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
-                    if dst & src:
-                        print(f"{u}: DPP source written by `{p}` {waits} wait states before `{t}`")
-                        bad += 1
-            if p.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc")):
-                break  # (a block boundary: what precedes on other paths is not visible here)
-            waits += 1
-            j -= 1
-    print(f"{u}: {n} v_fmac_f64_dpp instructions checked")
-print("hazards found:" if bad else "no hazard found", bad if bad else "")
-sys.exit(1 if bad else 0)
+
+        # the instruction's own label: paths that jump straight to it
+        if ins[i][0]:
+            for b in jumps.get(ins[i][0], []):
+                walk(b, 0)
+        walk(i - 1, 0)
+    return n, findings
+
+
+def main():
+    paths = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "fbstab_amd", "csrc", "build", "libfbstab_hip", "rec_*.o")))
+    if not paths:
+        print("no objects to check")
+        return 1
+    total, bad = 0, []
+    with tempfile.TemporaryDirectory() as tmp:
+        for pth in paths:
+            unit = os.path.basename(pth)
+            n_unit = 0
+            for dis in disassemble(pth, tmp):
+                for name, ins in functions(dis):
+                    n, f = check_function(name[:60], ins, unit)
+                    n_unit += n
+                    bad += f
+            total += n_unit
+            print(f"{unit}: {n_unit} v_fmac_f64_dpp instructions checked")
+    for f in sorted(set(bad)):
+        print(f)
+    print(f"{total} instructions; " + (f"{len(set(bad))} findings" if bad else "no hazard found"))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -40,8 +40,19 @@ inline void observe(const L& f) {
   s.prev = perm;
   s.have_prev = true;
 }
+// line search: trials evaluated per Newton step (1 = the full step accepted at once; the loop leaves
+// after max_linesearch_iters trials whether or not the last one was accepted)
+struct LsState { long long hist[32] = {0}; int cur = 0; };
+inline LsState& ls() { static LsState s; return s; }
+inline void ls_event(int step_done) {
+  LsState& s = ls();
+  if (!step_done) { s.cur++; return; }   // called once per trial, after it (accepted trials leave before: cur = trials - 1 then)
+  s.hist[s.cur > 31 ? 31 : s.cur]++;
+  s.cur = 0;
+}
 }  // namespace fbo_obs
 #define FBO_LDLT_OBSERVER(f) fbo_obs::observe(f)
+#define FBO_LINESEARCH_OBSERVER(done) fbo_obs::ls_event(done)
 extern "C" {
 inline void fbo_obs_dummy() {}
 }

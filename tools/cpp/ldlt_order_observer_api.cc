@@ -7,4 +7,5 @@ void fbo_obs_read(long long* out) {  // factorisations, same, first_of_qp, zfirs
   out[0] = s.factorisations; out[1] = s.same_as_previous; out[2] = s.first_of_qp; out[3] = s.zfirst;
   for (int i = 0; i < 65; i++) out[4 + i] = s.prefix_hist[i];
 }
+void fbo_obs_read_linesearch(long long* out) { for (int i = 0; i < 32; i++) out[i] = fbo_obs::ls().hist[i]; }
 }

@@ -99,9 +99,11 @@ __global__ __launch_bounds__(64, WAVES) void row_kernel_t(const double* H, const
 // next reader must wait for.  A scheduling barrier behind every instruction pins the order for free.)
 template <int J, bool FIRST>
 __device__ __forceinline__ void fmac_bc(double& acc, double src, double mult, int&) {
+#ifndef PROBE_NO_NOP  // (-DPROBE_NO_NOP: TIMING ONLY - what the 155 s_nop of a stage cost; the results may then be wrong)
   if constexpr (FIRST)
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
   else
+#endif
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
   FB_SB();
 }
