@@ -2203,7 +2203,8 @@ struct MpcR16 {
                           [&](auto I, double t) { Pn[decltype(I)::value] = fma(W[k], t, Pn[decltype(I)::value]); });
           }
         });
-        sfor<0, NX>([&](auto Cc) { Pn[decltype(Cc)::value] = rx ? Pn[decltype(Cc)::value] : 0.0; });
+        // (rows r >= NX of Pn are zero as they come: those rows of [A B], hence of W, are zero in the
+        // matrix copy - no select; the same holds for T and the rows of inv(Pi) below)
         FB_SB();
         FB_STAMP_LAP(7);
         ok = chol_rows<NX, RQ>(Pn, ro, sigma) && ok;
@@ -2227,7 +2228,6 @@ struct MpcR16 {
                              [&](auto I, double t) { Pinv[decltype(I)::value] = fma(T[k], t, Pinv[decltype(I)::value]); });
           }
         });
-        sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = rx ? Pinv[decltype(Cc)::value] : 0.0; });
         FB_STAMP_LAP(8);
       }
       pcur = pnxt;
