@@ -227,7 +227,10 @@ def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, 
     -ftrivial-auto-var-init=pattern (and -Wuninitialized -Wconditional-uninitialized,
     clean): every automatic variable starts from a fixed bit pattern, so such a read gives
     the same garbage every time - and a result that depends on it differs from the product
-    build's.  For each of the five record instances: its four fuzz shapes of
+    build's.  The variant also keeps the guard s_nop in front of every group of fused
+    broadcast-FMAs (FB_FMAC_GUARD_NOP=1), which the product build drops where
+    tools/check_dpp_hazards.py proves them unnecessary: an operand read too early would show
+    here as a difference too.  For each of the five record instances: its four fuzz shapes of
     test_random_shapes_on_every_mpc_instance plus batches of 1, 2, 3, 5 and 7 QPs (rows
     and whole wavefront halves without a QP) on an exact and a padded shape - outputs of
     the two builds bitwise equal, and at parity with the oracle."""

@@ -85,3 +85,36 @@ def test_the_built_objects_pass_if_they_are_here():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), objs[0]], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "no hazard found" in r.stdout
+
+
+_HAZARD_KERNEL = r"""
+#include <hip/hip_runtime.h>
+__global__ void k(const double* in, double* out) {
+  const int t = threadIdx.x;
+  double a = in[t], b = in[64 + t], acc = in[128 + t];
+  double src;
+  asm volatile("v_add_f64 %0, %1, %2" : "=v"(src) : "v"(a), "v"(b));
+  %s
+  asm volatile("v_fmac_f64_dpp %%0, %%1, %%2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(b));
+  out[t] = acc;
+}
+"""
+
+
+def test_a_compiled_object_with_the_hazard_fails_and_with_the_wait_states_passes(tmp_path):
+    """End to end, the way the Makefile uses it: hipcc object in, exit code out."""
+    import shutil, subprocess, sys
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        import pytest
+        pytest.skip("no hipcc here")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    rcs = {}
+    for name, gap in (("bad", ""), ("good", 'asm volatile("s_nop 1");')):
+        src = tmp_path / f"{name}.hip"
+        src.write_text(_HAZARD_KERNEL.replace("%s", gap).replace("%%", "%"))
+        obj = tmp_path / f"{name}.o"
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-c", "-o", str(obj), str(src)], stderr=subprocess.DEVNULL)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), str(obj)], capture_output=True, text=True)
+        rcs[name] = (r.returncode, r.stdout)
+    assert rcs["bad"][0] == 1 and "DPP source written by `v_add_f64" in rcs["bad"][1], rcs["bad"][1]
+    assert rcs["good"][0] == 0 and "1 v_fmac_f64_dpp instructions checked" in rcs["good"][1], rcs["good"][1]
