@@ -273,6 +273,43 @@ def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, 
             assert (np.abs(a[1] - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
 
 
+def test_one_step_qp_on_a_29_wide_stage_may_take_one_more_proximal_iteration(hip, oracle):
+    """A deviation found by tools/fuzz_shapes.py (seed 42, shape 128 of the stream: N=3, nx=23, nu=6,
+    nc=1, <24,8,16>) and kept here as found: a QP with no active constraint converges in ONE Newton
+    step to the accuracy of the linear solve, the oracle's step leaves a residual of 3.7e-7 - under
+    abs_tol = 1e-6, done after one proximal iteration - and the device's, whose Riccati recursion
+    multiplies with explicit inverses (forward stable, not backward stable: |V dx - r| = 4.6e-6 in
+    the z block against the oracle's 9.7e-8 at sigma = 1e-8, tools/fuzz_case.py), lands above it
+    and takes one more proximal iteration and Newton step, ending at 1e-12.
+    One of ~3,150 QPs of three fuzz seeds.  Pinned: such a QP may take ONE more iteration of each
+    kind, never fewer, and its solution is within the parity tolerance."""
+    rng = np.random.default_rng(42)
+    for it in range(128):
+        nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
+        B = int(rng.integers(1, 14))
+        o = default_options()
+        if rng.random() < 0.3:
+            o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
+        p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    assert (N, nx, nu, nc, B) == (3, 23, 6, 1, 10)
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    assert s.kernel_name() == "fbstab_mpc_r32_kernel<24,8,16>"
+    s.UpdateOptions(_opts(hip, o))
+    z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
+    s.close()
+    c = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    oc = c[4]
+    assert np.array_equal(out["eflag"], oc["eflag"]) and (out["eflag"] == 0).all()
+    dp = out["prox_iters"].astype(int) - oc["prox_iters"].astype(int)
+    dn = out["newton_iters"].astype(int) - oc["newton_iters"].astype(int)
+    assert ((dp == 0) | (dp == 1)).all() and ((dn == 0) | (dn == 1)).all(), (dp, dn)
+    assert (dp != 0).sum() <= 1 and (dn[dp == 0] == 0).all(), (dp, dn)
+    assert (out["residual"] <= 1e-6).all()
+    scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+    assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all()
+
+
 # (nz, nl, nv) -> threads per QP of the kernel that must run it (one wavefront for
 # nz + nl <= 64, four beyond; the K-in-global-memory layout above ~140)
 _DENSE_SHAPES = [
