@@ -73,6 +73,11 @@ def test_paths_that_leave_the_function_are_reported():
     assert len(f) == 1 and "call returns" in f[0]
     n, f = run(["s_nop 4", "s_swappc_b64 s[30:31], s[4:5]", "s_mov_b32 s0, 0", "s_mov_b32 s0, 0", FMAC])
     assert f == []
+    # code behind an unconditional jump that no label leads to: only an indirect jump gets there
+    n, f = run(["s_nop 4", "s_setpc_b64 s[30:31]", "s_mov_b32 s0, 0", FMAC])
+    assert len(f) == 1 and "without a label" in f[0]
+    n, f = run(["s_nop 4", "s_cbranch_scc1 L2", "s_branch L9", "L2: s_mov_b32 s0, 0", "s_mov_b32 s1, 0", FMAC, "L9: s_endpgm"])
+    assert f == []
 
 
 def test_the_built_objects_pass_if_they_are_here():

@@ -8,8 +8,8 @@ path into every such instruction, through labels, loop back-edges and fall-throu
   2. no VALU write of EXEC (v_cmpx*) within the FIVE wait states before it;
   3. no transcendental instruction (v_rsq / v_rcp / v_sqrt / v_exp / v_log / v_sin / v_cos) writes ANY of
      its register operands in the ONE wait state before it (result forwarding of the trans unit);
-  4. a path that leaves the function (entry, a call's return point) before the wait states are
-     accounted for is reported as unverifiable.
+  4. a path that leaves the function (entry, a call's return point, code that only an indirect jump
+     can reach) before the wait states are accounted for is reported as unverifiable.
 The fused instructions carry NO s_nop of their own (fb_row16.h: FB_FMAC_GUARD_NOP=0) - this check is what
 stands between the build and a stale operand, so `make` runs it and fails on a finding.
 usage: tools/check_dpp_hazards.py [objects or libraries ...]   (default: the product build's rec_*.o)"""
@@ -117,8 +117,12 @@ def check_function(name, ins, unit):
                 lab, p = ins[j]
                 op = p.split()[0]
                 if op in ("s_endpgm",) or op.startswith("s_setpc") or (op == "s_branch"):
-                    return  # nothing falls through these (s_setpc: a return; what follows it starts at a label)
-                if op.startswith("s_swappc"):
+                    # nothing falls through these.  What follows them is reached through its label (followed
+                    # above) - or, WITHOUT a label, only by an indirect jump this tool cannot follow
+                    if j + 1 < len(ins) and not ins[j + 1][0] and waits < 2:
+                        findings.append(f"{unit}: {name}: code behind `{p}` without a label {waits} wait states before `{t}` (unverifiable)")
+                    return
+                if op.startswith(("s_swappc", "s_call")):
                     if waits < 2:
                         findings.append(f"{unit}: {name}: a call returns {waits} wait states before `{t}` (unverifiable)")
                     return
