@@ -281,7 +281,7 @@ def test_one_step_qp_on_a_29_wide_stage_may_take_one_more_proximal_iteration(hip
     multiplies with explicit inverses (forward stable, not backward stable: |V dx - r| = 4.6e-6 in
     the z block against the oracle's 9.7e-8 at sigma = 1e-8, tools/fuzz_case.py), lands above it
     and takes one more proximal iteration and Newton step, ending at 1e-12.
-    One of ~3,000 QPs of three fuzz seeds.  Pinned: such a QP may take ONE more iteration of each
+    One of ~10,000 QPs of ten fuzz seeds.  Pinned: such a QP may take ONE more iteration of each
     kind, never fewer, and its solution is within the parity tolerance."""
     rng = np.random.default_rng(42)
     for it in range(128):
