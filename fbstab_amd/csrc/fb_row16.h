@@ -187,18 +187,20 @@ FB_DEV void bc_pipeline(Mov&& mov, Use&& use) {
 // pair v_mov_b64_dpp + v_fma_f64 of the streams above as ONE instruction, bitwise the same
 // result.  In the forward stage's arithmetic core (tools/probes/halfrow_probe.hip) it is
 // 18 % faster than the hand-pipelined pairs - no temporaries, no 17-cycle move-to-use distance
-// to schedule round - where the isolated instruction had measured 10 % (round 3).  One row per
-// QP only (R = 1: the 64-bit DPP forms exist for row_newbcast alone, a row PAIR needs the
-// spread).  Inline assembly is outside the compiler's hazard recognizer, so the two rules a DPP
-// operand brings are kept by hand:
-//   * two wait states between the VALU instruction that writes `src` and the first reader:
-//     the FIRST instruction of every group carries an s_nop 1 (all members of a group read the
-//     same src), and a scheduling barrier behind every member pins the group's order (a token
-//     operand would too - and makes the compiler put an s_nop between any two members: it treats
-//     a register an asm statement defines as a possible partial write);
+// to schedule round - where the isolated instruction had measured 10 % (round 3).  The 64-bit DPP
+// forms exist for row_newbcast alone: a row PAIR (R = 2) broadcasts from the two halves of a
+// spread value, each an ordinary register.  Inline assembly is outside the compiler's hazard
+// recognizer, so the two rules a DPP operand brings are kept by hand:
+//   * two wait states between the VALU instruction that writes `src` and the first reader.  All
+//     members of a group read the same src, so only the group's FIRST instruction can be too
+//     close; a scheduling barrier behind every member pins the group's order (a token operand
+//     would too - and makes the compiler put an s_nop between any two members: it treats a
+//     register an asm statement defines as a possible partial write).  Whether the first
+//     instruction carries an s_nop 1: FB_FMAC_GUARD_NOP and GUARD below;
 //   * five wait states behind a VALU write of EXEC: the only such writes are the v_cmpx of the
 //     hand-written LDS image blocks, which end with s_nop 4.
-// tools/check_dpp_hazards.py verifies both on the assembly of the record instances.
+// tools/check_dpp_hazards.py verifies both - and the trans-forwarding rule - on the disassembly of
+// every built record object (part of `make`).
 #ifndef FB_FMAC_DPP
 #define FB_FMAC_DPP 1
 #endif
