@@ -54,8 +54,9 @@ for q in bad:
     Hm, f, G, hh, A, b = H.mpc_explicit(p, q)
     zero = lambda n: np.zeros(n)
     data = {k: a[q] for k, a in p.arrays.items()}
-    os.environ["FBSTAB_HIP_GENERIC"] = "0"
+    os.environ["FBSTAB_HIP_GENERIC"] = os.environ.get("FUZZ_CASE_PROBE_GENERIC", "0")  # 1: probe the flat-vector kernel
     s1 = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=1)
+    print("    probe on", s1.kernel_name())
     s1.UpdateOptions(h)
     g = s1.debug_newton(data, zero(p.nz), zero(p.nl), zero(p.nv), zero(p.nz), zero(p.nl), zero(p.nv))
     s1.close()
