@@ -55,6 +55,41 @@ def test_the_producer_at_the_bottom_of_a_loop_is_found_through_the_back_edge():
     assert f == []
 
 
+def test_the_producer_before_an_unconditional_branch_is_found_through_the_jump():
+    """a path entered through `s_branch Lx` starts AT that branch; the instructions before
+    it belong to the path (the branch itself is one wait state), as with a conditional branch."""
+    for br in ("s_branch L1", "s_cbranch_scc0 L1"):
+        n, f = run(["s_nop 4", "v_mul_f64 v[2:3], v[10:11], v[12:13]", br, "L9: s_nop 4", "s_nop 4", "L1: " + FMAC,
+                    "s_endpgm"])
+        assert n == 1 and len(f) == 1 and "DPP source written" in f[0], (br, f)
+        # the branch counts as one wait state: one more instruction in front of it is enough
+        n, f = run(["s_nop 4", "v_mul_f64 v[2:3], v[10:11], v[12:13]", "s_mov_b32 s0, 0", br, "L9: s_nop 4", "s_nop 4",
+                    "L1: " + FMAC, "s_endpgm"])
+        assert f == [], (br, f)
+    # ... also when the label sits on an instruction BEFORE the fused one
+    n, f = run(["s_nop 4", "v_mul_f64 v[2:3], v[10:11], v[12:13]", "s_branch L1", "L9: s_nop 4", "s_nop 4",
+                "L1: s_mov_b32 s0, 0", FMAC, "s_endpgm"])
+    assert f == []  # mul, branch, s_mov: two wait states
+    n, f = run(["s_nop 4", "v_rcp_f64_e32 v[6:7], v[10:11]", "s_branch L1", "L9: s_nop 4", "s_nop 4", "L1: " + FMAC,
+                "s_endpgm"])
+    assert f == []  # a trans result needs one wait state: the branch is one
+    # linear code behind an unconditional branch is still not a fall-through path
+    n, f = run(["s_nop 4", "v_mul_f64 v[2:3], v[10:11], v[12:13]", "s_branch L7", "L1: " + FMAC, "L7: s_endpgm"])
+    assert f == []
+
+
+def test_an_object_without_a_code_object_is_a_finding(tmp_path):
+    """the build gate must not pass with nothing checked."""
+    import subprocess, sys
+    src = tmp_path / "x.c"
+    src.write_text("int f(void) { return 1; }\n")
+    obj = tmp_path / "x.o"
+    subprocess.check_call(["gcc", "-c", "-o", str(obj), str(src)])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), str(obj)],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no amdgcn code object" in r.stdout
+
+
 def test_exec_written_by_a_compare_needs_five_and_a_trans_result_one():
     n, f = run(["v_cmpx_le_i32_e32 vcc, 3, v30", "s_mov_b64 exec, s[4:5]", "s_nop 2", FMAC])
     assert len(f) == 1 and "EXEC" in f[0]

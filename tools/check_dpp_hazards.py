@@ -12,7 +12,9 @@ path into every such instruction, through labels, loop back-edges and fall-throu
      can reach) before the wait states are accounted for is reported as unverifiable.
 The fused instructions carry NO s_nop of their own (fb_row16.h: FB_FMAC_GUARD_NOP=0) - this check is what
 stands between the build and a stale operand, so `make` runs it and fails on a finding.
-usage: tools/check_dpp_hazards.py [objects or libraries ...]   (default: the product build's rec_*.o)"""
+An object in which no amdgcn code object is found is a finding (nothing was checked); with --expect-nonzero
+(the build) so is an object without a single fused instruction.
+usage: tools/check_dpp_hazards.py [--expect-nonzero] [objects or libraries ...]   (default: the product build's rec_*.o)"""
 import glob
 import os
 import re
@@ -104,19 +106,22 @@ def check_function(name, ins, unit):
         allr = set().union(*(regs_of(o.split()[0]) for o in ops[:3]))
         seen = set()
 
-        def walk(j, waits):
-            """instruction j is the next one BEFORE the point reached with `waits` wait states behind it"""
+        def walk(j, waits, via_jump=False):
+            """instruction j is the next one BEFORE the point reached with `waits` wait states behind it;
+            via_jump: j is the branch instruction this path was TAKEN from (an unconditional s_branch is
+            then one more instruction on the path - one wait state - not the end of it)"""
             while waits < 5:
                 if j < 0:
                     if waits < 2:
                         findings.append(f"{unit}: {name}: function entry {waits} wait states before `{t}` (unverifiable)")
                     return
-                if (j, waits) in seen:
+                if (j, waits, via_jump) in seen:
                     return
-                seen.add((j, waits))
+                seen.add((j, waits, via_jump))
                 lab, p = ins[j]
                 op = p.split()[0]
-                if op in ("s_endpgm",) or op.startswith("s_setpc") or (op == "s_branch"):
+                taken, via_jump = via_jump, False
+                if op in ("s_endpgm",) or op.startswith("s_setpc") or (op == "s_branch" and not taken):
                     # nothing falls through these.  What follows them is reached through its label (followed
                     # above) - or, WITHOUT a label, only by an indirect jump this tool cannot follow
                     if j + 1 < len(ins) and not ins[j + 1][0] and waits < 2:
@@ -140,19 +145,22 @@ def check_function(name, ins, unit):
                 waits += w
                 if lab:  # other ways into this instruction
                     for b in jumps.get(lab, []):
-                        walk(b, waits)
+                        walk(b, waits, True)
                 j -= 1
 
         # the instruction's own label: paths that jump straight to it
         if ins[i][0]:
             for b in jumps.get(ins[i][0], []):
-                walk(b, 0)
+                walk(b, 0, True)
         walk(i - 1, 0)
     return n, findings
 
 
 def main():
-    paths = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "fbstab_amd", "csrc", "build", "libfbstab_hip", "rec_*.o")))
+    args = sys.argv[1:]
+    expect_nonzero = "--expect-nonzero" in args  # the build: an object without a fused instruction is a finding
+    args = [a for a in args if a != "--expect-nonzero"]
+    paths = args or sorted(glob.glob(os.path.join(ROOT, "fbstab_amd", "csrc", "build", "libfbstab_hip", "rec_*.o")))
     if not paths:
         print("no objects to check")
         return 1
@@ -161,13 +169,18 @@ def main():
         for pth in paths:
             unit = os.path.basename(pth)
             n_unit = 0
-            for dis in disassemble(pth, tmp):
+            texts = disassemble(pth, tmp)
+            if not texts:
+                bad.append(f"{unit}: no amdgcn code object found in it (nothing was checked)")
+            for dis in texts:
                 for name, ins in functions(dis):
                     n, f = check_function(name[:60], ins, unit)
                     n_unit += n
                     bad += f
             total += n_unit
             print(f"{unit}: {n_unit} v_fmac_f64_dpp instructions checked")
+            if expect_nonzero and n_unit == 0:
+                bad.append(f"{unit}: no v_fmac_f64_dpp instruction found (--expect-nonzero)")
     for f in sorted(set(bad)):
         print(f)
     print(f"{total} instructions; " + (f"{len(set(bad))} findings" if bad else "no hazard found"))
