@@ -49,6 +49,7 @@ ALG_BYTES_PER_QP = 217736      # data 188,928 + guess 11,904 + s
 FLOP_PER_NEWTON = 0.94e6       # SURVEY.md 8(d), survey-derived flop model
 DENSE_ALG_BYTES_PER_QP = 8160 * 8 + 160 * 8 + 260 * 8 + 40   # data + guess (z,l,v) + solution + SolverOut
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_ACHIEVABLE_BPS = 6.29e12    # MI355X_MICROARCH.md: what a streaming kernel measures on this part
 FP64_PEAK_TFLOPS = 78.6        # AMD public MI355X FP64 vector/matrix spec
 
 
@@ -105,7 +106,7 @@ def library_sha256():
     import hashlib
     from fbstab_amd import hip_api
     try:
-        with open(hip_api.LIB_PATH, "rb") as f:
+        with open(hip_api.current_library_path(), "rb") as f:
             return hashlib.sha256(f.read()).hexdigest()
     except OSError:
         return None
@@ -237,7 +238,10 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for k in range(warmup):
+        # W untimed steps as asked - and no lane makes its FIRST solve (handle set-up, first touch of
+        # its 1.8 GB of scratch) inside the timed region: with P lanes and W < P the lanes W .. P-1
+        # get one untimed solve each as well (reported as `untimed_steps`)
+        for k in range(max(warmup, min(P, steps))):
             step(k, False)
         fence()
         w0 = time.time()
@@ -262,7 +266,8 @@ def main():
         newton = np.concatenate([o["newton_iters"] for o in outs])
         res = dict(elapsed=elapsed, kernel_ms=float(np.mean(kernel_ms)), ok=bool((eflag == 0).all()),
                    not_converged=int((eflag != 0).sum()), mean_newton=float(newton.mean()),
-                   query=lanes[0].solver.query(), kernel=lanes[0].solver.kernel_name(), wall=(w0, w1))
+                   query=lanes[0].solver.query(), kernel=lanes[0].solver.kernel_name(), wall=(w0, w1),
+                   untimed=max(warmup, min(P, steps)))
         for ln in lanes:
             ln.solver.close()
         del lanes
@@ -326,6 +331,8 @@ def main():
             "config": {"workload": "BASELINE configs[2]: batched FBstabMpc, batch=8192 per GPU, "
                                    "N=30 nx=12 nu=4 nc=20, cold start, default options",
                        "batch_per_gpu": B, "global_batch": world * B, "steps_in_flight": P,
+                       # warm-up steps actually run: max(W, lanes), so that every lane's first solve is untimed
+                       "untimed_steps": head["untimed"],
                        "parallelism": f"batch sharded over {world} GPU(s)" +
                                       (", one RCCL gather to rank 0 per batch" if dist is not None else "")},
             # achieved = algorithmic bytes of one batch over the time the GPU spends per
@@ -343,6 +350,9 @@ def main():
                          "traffic_source": tr["source"] if tr else None,
                          "traffic_build_matches": tr["build_matches"] if tr else None,
                          "traffic_per_step_GBps": (traffic / per_step_s / 1e9) if traffic else None,
+                         # the rate at which HBM (6.29 TB/s achievable on this part, MI355X_MICROARCH.md) could
+                         # move this kernel's counter bytes: the memory wall of the present record traffic
+                         "hbm_ceiling_qps": (B / (traffic / HBM_ACHIEVABLE_BPS)) if traffic else None,
                          "kernel": head["kernel"], "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_QP * B,
                          "per_launch": {"achieved": ALG_BYTES_PER_QP * B / (k_ms * 1e-3) / 1e9,

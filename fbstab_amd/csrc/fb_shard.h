@@ -43,6 +43,8 @@ struct RcclApi {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  int version = 0;  // NCCL_VERSION_CODE of the bound library (major * 10000 + minor * 100 + patch since 2.9)
   int load() {
     if (so) return FBSTAB_HIP_OK;
     const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -64,7 +66,18 @@ struct RcclApi {
     Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
     Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-    if (!ok) return fail(FBSTAB_HIP_ERR_DEVICE, "librccl.so lacks ncclSend / ncclRecv / ncclCommInitAll");
+    GetVersion = reinterpret_cast<decltype(GetVersion)>(sym("ncclGetVersion"));
+    if (!ok) {
+      so = nullptr;
+      return fail(FBSTAB_HIP_ERR_DEVICE, "librccl.so lacks ncclSend / ncclRecv / ncclCommInitAll / ncclGetVersion");
+    }
+    // The prototypes above are written out by hand for the 2.x ABI (ncclSend / ncclRecv exist since 2.7):
+    // a library that reports anything else is refused rather than called with a guessed signature.
+    if (GetVersion(&version) != ncclSuccess || version < 2700 || version >= 30000) {
+      so = nullptr;
+      return fail(FBSTAB_HIP_ERR_DEVICE, "librccl.so reports version code " + std::to_string(version) +
+                                             ": outside the 2.x ABI (>= 2.7) fb_shard.h declares");
+    }
     return FBSTAB_HIP_OK;
   }
 };

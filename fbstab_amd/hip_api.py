@@ -88,22 +88,19 @@ class _Plant(C.Structure):
 _libs: Dict[str, C.CDLL] = {}
 _current = LIB_PATH  # the library new solver objects bind to (see `library`)
 
-# Variant builds of the same sources (test artefacts under tests/_build/, not in this package):
-#   "pattern"  every automatic variable initialised to a bit pattern
-#              (-ftrivial-auto-var-init=pattern, `make -C fbstab_amd/csrc pattern`): a read
-#              of a value the code never set gives the same garbage in every build instead
-#              of whatever the optimiser resolved `undef` to
-VARIANTS = {"pattern": os.path.join(os.path.dirname(_HERE), "tests", "_build", "libfbstab_hip_pattern.so")}
-if os.environ.get("FBSTAB_HIP_VARIANT"):
-    _current = VARIANTS[os.environ["FBSTAB_HIP_VARIANT"]]
+
+def current_library_path() -> str:
+    """Path of the library new solver objects bind to (what bench.py hashes as "this build")."""
+    return _current
 
 
 class library:
-    """``with hip_api.library("pattern"):`` - solver objects created inside bind to the named
-    variant build (or a path); both libraries can be in use in one process."""
+    """``with hip_api.library(path):`` - solver objects created inside bind to ANOTHER build of the
+    same sources at ``path`` (the tests compare a pattern-initialised build with the product
+    library, tests/helpers.py: VARIANT_LIBS); both libraries can be in use in one process."""
 
-    def __init__(self, which: str):
-        self.path = VARIANTS.get(which, which)
+    def __init__(self, path: str):
+        self.path = path
 
     def __enter__(self):
         global _current

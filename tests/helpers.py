@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests."""
+import os
+
 import numpy as np
 
 from tools import fixtures as fx
@@ -31,6 +33,14 @@ def mpc_component_fixture(c):
     p.arrays = {k: fx._colmajor(v).reshape(1, -1) for k, v in seq.items()}
     p.arrays["x0"] = np.asarray(c["x0"], dtype=np.float64).reshape(1, -1)
     return p
+
+
+# Variant builds of the product sources the tests load beside the product library (`with
+# hip_api.library(VARIANT_LIBS[name])`); built by `make -C fbstab_amd/csrc <name>` into tests/_build/:
+#   "pattern"  every automatic variable initialised to a bit pattern (-ftrivial-auto-var-init=pattern)
+#              and the guard s_nop of every fused broadcast-FMA kept: a read of a value the code never
+#              set gives the same garbage in every build instead of whatever the optimiser made of it
+VARIANT_LIBS = {"pattern": os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libfbstab_hip_pattern.so")}
 
 
 def mpc_explicit(p, b=0):

@@ -82,11 +82,13 @@ def test_factorisation_option_of_the_dense_handle_without_gpu(lib):
     assert lib.fbstab_hip_dense_set_factorisation(None, 1, 0) == 1          # null handle
     assert lib.fbstab_hip_dense_get_factorisation(None, None, None, None) == 1
     assert b"null solver handle" in lib.fbstab_hip_last_error()
-    pat = hip_api.VARIANTS["pattern"]
+    from tests import helpers as H
+    pat = H.VARIANT_LIBS["pattern"]
+    assert not hasattr(hip_api, "VARIANTS")  # the product binding knows paths only; the table is the tests'
     assert os.path.dirname(pat) == os.path.join(ROOT, "tests", "_build")
     assert not any(f.endswith(".so") and f != "libfbstab_hip.so" for f in os.listdir(os.path.join(ROOT, "fbstab_amd")))
     if os.path.exists(pat):  # both libraries load side by side and export the same interface
-        with hip_api.library("pattern") as v:
+        with hip_api.library(pat) as v:
             assert v is not lib
             for name in hip_api.EXPORTED_SYMBOLS:
                 assert getattr(v, name) is not None
@@ -114,3 +116,36 @@ def test_replayed_traffic_prefers_the_summary_of_this_build(tmp_path, monkeypatc
     t = bench.stored_traffic(8192)
     assert not t["build_matches"] and "NOT the library of this run" in t["source"]
     assert bench.stored_traffic(4096) is None
+
+
+def test_hand_declared_rccl_types_match_the_header_where_it_exists(tmp_path):
+    """fb_shard.h binds RCCL by dlopen and declares the few types it uses itself: where
+    <rccl/rccl.h> is installed, the compiler checks those declarations against it - enum sizes, the
+    enumerators used, the signatures as far as an int-for-enum ABI allows - and load() refuses a
+    library whose ncclGetVersion is outside the 2.x range the declarations were written for."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no RCCL header in this image")
+    src = tmp_path / "rccl_abi.cc"
+    src.write_text(r'''
+#define __HIP_PLATFORM_AMD__ 1
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int), "int-sized enums");
+static_assert((int)ncclSuccess == 0 && (int)ncclChar == 0 && (int)ncclInt8 == 0, "enumerators fb_shard.h uses");
+static_assert(sizeof(ncclComm_t) == sizeof(void*), "opaque communicator");
+static_assert(NCCL_MAJOR == 2 && NCCL_VERSION_CODE >= 2700 && NCCL_VERSION_CODE < 30000, "the range load() accepts");
+static_assert(std::is_same<decltype(&ncclSend), ncclResult_t (*)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclSend");
+static_assert(std::is_same<decltype(&ncclRecv), ncclResult_t (*)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>::value, "ncclRecv");
+static_assert(std::is_same<decltype(&ncclCommInitAll), ncclResult_t (*)(ncclComm_t*, int, const int*)>::value, "ncclCommInitAll");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclGetVersion), ncclResult_t (*)(int*)>::value, "ncclGetVersion");
+static_assert(std::is_same<decltype(&ncclGroupStart), ncclResult_t (*)()>::value, "ncclGroupStart");
+static_assert(std::is_same<decltype(&ncclGetErrorString), const char* (*)(ncclResult_t)>::value, "ncclGetErrorString");
+int main() { return 0; }
+''')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I/opt/rocm/include", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(os.path.join(ROOT, "fbstab_amd", "csrc", "fb_shard.h")) as f:
+        text = f.read()
+    assert "ncclGetVersion" in text and "version < 2700 || version >= 30000" in text

@@ -207,7 +207,7 @@ def _solve_on(hipmod, which, p, o, shape):
     import contextlib
     N, nx, nu, nc = shape
     B = p.batch
-    with (hipmod.library(which) if which else contextlib.nullcontext()):
+    with (hipmod.library(H.VARIANT_LIBS[which]) if which else contextlib.nullcontext()):
         s = hipmod.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
     kern = s.kernel_name()
     s.UpdateOptions(_opts(hipmod, o))
@@ -235,7 +235,7 @@ def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, 
     and whole wavefront halves without a QP) on an exact and a padded shape - outputs of
     the two builds bitwise equal, and at parity with the oracle."""
     import os
-    if not os.path.exists(hip.VARIANTS["pattern"]):
+    if not os.path.exists(H.VARIANT_LIBS["pattern"]):
         pytest.fail("tests/_build/libfbstab_hip_pattern.so is missing: `make -C fbstab_amd/csrc pattern` "
                     "(__graft_entry__.build() builds it)")
     cases = []
