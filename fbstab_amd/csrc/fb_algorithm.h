@@ -62,6 +62,12 @@ struct TraceArg<true> {
   FB_DEV double* get() const { return p; }
 };
 
+// policies whose Newton step can be refined after the fact (P::kCanRefine: linear_residual2(), refine_step())
+template <class P, class = void>
+struct can_refine_of : std::false_type {};
+template <class P>
+struct can_refine_of<P, typename std::enable_if<P::kCanRefine>::type> : std::true_type {};
+
 // policies that pack a QP as a cooperative pass (P::kCoopLoad, P::load_guess_coop)
 template <class P, class = void>
 struct coop_load_of : std::false_type {};
@@ -73,6 +79,10 @@ struct Solver : TraceState<TRACE> {
   P& p;
   const C& c;
   const fbstab_options_t& o;
+  // (solve()) the stopping tolerance abs_tol + rel_tol (1 + |(f, h, b)|) of the QP in hand and the number
+  // of its Newton steps that were refined (wants_refinement)
+  mutable double combo_tol_ = 0.0;
+  mutable int refined_ = 0;
 
   FB_DEV Solver(P& p_, const C& c_, const fbstab_options_t& o_, double* tr_ = nullptr)
       : p(p_), c(c_), o(o_) {
@@ -311,6 +321,21 @@ struct Solver : TraceState<TRACE> {
           *fail = true;
           return Eo;
         }
+        if constexpr (can_refine_of<P>::value) {
+#if defined(FB_HOSTSIM) && defined(FB_HOSTSIM_TRACE_REFINE)
+          {
+            double dzm = 0.0, dlm = 0.0;
+            for (int q = 0; q < p.nz; q++) dzm = fmax(dzm, fabs(p.dz[q]));
+            for (int q = 0; q < p.nl; q++) dlm = fmax(dlm, fabs(p.dl[q]));
+            fprintf(stderr, "newton %d: Ei %.3e Eo %.3e lin %.3e tol %.3e combo %.3e |dz| %.3e |dl| %.3e\n", *newton_iters, Ei, Eo,
+                    sqrt(p.linear_residual2(c, sigma)), tol, combo_tol_, dzm, dlm);
+          }
+#endif
+          if (wants_refinement(p.linear_residual2(c, sigma), tol, combo_tol_)) {
+            p.refine_step(c, sigma);
+            refined_++;
+          }
+        }
         (*newton_iters)++;
         FB_STAMP_LAP(17);
         const double cm = 0.5 * Ei * Ei;
@@ -368,11 +393,12 @@ struct Solver : TraceState<TRACE> {
       if ((Ei <= tol && Eo < Ek) || (Ei <= o.inner_tol_min)) break;
       if (*newton_iters >= o.max_newton_iters) break;
       FB_STAMP_LAP(16);
-      double ti2, to2;
-      if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2)) {
+      double ti2, to2, lin2;
+      if (!p.newton_step(c, sigma, o.alpha, &ti2, &to2, &lin2)) {
         *fail = true;
         return Eo;
       }
+      if (wants_refinement(lin2, tol, o.abs_tol)) p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
       (*newton_iters)++;
       FB_STAMP_LAP(17);
       FB_STAMP_COUNT(31);
@@ -441,6 +467,28 @@ struct Solver : TraceState<TRACE> {
       c.sync();
     }
     return Eo_top;
+  }
+
+  // ---- when a Newton step is refined (policies with refine_step(): fb_mpc_r16.h, fb_mpc.h) -----------
+  // The z and l blocks of the inner residual are affine in x, so their share of the first trial's norm,
+  // sqrt(lin2), is what the LINEAR solve left of the Newton system - a quantity the reference's
+  // backward-stable substitutions keep near eps |dz| / sigma (riccati_linear_solver.cc:234-325) and the
+  // kernels' products with explicit inverses do not on ill-conditioned (wide) stages.  The rule is
+  // minimal on purpose: a step is refined when its leftover ALONE exceeds the tolerance the solver's next
+  // tests compare with - Ei <= inner_tol (impl:247) and Ek <= abs_tol + rel_tol (1 + |(f, h, b)|)
+  // (impl:158) -, i.e. when those tests could not pass however good the iterate is.  Below that the step is
+  // left as it is, bit for bit: its error is then of the size of the reference's own, and a step MORE
+  // accurate than the reference's parts from the reference just as a less accurate one does (measured:
+  // with the threshold at 1/16 of the tolerance the reference's servo-motor problem, whose second proximal
+  // iteration ends 11 % under the tolerance, finished one proximal iteration EARLIER than the oracle, whose
+  // own leftover takes it over the tolerance there; tests/test_hostsim.py).
+  // fbstab_options_t::reserved is a developer switch: 0 = the rule as stated, k > 0 = a threshold of
+  // 2^-k of the tolerance, < 0 = never.
+  FB_DEV bool wants_refinement(double lin2, double inner_tol, double combo_tol) const {
+    if (o.reserved < 0) return false;
+    double tau = inner_tol < combo_tol ? inner_tol : combo_tol;
+    for (int k = 0; k < o.reserved && k < 60; k++) tau *= 0.5;
+    return lin2 > tau * tau;
   }
 
 #if !defined(FB_HOSTSIM)  // (device intrinsics; the host simulation runs solve())
@@ -706,9 +754,13 @@ struct Solver : TraceState<TRACE> {
         double t = 1.0, cm = 0.0, m0 = 0.0, Et = 0.0, Eot = 0.0;
         int fails = 0;  // failed sufficient-decrease tests so far
         if (phase == kNewton) {
-          double ti2, to2;
-          const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2);
+          double ti2, to2, lin2;
+          const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
           auto sv = qu.save_area();
+          if (stepped && wants_refinement(lin2, sv[4], sv[0])) {
+            qu.count_refinement();
+            p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+          }
           if (!stepped) {
             out = out_base + __double_as_longlong(sv[15]);
             p.flush(c);
@@ -820,8 +872,15 @@ struct Solver : TraceState<TRACE> {
         sv[15] = __longlong_as_double((long long)(out - out_base));
         sv[16] = Ei;
       }
-      double ti2, to2;
-      const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2);
+      double ti2, to2, lin2;
+      const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+      if (stepped) {
+        auto sv = qu.save_area();
+        if (wants_refinement(lin2, sv[4], sv[0])) {
+          qu.count_refinement();
+          p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+        }
+      }
       if (!stepped) {
         auto sv = qu.save_area();
         out = out_base + __double_as_longlong(sv[15]);
@@ -912,6 +971,7 @@ struct Solver : TraceState<TRACE> {
   FB_DEV void solve(fbstab_solver_out_t* out) const {
     const double sigma = o.sigma0;
     const double combo_tol = o.abs_tol + o.rel_tol * (1.0 + p.forcing_norm(c));
+    combo_tol_ = combo_tol;
     p.load_guess(c);  // xk <- (z0,l0,v0), y = b - A z (impl:140, :334-347)
     double dx_norm = sqrt((double)p.num_primal_dual());  // dx.Fill(1) (impl:142)
     double Ek, Ei0;

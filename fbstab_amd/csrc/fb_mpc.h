@@ -129,6 +129,7 @@ struct MpcProblem {
 #endif
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
+  static constexpr bool kCanRefine = true;      // linear_residual2() / refine_step() below
   MpcLayout lay;
   MpcData D;
   double *uz, *ul, *uv, *uy;  // caller's (z,l,v,y) for this QP
@@ -403,6 +404,215 @@ struct MpcProblem {
     }
   }
 
+  // The backward recursion (:267-327) from the factors and (tx, tu, theta) of every stage in `fac`
+  // (stage N still resident in LDS): the step's z block to oz, its l block to ol.
+  FB_DEV void backward_sweep(const C& c, double* oz, double* ol) const {
+    const int N = lay.N, nx = lay.nx, nu = lay.nu, ns = lay.ns;
+    mptr Linv = lds + lay.w_linv; mptr Minv = lds + lay.w_minv;
+    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SGinv = lds + lay.w_sginv; mptr P = lds + lay.w_p;
+    mptr th = lds + lay.w_th; mptr tx = lds + lay.w_tx; mptr tu = lds + lay.w_tu;
+    mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2; mptr lp = lds + lay.w_lp;
+    for (int i = N; i >= 0; i--) {
+      if (i < N) {
+        const double* F = fac + (long)i * lay.f_stride;
+        copy_in(c, Minv, F + lay.f_minv, nx * nx);
+        copy_in(c, Linv, F + lay.f_linv, nx * nx);
+        copy_in(c, AM, F + lay.f_am, nx * nx);
+        copy_in(c, SM, F + lay.f_sm, nu * nx);
+        copy_in(c, P, F + lay.f_p, nu * nx);
+        copy_in(c, SGinv, F + lay.f_sginv, nu * nu);
+        copy_in(c, tx, F + lay.f_tx, nx);
+        copy_in(c, tu, F + lay.f_tu, nu);
+        copy_in(c, th, F + lay.f_th, nx);
+        c.sync();
+      }
+      // a = tu + P' l(i+1)   (a = tu at the terminal stage)
+      for (int r = c.tid; r < nu; r += C::nt) {
+        double s = tu[r];
+        if (i < N)
+          for (int k = 0; k < nx; k++) s += P[k + r * nx] * lp[k];
+        t2[r] = s;
+      }
+      c.sync();
+      // u = inv(SG)' a
+      for (int r = c.tid; r < nu; r += C::nt) {
+        double s = 0.0;
+        for (int k = r; k < nu; k++) s += SGinv[k + r * nu] * t2[k];
+        t1[nx + r] = s;
+      }
+      c.sync();
+      // b = tx + SM' u + AM' l(i+1)
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = tx[r];
+        for (int k = 0; k < nu; k++) s += SM[k + r * nu] * t1[nx + k];
+        if (i < N)
+          for (int k = 0; k < nx; k++) s += AM[k + r * nx] * lp[k];
+        t2[r] = s;
+      }
+      c.sync();
+      // x = -inv(M)' b
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = 0.0;
+        for (int k = r; k < nx; k++) s += Minv[k + r * nx] * t2[k];
+        t1[r] = -s;
+      }
+      c.sync();
+      // w = inv(L)(theta + x);  l = -inv(L)' w
+      for (int r = c.tid; r < nx; r += C::nt) {
+        double s = 0.0;
+        for (int k = 0; k <= r; k++) s += Linv[r + k * nx] * (th[k] + t1[k]);
+        t2[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < ns + nx; r += C::nt) {
+        if (r < ns) {
+          oz[(long)i * ns + r] = t1[r];
+        } else {
+          const int rr = r - ns;
+          double s = 0.0;
+          for (int k = rr; k < nx; k++) s += Linv[k + rr * nx] * t2[k];
+          lp[rr] = -s;
+          ol[(long)i * nx + rr] = -s;
+        }
+      }
+      c.sync();
+    }
+
+  }
+
+  // dv, A dz and W = (H dz + G'dl + A'dv, -G dz) from (dz, dl) (:329-341 + the residual increment of
+  // fb_algorithm.h): the third block row of the Newton system holds exactly for whatever dz is.
+  FB_DEV void post_sweep(const C& c) const {
+    const int N = lay.N, nx = lay.nx, nc = lay.nc, ns = lay.ns;
+    for (int i = 0; i <= N; i++) {
+      load_tile(c, i);
+      load_slices(c, i, dz, dl, nullptr);
+      c.sync();
+      for (int k = c.tid; k < nc; k += C::nt) {
+        const long g = (long)i * nc + k;
+        const double a = tile_Az(k);
+        const double d = rvm[g] + gam[g] * a;
+        adz[g] = a;
+        dv[g] = d;
+        (lds + lay.s_v)[k] = d;
+      }
+      c.sync();
+      for (int r = c.tid; r < ns + nx; r += C::nt) {
+        if (r < ns) {
+          wz[(long)i * ns + r] = tile_Hz(r) + tile_GTl(i, r) + tile_ATv(r);
+        } else {
+          const int rr = r - ns;
+          if (i == 0) wl[rr] = (lds + lay.s_z)[rr];  // -(G dz)_0 = dx(0)
+          if (i < N)
+            wl[(long)(i + 1) * nx + rr] = -(tile_ABz(rr) - dz[(long)(i + 1) * ns + rr]);
+        }
+      }
+      c.sync();
+    }
+  }
+
+  // ---- one refinement of the step (same rule as the record kernels') ---------
+  // Squared norm of what the linear solve left of the Newton system in its z and l block rows at the
+  // step (dz, dl, dv): minus the inner residual's affine blocks at x + dx (full_residual.cc:52-66).
+  FB_DEV double linear_residual2(const C& c, double sigma) const {
+    double s[1] = {0.0};
+    for (int i = c.tid; i < nz; i += C::nt) {
+      const double r = (rz[i] + wz[i]) + sigma * ((z[i] + dz[i]) - zb[i]);
+      s[0] += r * r;
+    }
+    for (int i = c.tid; i < nl; i += C::nt) {
+      const double r = (rl[i] + wl[i]) + sigma * ((l[i] + dl[i]) - lb[i]);
+      s[0] += r * r;
+    }
+    c.sum(s);
+    return s[0];
+  }
+  // V ddx = r - V dx with the factors newton_step() left in `fac` (this kernel inverts its triangular
+  // factors explicitly too: forward stable only, see the header), dx += ddx: the vector recursions of
+  // riccati_linear_solver.cc:212-327 once more, on the residual.  dv and W follow from the refined
+  // (dz, dl) as before.
+  FB_DEV void refine_step(const C& c, double sigma) const {
+    const int N = lay.N, nx = lay.nx, nu = lay.nu, ns = lay.ns;
+    mptr Linv = lds + lay.w_linv; mptr Minv = lds + lay.w_minv;
+    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SGinv = lds + lay.w_sginv; mptr P = lds + lay.w_p;
+    mptr r1 = lds + lay.w_r1;
+    mptr th = lds + lay.w_th; mptr thp = lds + lay.w_thp; mptr hh = lds + lay.w_h;
+    mptr tx = lds + lay.w_tx; mptr tu = lds + lay.w_tu;
+    mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2;
+    for (int r = c.tid; r < nx; r += C::nt) thp[r] = 0.0;
+    c.sync();
+    for (int i = 0; i <= N; i++) {
+      double* F = fac + (long)i * lay.f_stride;
+      copy_in(c, Minv, F + lay.f_minv, nx * nx);
+      copy_in(c, Linv, F + lay.f_linv, nx * nx);
+      copy_in(c, SM, F + lay.f_sm, nu * nx);
+      copy_in(c, SGinv, F + lay.f_sginv, nu * nu);
+      if (i < N) {
+        copy_in(c, AM, F + lay.f_am, nx * nx);
+        copy_in(c, P, F + lay.f_p, nu * nx);
+      }
+      for (int r = c.tid; r < ns + nx; r += C::nt) {
+        if (r < ns) {
+          const long g = (long)i * ns + r;
+          r1[r] = -((rz[g] + wz[g]) + sigma * ((z[g] + dz[g]) - zb[g]));
+        } else {
+          const int rr = r - ns;
+          const long g = (long)i * nx + rr;
+          th[rr] = thp[rr] + ((rl[g] + wl[g]) + sigma * ((l[g] + dl[g]) - lb[g]));
+        }
+      }
+      c.sync();
+      for (int r = c.tid; r < nx; r += C::nt) {  // w = inv(L) theta
+        double s = 0.0;
+        for (int k = 0; k <= r; k++) s += Linv[r + k * nx] * th[k];
+        t1[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < nx; r += C::nt) {  // h = inv(L)' w - rx
+        double s = -r1[r];
+        for (int k = r; k < nx; k++) s += Linv[k + r * nx] * t1[k];
+        hh[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < nx; r += C::nt) {  // tx = inv(M) h
+        double s = 0.0;
+        for (int k = 0; k <= r; k++) s += Minv[r + k * nx] * hh[k];
+        tx[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < nu; r += C::nt) {  // t2 = SM tx + ru
+        double s = r1[nx + r];
+        for (int k = 0; k < nx; k++) s += SM[r + k * nu] * tx[k];
+        t2[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < nu; r += C::nt) {  // tu = inv(SG) t2
+        double s = 0.0;
+        for (int k = 0; k <= r; k++) s += SGinv[r + k * nu] * t2[k];
+        tu[r] = s;
+      }
+      c.sync();
+      for (int r = c.tid; r < nx; r += C::nt) {
+        F[lay.f_tx + r] = tx[r];
+        F[lay.f_th + r] = th[r];
+        if (i < N) {  // theta(i+1) partial = P tu + AM tx
+          double s = 0.0;
+          for (int k = 0; k < nu; k++) s += P[r + k * nx] * tu[k];
+          for (int k = 0; k < nx; k++) s += AM[r + k * nx] * tx[k];
+          thp[r] = s;
+        }
+      }
+      for (int r = c.tid; r < nu; r += C::nt) F[lay.f_tu + r] = tu[r];
+      c.sync();
+    }
+    // the correction to (wz, wl) - the forward recursion above has read them, the post sweep rewrites them
+    backward_sweep(c, wz, wl);
+    for (int i = c.tid; i < nz; i += C::nt) dz[i] += wz[i];
+    for (int i = c.tid; i < nl; i += C::nt) dl[i] += wl[i];
+    c.sync();
+    post_sweep(c);
+  }
+
   // ---- the Newton step --------------------------------------------------------
   // Solves V(x,xbar,sigma) dx = -R(x,xbar,sigma) (abstract_components.h:276-288)
   // and produces dz, dl, dv, adz = A dz, wz = H dz + G'dl + A'dv, wl = -G dz.
@@ -422,7 +632,7 @@ struct MpcProblem {
     mptr r1 = lds + lay.w_r1; mptr r2 = lds + lay.w_r2;
     mptr th = lds + lay.w_th; mptr thp = lds + lay.w_thp; mptr hh = lds + lay.w_h;
     mptr tx = lds + lay.w_tx; mptr tu = lds + lay.w_tu;
-    mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2; mptr lp = lds + lay.w_lp;
+    mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2;
 
     // Base case L(0) = sqrt(sigma) I  =>  inv(L(0)) = I / sqrt(sigma)
     // (riccati_linear_solver.cc:127).
@@ -630,101 +840,8 @@ struct MpcProblem {
       }
     }
 
-    // ============ backward sweep (:267-327) =================================
-    // Stage N is still resident in LDS.
-    for (int i = N; i >= 0; i--) {
-      if (i < N) {
-        const double* F = fac + (long)i * lay.f_stride;
-        copy_in(c, Minv, F + lay.f_minv, nx * nx);
-        copy_in(c, Linv, F + lay.f_linv, nx * nx);
-        copy_in(c, AM, F + lay.f_am, nx * nx);
-        copy_in(c, SM, F + lay.f_sm, nu * nx);
-        copy_in(c, P, F + lay.f_p, nu * nx);
-        copy_in(c, SGinv, F + lay.f_sginv, nu * nu);
-        copy_in(c, tx, F + lay.f_tx, nx);
-        copy_in(c, tu, F + lay.f_tu, nu);
-        copy_in(c, th, F + lay.f_th, nx);
-        c.sync();
-      }
-      // a = tu + P' l(i+1)   (a = tu at the terminal stage)
-      for (int r = c.tid; r < nu; r += C::nt) {
-        double s = tu[r];
-        if (i < N)
-          for (int k = 0; k < nx; k++) s += P[k + r * nx] * lp[k];
-        t2[r] = s;
-      }
-      c.sync();
-      // u = inv(SG)' a
-      for (int r = c.tid; r < nu; r += C::nt) {
-        double s = 0.0;
-        for (int k = r; k < nu; k++) s += SGinv[k + r * nu] * t2[k];
-        t1[nx + r] = s;
-      }
-      c.sync();
-      // b = tx + SM' u + AM' l(i+1)
-      for (int r = c.tid; r < nx; r += C::nt) {
-        double s = tx[r];
-        for (int k = 0; k < nu; k++) s += SM[k + r * nu] * t1[nx + k];
-        if (i < N)
-          for (int k = 0; k < nx; k++) s += AM[k + r * nx] * lp[k];
-        t2[r] = s;
-      }
-      c.sync();
-      // x = -inv(M)' b
-      for (int r = c.tid; r < nx; r += C::nt) {
-        double s = 0.0;
-        for (int k = r; k < nx; k++) s += Minv[k + r * nx] * t2[k];
-        t1[r] = -s;
-      }
-      c.sync();
-      // w = inv(L)(theta + x);  l = -inv(L)' w
-      for (int r = c.tid; r < nx; r += C::nt) {
-        double s = 0.0;
-        for (int k = 0; k <= r; k++) s += Linv[r + k * nx] * (th[k] + t1[k]);
-        t2[r] = s;
-      }
-      c.sync();
-      for (int r = c.tid; r < ns + nx; r += C::nt) {
-        if (r < ns) {
-          dz[(long)i * ns + r] = t1[r];
-        } else {
-          const int rr = r - ns;
-          double s = 0.0;
-          for (int k = rr; k < nx; k++) s += Linv[k + rr * nx] * t2[k];
-          lp[rr] = -s;
-          dl[(long)i * nx + rr] = -s;
-        }
-      }
-      c.sync();
-    }
-
-    // ============ post sweep: dv, A dz and W (:329-341 + the residual
-    // increment of fb_algorithm.h) ========================================
-    for (int i = 0; i <= N; i++) {
-      load_tile(c, i);
-      load_slices(c, i, dz, dl, nullptr);
-      c.sync();
-      for (int k = c.tid; k < nc; k += C::nt) {
-        const long g = (long)i * nc + k;
-        const double a = tile_Az(k);
-        const double d = rvm[g] + gam[g] * a;
-        adz[g] = a;
-        dv[g] = d;
-        (lds + lay.s_v)[k] = d;
-      }
-      c.sync();
-      for (int r = c.tid; r < ns + nx; r += C::nt) {
-        if (r < ns) {
-          wz[(long)i * ns + r] = tile_Hz(r) + tile_GTl(i, r) + tile_ATv(r);
-        } else {
-          const int rr = r - ns;
-          if (i == 0) wl[rr] = (lds + lay.s_z)[rr];  // -(G dz)_0 = dx(0)
-          if (i < N)
-            wl[(long)(i + 1) * nx + rr] = -(tile_ABz(rr) - dz[(long)(i + 1) * ns + rr]);
-        }
-      }
-      c.sync();
-    }
+    backward_sweep(c, dz, dl);
+    post_sweep(c);
     return true;
   }
 

@@ -473,7 +473,7 @@ struct MpcR16 {
   // lane (zb[c] = element c of the stage vector): C through its LDS transpose.
   // Caller has written Cl and synchronised.
   template <class Out>
-  FB_DEV void rows_of_C_times(lds_ptr Cl, const double (&zb)[NS], int r, Out&& out) const {
+  static FB_DEV void rows_of_C_times(lds_ptr Cl, const double (&zb)[NS], int r, Out&& out) {
     sfor<0, KS>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
       const int k = r + LPQ * s;
@@ -483,7 +483,7 @@ struct MpcR16 {
       out(S_, k < NC, dot4<NS>(clk, zb));
     });
   }
-  FB_DEV void C_to_lds(const C& c, lds_ptr Cl, const double (&Cc)[NC], int r) const {
+  static FB_DEV void C_to_lds(const C& c, lds_ptr Cl, const double (&Cc)[NC], int r) {
     c.sync();
     sfor<0, NC>([&](auto Kk) { Cl[r * CS + decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
     c.sync();
@@ -1949,6 +1949,15 @@ struct MpcR16 {
     double vb[KS];
   };
   static FB_DEV void load_fwd(const double* R, FwdIn& in) {
+#if defined(FB_R16_EXTRA_READS)
+    {  // (experiment: up to three more slot pairs per stage and forward sweep - pairs no sweep touches:
+       //  ybar, (f h), b - read and thrown away: what a per cent of record traffic costs)
+      const dbl2 j0 = ld2(R, sYB);
+      asm volatile("" ::"v"(j0));
+      if constexpr (FB_R16_EXTRA_READS > 1) { const dbl2 j1 = ld2(R, sF); asm volatile("" ::"v"(j1)); }
+      if constexpr (FB_R16_EXTRA_READS > 2) { const dbl2 j2 = ld2(R, sB); asm volatile("" ::"v"(j2)); }
+    }
+#endif
     in.zr = ld2(R, sZ);
     in.bb = ld2(R, sZB);
     in.dw = ld2(R, sDZ);
@@ -1966,7 +1975,9 @@ struct MpcR16 {
     dbl2 zr, bb, lr;
     dbl2 vy[KS], gr[KS];
     double vb[KS];
+    dbl2 dw, dwl, da[KS];  // (refinement sweep only) the step in the record: (dz wz) (dl wl+) (dv adz)
   };
+  template <bool REFINE = false>
   static FB_DEV void load_bwd(const double* R, BwdIn& in) {
     in.zr = ld2(R, sZ);
     in.bb = ld2(R, sZB);
@@ -1975,8 +1986,13 @@ struct MpcR16 {
       constexpr int s = decltype(S_)::value;
       in.vy[s] = ld2(R, sV + 2 * s);
       if constexpr (kStoreGamma) in.gr[s] = ld2(R, sGAM + 2 * s);
+      if constexpr (REFINE) in.da[s] = ld2(R, sDV + 2 * s);
     });
     ldv<sVB, KS>(R, in.vb);
+    if constexpr (REFINE) {
+      in.dw = ld2(R, sDZ);
+      in.dwl = ld2(R, sDL);
+    }
   }
   // (gamma, rv / mu) of constraint k at (v, y) for the subproblem centred at vbar
   // (riccati_linear_solver.cc:91-99)
@@ -1989,31 +2005,97 @@ struct MpcR16 {
     return o;
   }
 
+  // What a Newton step hands back: the squared norms of the inner and the penalised natural residual at
+  // x + dx (the first line-search trial) and `lin2`, the part of the first that belongs to the z and l
+  // blocks - there the residual is affine in x, so that part IS the squared norm of the Newton system's
+  // own residual r - V dx in those block rows (the third block row is solved exactly, dv = D^-1(rv + C A dz)):
+  // what the linear solve left over.  It decides whether the step is refined (refine_step()).
+  struct StepOut {
+    double in2, out2, lin2;
+    int loff;  // matrix copy left resident in LDS
+    bool ok;
+  };
   FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
-                          double* trial_outer2) {
+                          double* trial_outer2, double* lin2 = nullptr) {
     FB_WAVE_COUNT(27);  // Newton steps executed by the wavefront (any row active)
     FB_WAVE_TIMER(20);
     // (row-uniform; rows of a wavefront that disagree run one form after the other)
-    if (rowdl) return newton_step_t<true>(c, sigma, alpha, trial_inner2, trial_outer2);
-    return newton_step_t<false>(c, sigma, alpha, trial_inner2, trial_outer2);
-  }
-  // ROW: the costate step from the Newton system's row, form (b) above
-  template <bool ROW>
-  FB_DEV bool newton_step_t(const C& c, double sigma, double alpha, double* trial_inner2,
-                            double* trial_outer2) {
-    // Locals only below: lambdas must not capture `this`.
-    const int N_ = N;
-    const int r = c.tid;
-    double* const R0 = rec;
-    const double* const P0 = pack;
-    const lds_iptr po = lpo;
-    pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
-    lds_ptr Tr = lds + kPackLds;
-    lds_ptr Cl = lds + kPackLds;
-    const bool rx = r < NX;
-    const bool bnd = bounds;
     const double tp = pend_t;  // pending step length
     pend_t = 0.0;
+    StepOut o;
+    if (rowdl) o = newton_core<true, false>(c, rec, pack, lpo, lds, pack_view(c), N, bounds, tp, lds_off, sigma, alpha);
+    else o = newton_core<false, false>(c, rec, pack, lpo, lds, pack_view(c), N, bounds, tp, lds_off, sigma, alpha);
+    lds_off = o.loff;
+    *trial_inner2 = o.in2;
+    *trial_outer2 = o.out2;
+    if (lin2) *lin2 = o.lin2;
+    return o.ok;
+  }
+  // ---- one refinement of the step in the record ---------------------------------
+  // The sweeps multiply with explicitly inverted triangular factors where the reference substitutes
+  // (riccati_linear_solver.cc:234-325): forward stable, not backward stable - on ill-conditioned stages
+  // (wide stages, the first ceil(nx / nu) stages of every problem, whose Pi_i keeps eigenvalues of order
+  // sigma) the step can leave a residual r - V dx orders above eps |V| |dx|, and a QP whose convergence
+  // test sits inside that band takes an iteration the reference does not.  refine_step() solves
+  // V ddx = r - V dx with the SAME factors (the forward sweep is run again on the residual, which it forms
+  // from the step in the record; the factorisation is recomputed - identical values - rather than kept:
+  // W and, in the row form, inv(Pi) are not in the record) and adds ddx to the step; dv follows the third
+  // block row exactly as before.  One such sweep leaves eps |V| |dx| in every block
+  // (tools/riccati_forms_study.py).  The caller decides when: Solver::solve_stream asks for it when
+  // sqrt(lin2) exceeds a fraction of the tolerance its next tests compare against - typical QPs never do
+  // (BASELINE workload: 1e-12 against 1e-6) and run bitwise as before.
+  // Real calls (no inlining): a second copy of the sweeps inside the solver loop would cost the common
+  // path its register allocation.  They take scalars only, like the cooperative passes.
+  template <bool L = kPackInLds>
+  static FB_DEV auto view_of(const C& c, lds_ptr lds_row, const double* P0) {
+    if constexpr (L) return lds_row + 2 * c.tid;
+    else return P0;
+  }
+  static __device__ __attribute__((noinline)) StepOut refine_row_form(double* R0, const double* P0, lds_iptr po,
+                                                                      lds_ptr lds_row, int N_, bool bnd, int loff,
+                                                                      double sigma, double alpha) {
+    C c;
+    c.tid = threadIdx.x & (LPQ - 1);
+    pk_ptr Lp = view_of(c, lds_row, P0);
+    return newton_core<true, true>(c, R0, P0, po, lds_row, Lp, N_, bnd, 0.0, loff, sigma, alpha);
+  }
+  static __device__ __attribute__((noinline)) StepOut refine_ref_form(double* R0, const double* P0, lds_iptr po,
+                                                                      lds_ptr lds_row, int N_, bool bnd, int loff,
+                                                                      double sigma, double alpha) {
+    C c;
+    c.tid = threadIdx.x & (LPQ - 1);
+    pk_ptr Lp = view_of(c, lds_row, P0);
+    return newton_core<false, true>(c, R0, P0, po, lds_row, Lp, N_, bnd, 0.0, loff, sigma, alpha);
+  }
+  // No step may be pending (the Newton step that wrote the record has consumed it).
+  FB_DEV bool refine_step(const C&, double sigma, double alpha, double* trial_inner2, double* trial_outer2,
+                          double* lin2) {
+    StepOut o;
+    if (rowdl) o = refine_row_form(rec, pack, lpo, lds, N, bounds, lds_off, sigma, alpha);
+    else o = refine_ref_form(rec, pack, lpo, lds, N, bounds, lds_off, sigma, alpha);
+    lds_off = o.loff;
+    if (!o.ok) return false;  // (cannot happen: the same factorisation has just succeeded; the step stands)
+    *trial_inner2 = o.in2;
+    *trial_outer2 = o.out2;
+    *lin2 = o.lin2;
+    return true;
+  }
+
+  // ROW: the costate step from the Newton system's row, form (b) above.
+  // REFINE: the right-hand side is the Newton system's residual at the step in the record, and the
+  // backward sweep ADDS its solution to that step (refine_step()).
+  template <bool ROW, bool REFINE>
+  static FB_DEV StepOut newton_core(const C& c, double* const R0, const double* const P0, const lds_iptr po,
+                                    lds_ptr lds_row, pk_ptr Lp, const int N_, const bool bnd, const double tp,
+                                    int loff, double sigma, double alpha) {
+    // Locals only below: the lambdas capture no object.
+    const int r = c.tid;
+    lds_ptr Tr = lds_row + kPackLds;
+    lds_ptr Cl = lds_row + kPackLds;
+    const bool rx = r < NX;
+    StepOut ret;
+    ret.in2 = ret.out2 = ret.lin2 = 0.0;
+    ret.ok = false;
 
     double Pinv[NX];  // row r of inv(Pi_i); Pi_0 = sigma I (riccati_linear_solver.cc:127)
     sfor<0, NX>([&](auto Cc) { Pinv[decltype(Cc)::value] = (rx && r == decltype(Cc)::value) ? 1.0 / sigma : 0.0; });
@@ -2027,8 +2109,7 @@ struct MpcR16 {
     double wln = 0.0;  // WLN of the previous stage = wl of this one
     // offsets of the matrix copies of stages i and i+1 (fetched a stage ahead)
     int pcur = po[0], pnxt = po[N_ > 0 ? 1 : 0];
-    int loff = lds_off;  // copy resident in LDS
-    load_fwd(R0, cur);
+    load_fwd(R0, cur);  // (loff: the copy resident in LDS)
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
       FB_PHASE(fwd_top);
@@ -2052,19 +2133,30 @@ struct MpcR16 {
         const dbl2 bt = barrier_terms(vk, yk, cur.vb[s], sigma, alpha, k < NC);
         Gam[s] = bt[0];
         Rvm[s] = bt[1];
-        st2(R, sV + 2 * s, vk, yk);
-        if constexpr (kStoreGamma) st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
+        if constexpr (!REFINE) {  // (the refinement sweep finds all of this in the record: tp = 0)
+          st2(R, sV + 2 * s, vk, yk);
+          if constexpr (kStoreGamma) st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
+        }
       });
       // pending step on (z, rz), (l, rl); eliminated right-hand side (:222-225)
       const double zz = fma(tp, cur.dw[0], cur.zr[0]);
       const double rzz = fma(tp, cur.dw[1], cur.zr[1]);
       const double ll = fma(tp, cur.dwl[0], cur.lr[0]);
-      const double rll = fma(tp, wl_of_stage(i, rx, cur.dw[0], wln), cur.lr[1]);
+      const double wlcur = wl_of_stage(i, rx, cur.dw[0], wln);  // wl(i) of the step in the record
+      const double rll = fma(tp, wlcur, cur.lr[1]);
       wln = cur.dwl[1];
-      st2(R, sZ, zz, rzz);
-      st2(R, sL, ll, rll);
-      double r1 = -(rzz + sigma * (zz - cur.bb[0]));  // zero where there is no row
-      const double r2 = rll + sigma * (ll - cur.bb[1]);
+      double r1, r2;
+      if constexpr (!REFINE) {
+        st2(R, sZ, zz, rzz);
+        st2(R, sL, ll, rll);
+        r1 = -(rzz + sigma * (zz - cur.bb[0]));  // zero where there is no row
+        r2 = rll + sigma * (ll - cur.bb[1]);
+      } else {
+        // r - V dx in the z and l block rows = minus the inner residual's affine blocks at x + dx, formed
+        // the way the backward sweep's trial norms form them (the v block row holds exactly: no rv term)
+        r1 = -((rzz + cur.dw[1]) + sigma * ((zz + cur.dw[0]) - cur.bb[0]));
+        r2 = (rll + wlcur) + sigma * ((ll + cur.dwl[0]) - cur.bb[1]);
+      }
       FB_SB();
       // next stage's inputs, a whole stage ahead (the last stage fetches itself once
       // more: no branch here)
@@ -2073,7 +2165,7 @@ struct MpcR16 {
       FB_STAMP_LAP(0);
       // K row: H + sigma I (at pivot time) + inv(Pi) block + C' Gamma C (:101-123, :142-145)
       sfor<0, NX>([&](auto Cc) { K[decltype(Cc)::value] += Pinv[decltype(Cc)::value]; });
-      {
+      if constexpr (!REFINE) {
         double p[4] = {r1, 0.0, 0.0, 0.0};
         bc_cols_dot<NC, RQ, true>(Cc_, Rvm, p);
         r1 = (p[0] + p[1]) + (p[2] + p[3]);
@@ -2140,7 +2232,7 @@ struct MpcR16 {
       // :149-175) from one pass over Lc
       double W[NS];
       ok = chol_rows<NS, RQ>(K, ro, sigma) && ok;
-      if (!ok) { lds_off = loff; return false; }
+      if (!ok) { ret.loff = loff; return ret; }
       double XC[NS];
       FB_STAMP_LAP(3);
       FB_SB();
@@ -2208,7 +2300,7 @@ struct MpcR16 {
         FB_SB();
         FB_STAMP_LAP(7);
         ok = chol_rows<NX, RQ>(Pn, ro, sigma) && ok;
-        if (!ok) { lds_off = loff; return false; }
+        if (!ok) { ret.loff = loff; return ret; }
         FB_SB();
         FB_PHASE(tinv12);
         double T[NX];
@@ -2244,7 +2336,15 @@ struct MpcR16 {
     // u), and the stage's own iterate vectors come a stage ahead as one bundle.
     double lp = 0.0;    // dl(i+1), lanes < NX
     double dzn = 0.0;   // dx(i+1), lanes < NX
+    [[maybe_unused]] double lpt = 0.0;  // (REFINE) dl(i+1) of the refined step; lp and dzn are then the correction's
     double s_in = 0.0, s_out = 0.0;
+    // the z and l blocks' share of s_in (StepOut::lin2).  It feeds a threshold test only: summed in single
+    // precision, one 32-bit register held across the sweep.  (What it costs was measured - a double, a float
+    // and a sum kept in LDS with ds_add_f64 all put the headline 2 % under a build without it, and so does a
+    // build in which the optimiser removes the sum again because nobody reads it: not the sum, the register
+    // allocation of a kernel at 491 of 512 registers moves with any change of its source; gpurun_out/r05_c..f.)
+    float s_lin = 0.f;
+    auto lin_acc = [](double ri, float acc) { const float rf = (float)ri; return fmaf(rf, rf, acc); };
     dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1, handed down by stage i+1
     double lbn = 0.0;
     double Ac[NX];
@@ -2259,7 +2359,7 @@ struct MpcR16 {
       const double* R = R0 + (long)N_ * kRec;
       load_fac(R);
       ldv<pABc, NX>(P0 + pcur, Ac);
-      load_bwd(R, bin);
+      load_bwd<REFINE>(R, bin);
     }
     for (int i = N_; i >= 0; i--) {
       FB_PHASE(bwd_top);
@@ -2270,7 +2370,7 @@ struct MpcR16 {
       int ro = r;
       asm volatile("" : "+v"(ro));
       BwdIn cu = bin;
-      load_bwd(Rp, bin);
+      load_bwd<REFINE>(Rp, bin);
       if constexpr (!kStoreGamma) {
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
@@ -2349,18 +2449,29 @@ struct MpcR16 {
       rows_of_C_times(Cl, dzb, r, [&](auto S_, bool valid, double a) {
         constexpr int sl = decltype(S_)::value;
         double d = 0.0;
+        double dt = 0.0, at = valid ? a : 0.0;  // what the record gets: the step, or (REFINE) the step + correction
+        if constexpr (REFINE) {
+          dt = cu.da[sl][0];
+          at = cu.da[sl][1] + at;
+        }
         if (valid) {
-          d = cu.gr[sl][1] + cu.gr[sl][0] * a;
+          if constexpr (REFINE) {
+            d = cu.gr[sl][0] * a;  // (no rv / mu: the third block row has no residual)
+            dt += d;
+          } else {
+            d = cu.gr[sl][1] + cu.gr[sl][0] * a;
+            dt = d;
+          }
           // first line-search trial, v block (full_residual.cc:68-71, :99-106)
-          const double vi = cu.vy[sl][0] + d;
-          const double yi = cu.vy[sl][1] - a;
+          const double vi = cu.vy[sl][0] + dt;
+          const double yi = cu.vy[sl][1] - at;
           const double ys = yi + sigma * (vi - cu.vb[sl]);
           const double ph = pfb(ys, vi, alpha);
           const double pn = pnr(yi, vi, alpha);
           s_in = fma(ph, ph, s_in);
           s_out = fma(pn, pn, s_out);
         }
-        st2(R, sDV + 2 * sl, d, valid ? a : 0.0);
+        st2(R, sDV + 2 * sl, dt, at);
         dvs[sl] = d;
       });
       // ---- wz = H dz + G'dl + A'dv; (G'dl)_x = [A B]'dl(i+1) - dl(i)
@@ -2371,51 +2482,67 @@ struct MpcR16 {
         w = (p[0] + p[1]) + (p[2] + p[3]);
         if constexpr (ROW) {
           // form (b): the state rows of (H + sigma I) dz + G'dl + A'dv = -(rz + sigma (z - zbar))
-          const double rin = cu.zr[1] + sigma * (cu.zr[0] - cu.bb[0]);  // inner residual, z block
+          // inner residual, z block - (REFINE) at x + dx: what is left of the row
+          double rin = cu.zr[1] + sigma * (cu.zr[0] - cu.bb[0]);
+          if constexpr (REFINE) rin = (cu.zr[1] + cu.dw[1]) + sigma * ((cu.zr[0] + cu.dw[0]) - cu.bb[0]);
           dli = rx ? (w + sigma * dzu) + rin : 0.0;
           w -= dli;
         }
+      }
+      // (REFINE) from here on the STEP: what the record held plus this sweep's correction
+      double dzt = dzu, wt = w, dlt = dli;
+      if constexpr (REFINE) {
+        dzt += cu.dw[0];
+        wt += cu.dw[1];
+        dlt += cu.dwl[0];
       }
       double wlv = 0.0;  // wl(i + 1)
       if (i < N_) {
         // l block i+1: wl = -(A dx + B du - dx(i+1)); trial norms (full_residual.cc:60-66)
         const double abz = dot4<NS>(AB, dzb);
         wlv = rx ? -(abz - dzn) : 0.0;
+        if constexpr (REFINE) wlv += cu.dwl[1];  // (dzn is the correction's: wl(i + 1) of the step + its increment)
         const double lr = lrn[1] + wlv;
-        const double li = lrn[0] + lp;
+        const double li = lrn[0] + (REFINE ? lpt : lp);
         const double ri = lr + sigma * (li - lbn);
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
+        s_lin = lin_acc(ri, s_lin);
       }
       {
-        st2(R, sDZ, dzu, w);
-        const double zrr = cu.zr[1] + w;
-        const double zi = cu.zr[0] + dzu;
+        st2(R, sDZ, dzt, wt);
+        const double zrr = cu.zr[1] + wt;
+        const double zi = cu.zr[0] + dzt;
         const double ri = zrr + sigma * (zi - cu.bb[0]);
         s_in = fma(ri, ri, s_in);
         s_out = fma(zrr, zrr, s_out);
+        s_lin = lin_acc(ri, s_lin);
       }
-      st2(R, sDL, dli, wlv);
+      st2(R, sDL, dlt, wlv);
       if (i == 0) {
         // l block 0: -(G dz)_0 = dx(0)
-        const double wl0 = rx ? dzu : 0.0;
+        const double wl0 = rx ? dzt : 0.0;
         const double lr = cu.lr[1] + wl0;
-        const double li = cu.lr[0] + dli;
+        const double li = cu.lr[0] + dlt;
         const double ri = lr + sigma * (li - cu.bb[1]);
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
+        s_lin = lin_acc(ri, s_lin);
       }
       lp = dli;
+      if constexpr (REFINE) lpt = dlt;
       dzn = rx ? dzu : 0.0;
       lrn = cu.lr;
       lbn = cu.bb[1];
       FB_STAMP_LAP(10);
       FB_PHASE(bwd_end);
     }
-    lds_off = loff;
-    *trial_inner2 = qp_reduce<RQ, OpSum16>(s_in);
-    *trial_outer2 = qp_reduce<RQ, OpSum16>(s_out);
-    return true;
+    ret.loff = loff;
+    ret.in2 = qp_reduce<RQ, OpSum16>(s_in);
+    ret.out2 = qp_reduce<RQ, OpSum16>(s_out);
+    ret.lin2 = qp_reduce<RQ, OpSum16>((double)s_lin);
+    ret.ok = true;
+    return ret;
   }
 };
 

@@ -39,8 +39,12 @@ __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_op
     p.choose_costate_form(opts.sigma0);
     p.probe_set_xbar(ctx, dbg);
     p.residual(ctx);
-    double a, b;
-    const bool ok = p.newton_step(ctx, opts.sigma0, opts.alpha, &a, &b);
+    double a, b, lin2;
+    const bool ok = p.newton_step(ctx, opts.sigma0, opts.alpha, &a, &b, &lin2);
+    // the solver's own rule for refining a step (Solver::wants_refinement), no inner tolerance in play
+    Solver<P, C> rule(p, ctx, opts);
+    if (ok && rule.wants_refinement(lin2, opts.abs_tol, opts.abs_tol))
+      p.refine_step(ctx, opts.sigma0, opts.alpha, &a, &b, &lin2);
     ctx.sync();
     p.probe_dump(ctx, dbg, ok);
     return;
@@ -57,6 +61,11 @@ __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_op
     ok = p.newton_step(ctx, opts.sigma0, opts.alpha, &a, &b);
   } else {
     ok = p.newton_step(ctx, opts.sigma0, opts.alpha);
+    if constexpr (can_refine_of<P>::value) {  // the solver's own rule (Solver::wants_refinement)
+      Solver<P, C> rule(p, ctx, opts);
+      if (ok && rule.wants_refinement(p.linear_residual2(ctx, opts.sigma0), opts.abs_tol, opts.abs_tol))
+        p.refine_step(ctx, opts.sigma0);
+    }
   }
   ctx.sync();
   double* o = dbg;
@@ -183,6 +192,10 @@ struct R16Queue {
     return (typename P::lds_iptr)((lds_ptr)smem_ + P::kQpPerWave * P::kLdsPerRow) + row() * P::lpo_ints(N);
   }
   __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
+  // ctl[1]: Newton steps of this launch that were refined (fbstab_hip_mpc_refined_steps)
+  __device__ __forceinline__ void count_refinement() const {
+    if (tid() == 0) atomicAdd(&ctl[1], 1);
+  }
 
   // Sweep: the rows of a wavefront start every step of their trajectories together
   // (Solver::solve_stream, kPause) - warm-started steps are mostly passes over the

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(NT, FB_MPC_MIN_WAVES) void fbstab_mpc_kernel(MpcLay
     } else {
       Solver<MpcProblem<C, WG>, C, TRACE> solver(p, ctx, opts, dbg);
       solver.solve(out + q);
+      if (solver.refined_ > 0 && ctx.tid == 0) atomicAdd(counter + 1, solver.refined_);  // fbstab_hip_mpc_refined_steps
     }
     ctx.sync();
   }
@@ -1030,6 +1031,19 @@ int fbstab_hip_mpc_query(fbstab_mpc_handle_t h, long long* scratch_bytes, int* l
 const char* fbstab_hip_mpc_kernel_name(fbstab_mpc_handle_t h) {
   if (!h) return "";
   return h->rec ? h->rec->name : "fbstab_mpc_kernel<64>";
+}
+
+int fbstab_hip_mpc_refined_steps(fbstab_mpc_handle_t h, long long* steps) {
+  if (!h) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null solver handle");
+  if (!steps) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null output pointer");
+  *steps = -1;
+  if (!h->timed) return FBSTAB_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  int n = 0;  // word 1 of the queue block (zeroed before every launch): R16Queue::count_refinement, fb_mpc.h
+  HIP_TRY(hipMemcpy(&n, h->counter + 1, sizeof(n), hipMemcpyDeviceToHost));
+  *steps = n;
+  return FBSTAB_HIP_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -147,6 +147,8 @@ def load_library() -> C.CDLL:
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.fbstab_hip_mpc_kernel_name.restype = C.c_char_p
     lib.fbstab_hip_mpc_kernel_name.argtypes = [C.c_void_p]
+    if hasattr(lib, "fbstab_hip_mpc_refined_steps"):  # (absent from a round-4 build loaded for an A/B: FBSTAB_HIP_LIB)
+        lib.fbstab_hip_mpc_refined_steps.argtypes = [C.c_void_p, C.c_void_p]
     lib.fbstab_hip_mpc_receding_sweep.argtypes = [
         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -171,6 +173,7 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch", "fbstab_hip_mpc_solve_batch_final",
     "fbstab_hip_mpc_solve_traced", "fbstab_hip_mpc_receding_sweep",
     "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_kernel_name",
+    "fbstab_hip_mpc_refined_steps",
     "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
     "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_batch_final",
@@ -367,6 +370,12 @@ class FBstabMpcBatch(_SolverBase):
 
     def kernel_name(self) -> str:
         return self._lib.fbstab_hip_mpc_kernel_name(self._h).decode()
+
+    def refined_steps(self) -> int:
+        """Newton steps of the last call that were refined (fbstab_hip_mpc_refined_steps)."""
+        n = C.c_longlong(-1)
+        _check(self._lib, self._lib.fbstab_hip_mpc_refined_steps(self._h, C.byref(n)))
+        return int(n.value)
 
     def Solve(self, data: Dict[str, object], z, l, v, y, out=None, stream: int = 0,
               async_: bool = False, keep_matrices: bool = False):

@@ -78,6 +78,52 @@ def mpc_explicit(p, b=0):
     return H, f, G, h, A, bb
 
 
+def newton_system_residual(p, q, step, x=None, xbar=None, sigma=1e-8, alpha=0.95):
+    """|V dx - r| of the Newton system V(x, xbar, sigma) dx = -R(x, xbar, sigma) (abstract_components.h:276-288,
+    full_residual.cc:49-74) for QP ``q`` of the MpcProblem ``p`` at x = (z, l, v) (default: zeros), evaluated in
+    numpy longdouble (64-bit mantissa).  step: dict with dz, dl, dv.  Returns ([max |.| of the z, l, v block
+    rows], 2-norm over all rows)."""
+    LD = np.longdouble
+    Hm, f, G, hh, A, b = (m.astype(LD) for m in mpc_explicit(p, q))
+    zero = lambda n: np.zeros(n, LD)
+    z, l, v = (t.astype(LD) for t in x) if x is not None else (zero(p.nz), zero(p.nl), zero(p.nv))
+    zb, lb, vb = (t.astype(LD) for t in xbar) if xbar is not None else (z, l, v)
+    sig, al = LD(sigma), LD(alpha)
+    ys = (b - A @ z) + sig * (v - vb)
+    rr = np.sqrt(ys * ys + v * v)
+    c0 = al * (1 - 1 / np.sqrt(LD(2)))
+    safe = np.where(rr > 0, rr, 1)
+    gam = np.where(rr < 1e-13, c0, al * (1 - ys / safe))
+    mu = np.where(rr < 1e-13, c0, al * (1 - v / safe))
+    pos = (rr >= 1e-13) & (ys > 0) & (v > 0)
+    gam = np.where(pos, gam + (1 - al) * v, gam)
+    mu = np.where(pos, mu + (1 - al) * ys, mu)
+    mus = mu + sig * gam
+    phi = al * (ys + v - rr) + (1 - al) * np.maximum(ys, 0) * np.maximum(v, 0)
+    rz = -(Hm @ z + f + G.T @ l + A.T @ v + sig * (z - zb))
+    rl = -(hh - G @ z + sig * (l - lb))
+    dz, dl, dv = (np.asarray(step[k]).astype(LD) for k in ("dz", "dl", "dv"))
+    e1 = Hm @ dz + sig * dz + G.T @ dl + A.T @ dv - rz
+    e2 = -G @ dz + sig * dl - rl
+    e3 = -gam * (A @ dz) + mus * dv + phi
+    blocks = [float(np.abs(e).max()) for e in (e1, e2, e3)]
+    return blocks, float(np.sqrt((e1 * e1).sum() + (e2 * e2).sum() + (e3 * e3).sum()))
+
+
+def fuzz_stream_shape(seed, index):
+    """Shape number ``index`` (from 0) of tools/fuzz_shapes.py's stream for ``seed``: (problem, options)."""
+    from oracle.oracle_py import default_options
+    rng = np.random.default_rng(seed)
+    for it in range(index + 1):
+        nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
+        B = int(rng.integers(1, 14))
+        o = default_options()
+        if rng.random() < 0.3:
+            o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
+        p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    return p, o
+
+
 def dense_explicit(p, b=0):
     a = {k: v[b] for k, v in p.arrays.items()}
     H = a["H"].reshape(p.nz, p.nz).T

@@ -66,3 +66,24 @@ class HostSim:
             if prob.nl:
                 l[b] = lb
         return z, l, v, y, _out_to_numpy(out)
+
+    def newton_mpc(self, prob, b, x, xbar, sigma, alpha, refine_sweeps=0):
+        """One Newton step of the flat-vector device logic for QP ``b`` at x = (z, l, v), xbar (hostsim.cc:
+        hostsim_mpc_newton_refined), followed by ``refine_sweeps`` refinement sweeps.  Returns a dict."""
+        N, nx, nu, nc = prob.sizes()
+        a = {k: np.ascontiguousarray(prob.arrays[k][b]) for k in prob.arrays}
+        nz, nl, nv = prob.nz, prob.nl, prob.nv
+        out = np.zeros(3 * nz + 3 * nl + 2 * nv + 2)
+        z, l, v = (np.ascontiguousarray(t, dtype=np.float64) for t in x)
+        zb, lb, vb = (np.ascontiguousarray(t, dtype=np.float64) for t in xbar)
+        self.lib.hostsim_mpc_newton_refined.argtypes = [C.c_int] * 4 + [C.c_void_p] * 18 + [C.c_double, C.c_double, C.c_int, C.c_void_p]
+        rc = self.lib.hostsim_mpc_newton_refined(
+            N, nx, nu, nc, _p(a["Q"]), _p(a["R"]), _p(a["S"]), _p(a["q"]), _p(a["r"]), _p(a["A"]), _p(a["B"]),
+            _p(a["c"]), _p(a["E"]), _p(a["L"]), _p(a["d"]), _p(a["x0"]), _p(z), _p(l), _p(v), _p(zb), _p(lb), _p(vb),
+            C.c_double(sigma), C.c_double(alpha), refine_sweeps, _p(out))
+        o, r = 0, {"ok": rc == 0}
+        for name, n in (("dz", nz), ("dl", nl), ("dv", nv), ("adz", nv), ("wz", nz), ("wl", nl), ("rz", nz), ("rl", nl)):
+            r[name] = out[o:o + n].copy()
+            o += n
+        r["lin2_before"], r["lin2_after"] = out[o], out[o + 1]
+        return r

@@ -60,6 +60,13 @@ int hostsim_dense_solve(int nz, int nl, int nv, const double* H, const double* f
 
 }  // extern "C"
 
+extern "C" int hostsim_mpc_newton_refined(int N, int nx, int nu, int nc, const double* Q, const double* R,
+                                          const double* S, const double* q, const double* r, const double* A,
+                                          const double* B, const double* c, const double* E, const double* L,
+                                          const double* d, const double* x0, const double* z, const double* l,
+                                          const double* v, const double* zb, const double* lb, const double* vb,
+                                          double sigma, double alpha, int refine_sweeps, double* out);
+
 // Component probe: one Newton step of the device logic at (x, xbar, sigma).
 // out: dz,dl,dv,adz,wz,wl,rz,rl concatenated; returns 0 ok / 2 factor failure.
 extern "C" int hostsim_mpc_newton(int N, int nx, int nu, int nc, const double* Q,
@@ -70,6 +77,20 @@ extern "C" int hostsim_mpc_newton(int N, int nx, int nu, int nc, const double* Q
                                   const double* l, const double* v, const double* zb,
                                   const double* lb, const double* vb, double sigma,
                                   double alpha, double* out) {
+  return hostsim_mpc_newton_refined(N, nx, nu, nc, Q, R, S, q, r, A, B, c, E, L, d, x0, z, l, v, zb, lb, vb, sigma,
+                                    alpha, 0, out);
+}
+
+// The same with `refine_sweeps` refinement sweeps behind the step (MpcProblem::refine_step); out then has
+// two more entries behind rl: linear_residual2() before and after.
+extern "C" int hostsim_mpc_newton_refined(int N, int nx, int nu, int nc, const double* Q,
+                                          const double* R, const double* S, const double* q,
+                                          const double* r, const double* A, const double* B,
+                                          const double* c, const double* E, const double* L,
+                                          const double* d, const double* x0, const double* z,
+                                          const double* l, const double* v, const double* zb,
+                                          const double* lb, const double* vb, double sigma,
+                                          double alpha, int refine_sweeps, double* out) {
   MpcLayout lay;
   lay.init(N, nx, nu, nc, 1);
   std::vector<double> lds(lay.lds_doubles, 0.0), ws(lay.ws_doubles, 0.0);
@@ -86,6 +107,11 @@ extern "C" int hostsim_mpc_newton(int N, int nx, int nu, int nc, const double* Q
   for (int i = 0; i < lay.nv; i++) p.vb[i] = vb[i];
   p.residual(ctx);
   const bool ok = p.newton_step(ctx, sigma, alpha);
+  if (ok && refine_sweeps > 0) {
+    out[2 * lay.nz + 2 * lay.nl + 2 * lay.nv + lay.nz + lay.nl] = p.linear_residual2(ctx, sigma);
+    for (int k = 0; k < refine_sweeps; k++) p.refine_step(ctx, sigma);
+    out[2 * lay.nz + 2 * lay.nl + 2 * lay.nv + lay.nz + lay.nl + 1] = p.linear_residual2(ctx, sigma);
+  }
   double* o = out;
   auto put = [&](const double* s, int n) { std::memcpy(o, s, n * sizeof(double)); o += n; };
   put(p.dz, lay.nz); put(p.dl, lay.nl); put(p.dv, lay.nv); put(p.adz, lay.nv);

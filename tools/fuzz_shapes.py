@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Developer tool: random MPC shapes over every record instance (and the flat-vector
 kernel) against the oracle: exit flags, proximal counts equal; Newton counts equal on
-all but a few.  argv: number of shapes [seed]."""
+all but a few.  argv: number of shapes [seed] [r16].  With `r16` every shape is drawn inside the
+headline instance <12,4,20> (nx <= 12, nu <= 4, nc <= 20); a shape is flagged ("CHECK") as soon as ANY
+count differs from the oracle's (strict), otherwise when flags / proximal counts differ, a Newton
+count differs by more than two or the solutions part.  The last column counts the Newton steps the kernel
+refined (fbstab_hip_mpc_refined_steps)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,10 +14,16 @@ from tools import fixtures as fx
 from oracle.oracle_py import Oracle, default_options
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+r16 = len(sys.argv) > 3 and sys.argv[3] == "r16"
+strict = r16 or os.environ.get("FUZZ_STRICT", "1") != "0"
+nqp = nref = 0
 orc = Oracle(False)
 bad = 0
 for it in range(n):
-    nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
+    if r16:
+        nx = int(rng.integers(1, 13)); nu = int(rng.integers(1, 5)); nc = int(rng.integers(1, 21)); N = int(rng.integers(1, 33))
+    else:
+        nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
     B = int(rng.integers(1, 14))
     o = default_options()
     if rng.random() < 0.3:
@@ -26,19 +36,20 @@ for it in range(n):
     s.UpdateOptions(h)
     z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
     out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
-    kn = s.kernel_name(); s.close()
+    kn = s.kernel_name(); refined = s.refined_steps(); s.close()
+    nqp += B; nref += refined
     c = orc.solve_mpc(p, opts=o, nthreads=orc.num_threads())
     oc = c[4]
     dn = np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
     okf = np.array_equal(out["eflag"], oc["eflag"]) and np.array_equal(out["prox_iters"], oc["prox_iters"])
     good = oc["eflag"] == 0
     dz = float(np.abs(z - c[0])[good].max()) if good.any() else 0.0
-    flag = "" if (okf and dn.max() <= 2 and dz < 1e-4) else "  <-- CHECK"
+    flag = "" if (okf and dn.max() <= (0 if strict else 2) and dz < 1e-4) else "  <-- CHECK"
     bad += flag != ""
     if flag:
         print("   device: eflag", out["eflag"].tolist(), "prox", out["prox_iters"].tolist(), "newton", out["newton_iters"].tolist(),
               "residual", [f"{r:.2e}" for r in out["residual"]])
         print("   oracle: eflag", oc["eflag"].tolist(), "prox", oc["prox_iters"].tolist(), "newton", oc["newton_iters"].tolist(),
               "residual", [f"{r:.2e}" for r in oc["residual"]])
-    print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e}{flag}")
-print("shapes to check:", bad)
+    print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e} refined={refined}{flag}")
+print(f"shapes to check: {bad}   ({n} shapes, {nqp} QPs, {nref} refined Newton steps; strict={strict})")

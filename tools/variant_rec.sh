@@ -1,0 +1,20 @@
+#!/bin/bash
+# Developer tool: a variant of ONE record instance (default rec_12_4_20, the headline's) compiled with extra
+# flags and linked with the product build's other objects into tools/_build/<name>.so - a minute instead of
+# the three of a whole library; for same-box A/B runs (tools/ab_headline.sh).
+# usage: tools/variant_rec.sh <name> [-DFLAG ...]        (REC=rec_24_8_16 tools/variant_rec.sh ... for another instance)
+set -e
+cd "$(dirname "$0")/../fbstab_amd/csrc"
+name=$1; shift
+rec=${REC:-rec_12_4_20}
+out=../../tools/_build/$name
+mkdir -p $out
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function "$@" -c -o $out/$rec.o $rec.hip
+python3 ../../tools/check_dpp_hazards.py $out/$rec.o | tail -1
+objs=""
+for o in build/libfbstab_hip/*.o; do
+  b=$(basename $o)
+  if [ "$b" = "$rec.o" ]; then objs="$objs $out/$rec.o"; else objs="$objs $o"; fi
+done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/_build/$name.so $objs
+echo "built tools/_build/$name.so"
