@@ -469,25 +469,23 @@ struct Solver : TraceState<TRACE> {
     return Eo_top;
   }
 
-  // ---- when a Newton step is refined (policies with refine_step(): fb_mpc_r16.h, fb_mpc.h) -----------
-  // The z and l blocks of the inner residual are affine in x, so their share of the first trial's norm,
-  // sqrt(lin2), is what the LINEAR solve left of the Newton system - a quantity the reference's
-  // backward-stable substitutions keep near eps |dz| / sigma (riccati_linear_solver.cc:234-325) and the
-  // kernels' products with explicit inverses do not on ill-conditioned (wide) stages.  The rule is
-  // minimal on purpose: a step is refined when its leftover ALONE exceeds the tolerance the solver's next
-  // tests compare with - Ei <= inner_tol (impl:247) and Ek <= abs_tol + rel_tol (1 + |(f, h, b)|)
-  // (impl:158) -, i.e. when those tests could not pass however good the iterate is.  Below that the step is
-  // left as it is, bit for bit: its error is then of the size of the reference's own, and a step MORE
-  // accurate than the reference's parts from the reference just as a less accurate one does (measured:
-  // with the threshold at 1/16 of the tolerance the reference's servo-motor problem, whose second proximal
-  // iteration ends 11 % under the tolerance, finished one proximal iteration EARLIER than the oracle, whose
-  // own leftover takes it over the tolerance there; tests/test_hostsim.py).
-  // fbstab_options_t::reserved is a developer switch: 0 = the rule as stated, k > 0 = a threshold of
-  // 2^-k of the tolerance, < 0 = never.
+  // ---- iterative refinement of a Newton step: an OPTION, off by default -------------------------------
+  // (policies with refine_step(): fb_mpc_r16.h, fb_mpc.h).  The z and l blocks of the inner residual are
+  // affine in x, so their share of the first trial's norm, sqrt(lin2), is what the LINEAR solve left of
+  // the Newton system.  With fbstab_options_t::reserved = k > 0 a step whose leftover exceeds
+  // 2^(1 - k) of the tolerance the solver's next tests compare with - Ei <= inner_tol (impl:247),
+  // Ek <= abs_tol + rel_tol (1 + |(f, h, b)|) (impl:158) - is refined once with the same factors, which
+  // takes it to eps |V| |dx| in every block row: a solve MORE accurate than the reference's.
+  // It is not the default because parity is measured against the reference, whose own linear solve has an
+  // error: on the reference's servo-motor problem the second proximal iteration ends 11 % under the
+  // tolerance, the oracle's leftover (5e-6 at that step, like the kernels') takes it over and it runs a
+  // third; with the rule at k = 1 the kernels stop after two (tests/test_hostsim.py).  What closes the
+  // deviation round 4 found is structural instead: the kernels substitute with the Cholesky factors where
+  // that deviation came from (fb_row16.h subst_rows, fb_mpc.h solve_lower), as the reference does.
   FB_DEV bool wants_refinement(double lin2, double inner_tol, double combo_tol) const {
-    if (o.reserved < 0) return false;
+    if (o.reserved <= 0) return false;
     double tau = inner_tol < combo_tol ? inner_tol : combo_tol;
-    for (int k = 0; k < o.reserved && k < 60; k++) tau *= 0.5;
+    for (int k = 1; k < o.reserved && k < 60; k++) tau *= 0.5;
     return lin2 > tau * tau;
   }
 

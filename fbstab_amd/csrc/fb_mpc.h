@@ -17,10 +17,12 @@
 //     (full_feasibility.cc:25-88).
 //
 // Differences from the reference that change rounding but not mathematics:
-//   * triangular factors M, SG, L(i) are inverted explicitly once per stage
-//     (each column by an independent forward substitution) and then applied
-//     as matrix products, so that no stage needs more than the three Cholesky
-//     chains as sequential work;
+//   * L(i) is inverted explicitly once per stage (each column by an independent forward
+//     substitution) and applied as h = inv(L)'(inv(L) theta); M and SG are NOT (round 5): AM, SM, P and
+//     the vectors tx, tu, u, x come from substitutions with the factors themselves, as in the reference
+//     (riccati_linear_solver.cc:149-175, :241-249, :299-325) - products with explicitly inverted M, SG
+//     are forward stable only, and on stages wider than the inputs can reach (nx > N nu) they left
+//     4.6e-6 in the Newton system where the reference leaves 1e-7;
 //   * the forward vector recursion runs inside the factor sweep, and the
 //     backward sweep reuses tx = inv(M) h and tu = inv(SG)(SM tx + ru) from it
 //     (the reference recomputes them, riccati_linear_solver.cc:299-312);
@@ -370,6 +372,40 @@ struct MpcProblem {
     return kBothInfeasible;
   }
 
+  // ---- triangular solves with a lower factor Lo (n x n, column-major) ----------------------------
+  // X <- X inv(Lo)' for the m x n matrix X (Eigen: Lo.transpose().solveInPlace<OnTheRight>(X)): one row
+  // per thread, x[c] = (x[c] - sum_{k<c} x[k] Lo[c][k]) / Lo[c][c].  Caller syncs afterwards.
+  FB_DEV void solve_right_t(const C& c, mptr X, int m, mptr Lo, int n) const {
+    for (int r = c.tid; r < m; r += C::nt) {
+      for (int cc = 0; cc < n; cc++) {
+        double s = X[r + cc * m];
+        for (int k = 0; k < cc; k++) s -= X[r + k * m] * Lo[cc + k * n];
+        X[r + cc * m] = s / Lo[cc + cc * n];
+      }
+    }
+  }
+  // x <- inv(Lo) x (forward substitution, column-oriented: the entries below a solved one take its
+  // contribution side by side).  Synchronised on return.
+  FB_DEV void solve_lower(const C& c, mptr Lo, int n, mptr x) const {
+    for (int k = 0; k < n; k++) {
+      const double xk = x[k] / Lo[k + k * n];
+      c.sync();
+      if (c.tid == 0) x[k] = xk;
+      for (int r = k + 1 + c.tid; r < n; r += C::nt) x[r] -= Lo[r + k * n] * xk;
+      c.sync();
+    }
+  }
+  // x <- inv(Lo)' x (back substitution with the transpose).  Synchronised on return.
+  FB_DEV void solve_lower_t(const C& c, mptr Lo, int n, mptr x) const {
+    for (int k = n - 1; k >= 0; k--) {
+      const double xk = x[k] / Lo[k + k * n];
+      c.sync();
+      if (c.tid == 0) x[k] = xk;
+      for (int r = c.tid; r < k; r += C::nt) x[r] -= Lo[k + r * n] * xk;
+      c.sync();
+    }
+  }
+
   // ---- dense micro-kernels on LDS matrices (n <= 64 <= NT) -------------------
   // In-place lower Cholesky, one thread per row (left-looking: column j is
   // finished from the already final columns < j).  Workgroup-uniform result.
@@ -408,19 +444,19 @@ struct MpcProblem {
   // (stage N still resident in LDS): the step's z block to oz, its l block to ol.
   FB_DEV void backward_sweep(const C& c, double* oz, double* ol) const {
     const int N = lay.N, nx = lay.nx, nu = lay.nu, ns = lay.ns;
-    mptr Linv = lds + lay.w_linv; mptr Minv = lds + lay.w_minv;
-    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SGinv = lds + lay.w_sginv; mptr P = lds + lay.w_p;
+    mptr Linv = lds + lay.w_linv; mptr M = lds + lay.w_m;  // (M, SG: the Cholesky factors themselves)
+    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SG = lds + lay.w_sg; mptr P = lds + lay.w_p;
     mptr th = lds + lay.w_th; mptr tx = lds + lay.w_tx; mptr tu = lds + lay.w_tu;
     mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2; mptr lp = lds + lay.w_lp;
     for (int i = N; i >= 0; i--) {
       if (i < N) {
         const double* F = fac + (long)i * lay.f_stride;
-        copy_in(c, Minv, F + lay.f_minv, nx * nx);
+        copy_in(c, M, F + lay.f_minv, nx * nx);
         copy_in(c, Linv, F + lay.f_linv, nx * nx);
         copy_in(c, AM, F + lay.f_am, nx * nx);
         copy_in(c, SM, F + lay.f_sm, nu * nx);
         copy_in(c, P, F + lay.f_p, nu * nx);
-        copy_in(c, SGinv, F + lay.f_sginv, nu * nu);
+        copy_in(c, SG, F + lay.f_sginv, nu * nu);
         copy_in(c, tx, F + lay.f_tx, nx);
         copy_in(c, tu, F + lay.f_tu, nu);
         copy_in(c, th, F + lay.f_th, nx);
@@ -434,12 +470,9 @@ struct MpcProblem {
         t2[r] = s;
       }
       c.sync();
-      // u = inv(SG)' a
-      for (int r = c.tid; r < nu; r += C::nt) {
-        double s = 0.0;
-        for (int k = r; k < nu; k++) s += SGinv[k + r * nu] * t2[k];
-        t1[nx + r] = s;
-      }
+      // u = inv(SG)' a: back substitution (:307-309)
+      solve_lower_t(c, SG, nu, t2);
+      for (int r = c.tid; r < nu; r += C::nt) t1[nx + r] = t2[r];
       c.sync();
       // b = tx + SM' u + AM' l(i+1)
       for (int r = c.tid; r < nx; r += C::nt) {
@@ -450,12 +483,9 @@ struct MpcProblem {
         t2[r] = s;
       }
       c.sync();
-      // x = -inv(M)' b
-      for (int r = c.tid; r < nx; r += C::nt) {
-        double s = 0.0;
-        for (int k = r; k < nx; k++) s += Minv[k + r * nx] * t2[k];
-        t1[r] = -s;
-      }
+      // x = -inv(M)' b: back substitution (:315-320)
+      solve_lower_t(c, M, nx, t2);
+      for (int r = c.tid; r < nx; r += C::nt) t1[r] = -t2[r];
       c.sync();
       // w = inv(L)(theta + x);  l = -inv(L)' w
       for (int r = c.tid; r < nx; r += C::nt) {
@@ -533,20 +563,20 @@ struct MpcProblem {
   // (dz, dl) as before.
   FB_DEV void refine_step(const C& c, double sigma) const {
     const int N = lay.N, nx = lay.nx, nu = lay.nu, ns = lay.ns;
-    mptr Linv = lds + lay.w_linv; mptr Minv = lds + lay.w_minv;
-    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SGinv = lds + lay.w_sginv; mptr P = lds + lay.w_p;
+    mptr Linv = lds + lay.w_linv; mptr M = lds + lay.w_m;
+    mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SG = lds + lay.w_sg; mptr P = lds + lay.w_p;
     mptr r1 = lds + lay.w_r1;
     mptr th = lds + lay.w_th; mptr thp = lds + lay.w_thp; mptr hh = lds + lay.w_h;
     mptr tx = lds + lay.w_tx; mptr tu = lds + lay.w_tu;
-    mptr t1 = lds + lay.w_t1; mptr t2 = lds + lay.w_t2;
+    mptr t1 = lds + lay.w_t1;
     for (int r = c.tid; r < nx; r += C::nt) thp[r] = 0.0;
     c.sync();
     for (int i = 0; i <= N; i++) {
       double* F = fac + (long)i * lay.f_stride;
-      copy_in(c, Minv, F + lay.f_minv, nx * nx);
+      copy_in(c, M, F + lay.f_minv, nx * nx);
       copy_in(c, Linv, F + lay.f_linv, nx * nx);
       copy_in(c, SM, F + lay.f_sm, nu * nx);
-      copy_in(c, SGinv, F + lay.f_sginv, nu * nu);
+      copy_in(c, SG, F + lay.f_sginv, nu * nu);
       if (i < N) {
         copy_in(c, AM, F + lay.f_am, nx * nx);
         copy_in(c, P, F + lay.f_p, nu * nx);
@@ -572,26 +602,17 @@ struct MpcProblem {
         double s = -r1[r];
         for (int k = r; k < nx; k++) s += Linv[k + r * nx] * t1[k];
         hh[r] = s;
-      }
-      c.sync();
-      for (int r = c.tid; r < nx; r += C::nt) {  // tx = inv(M) h
-        double s = 0.0;
-        for (int k = 0; k <= r; k++) s += Minv[r + k * nx] * hh[k];
         tx[r] = s;
       }
       c.sync();
+      solve_lower(c, M, nx, tx);  // tx = inv(M) h
       for (int r = c.tid; r < nu; r += C::nt) {  // t2 = SM tx + ru
         double s = r1[nx + r];
         for (int k = 0; k < nx; k++) s += SM[r + k * nu] * tx[k];
-        t2[r] = s;
-      }
-      c.sync();
-      for (int r = c.tid; r < nu; r += C::nt) {  // tu = inv(SG) t2
-        double s = 0.0;
-        for (int k = 0; k <= r; k++) s += SGinv[r + k * nu] * t2[k];
         tu[r] = s;
       }
       c.sync();
+      solve_lower(c, SG, nu, tu);  // tu = inv(SG) t2
       for (int r = c.tid; r < nx; r += C::nt) {
         F[lay.f_tx + r] = tx[r];
         F[lay.f_th + r] = th[r];
@@ -624,9 +645,9 @@ struct MpcProblem {
     mptr tA = lds + lay.t_a; mptr tB = lds + lay.t_b; mptr tE = lds + lay.t_e;
     mptr tL = lds + lay.t_l;
     mptr Sb = lds + lay.w_sb; mptr Rb = lds + lay.w_rb;
-    mptr Linv = lds + lay.w_linv; mptr M = lds + lay.w_m; mptr Minv = lds + lay.w_minv;
+    mptr Linv = lds + lay.w_linv; mptr M = lds + lay.w_m;
     mptr AM = lds + lay.w_am; mptr SM = lds + lay.w_sm; mptr SG = lds + lay.w_sg;
-    mptr SGinv = lds + lay.w_sginv; mptr PP = lds + lay.w_pp; mptr P = lds + lay.w_p;
+    mptr PP = lds + lay.w_pp; mptr P = lds + lay.w_p;
     mptr Ln = lds + lay.w_ln;
     mptr Gam = lds + lay.w_gam; mptr Rvm = lds + lay.w_rvm;
     mptr r1 = lds + lay.w_r1; mptr r2 = lds + lay.w_r2;
@@ -710,7 +731,6 @@ struct MpcProblem {
       }
       c.sync();
       if (!chol(c, M, nx)) return false;
-      tri_inv(c, M, Minv, nx);
       // w = inv(L) theta  (first half of h = inv(L L') theta - rx, :233-236,:257-261)
       for (int r = c.tid; r < nx; r += C::nt) {
         double s = 0.0;
@@ -718,49 +738,40 @@ struct MpcProblem {
         t1[r] = s;
       }
       c.sync();
-      // AM = A inv(M)', SM = Sbar inv(M)' (:149-161); h = inv(L)' w - rx.
+      // AM = A inv(M)', SM = Sbar inv(M)' (:149-161) by substitution with M, a row per thread;
+      // h = inv(L)' w - rx.
       {
         const int na = (i < N) ? nx * nx : 0;
         for (int idx = c.tid; idx < na + nu * nx + nx; idx += C::nt) {
           if (idx < na) {
-            const int r = idx % nx, cc = idx / nx;
-            double s = 0.0;
-            for (int k = 0; k <= cc; k++) s += tA[r + k * nx] * Minv[cc + k * nx];
-            AM[idx] = s;
+            AM[idx] = tA[idx];
           } else if (idx < na + nu * nx) {
-            const int e = idx - na;
-            const int r = e % nu, cc = e / nu;
-            double s = 0.0;
-            for (int k = 0; k <= cc; k++) s += Sb[r + k * nu] * Minv[cc + k * nx];
-            SM[e] = s;
+            SM[idx - na] = Sb[idx - na];
           } else {
             const int r = idx - na - nu * nx;
             double s = -r1[r];
             for (int k = r; k < nx; k++) s += Linv[k + r * nx] * t1[k];
             hh[r] = s;
+            tx[r] = s;
           }
         }
       }
       c.sync();
-      // SG = chol(Rbar - SM SM') (:163-165); tx = inv(M) h (:241-243).
-      for (int idx = c.tid; idx < nu * nu + nx; idx += C::nt) {
-        if (idx < nu * nu) {
-          const int r = idx % nu, cc = idx / nu;
-          if (r >= cc) {
-            double s = Rb[idx];
-            for (int k = 0; k < nx; k++) s -= SM[r + k * nu] * SM[cc + k * nu];
-            SG[idx] = s;
-          }
-        } else {
-          const int r = idx - nu * nu;
-          double s = 0.0;
-          for (int k = 0; k <= r; k++) s += Minv[r + k * nx] * hh[k];
-          tx[r] = s;
+      if (i < N) solve_right_t(c, AM, nx, M, nx);
+      solve_right_t(c, SM, nu, M, nx);
+      // tx = inv(M) h (:241-243): forward substitution
+      solve_lower(c, M, nx, tx);
+      // SG = chol(Rbar - SM SM') (:163-165)
+      for (int idx = c.tid; idx < nu * nu; idx += C::nt) {
+        const int r = idx % nu, cc = idx / nu;
+        if (r >= cc) {
+          double s = Rb[idx];
+          for (int k = 0; k < nx; k++) s -= SM[r + k * nu] * SM[cc + k * nu];
+          SG[idx] = s;
         }
       }
       c.sync();
       if (!chol(c, SG, nu)) return false;
-      tri_inv(c, SG, SGinv, nu);
       // PP = AM SM' - B (:169-170); t2 = SM tx + ru (:247-248)
       {
         const int np = (i < N) ? nx * nu : 0;
@@ -779,27 +790,20 @@ struct MpcProblem {
         }
       }
       c.sync();
-      // P = PP inv(SG)' (:171-175); tu = inv(SG) t2 (:249)
+      // P = PP inv(SG)' (:171-175); tu = inv(SG) t2 (:249): substitutions with SG
       {
         const int np = (i < N) ? nx * nu : 0;
         for (int idx = c.tid; idx < np + nu; idx += C::nt) {
-          if (idx < np) {
-            const int r = idx % nx, cc = idx / nx;
-            double s = 0.0;
-            for (int k = 0; k <= cc; k++) s += PP[r + k * nx] * SGinv[cc + k * nu];
-            P[idx] = s;
-          } else {
-            const int r = idx - np;
-            double s = 0.0;
-            for (int k = 0; k <= r; k++) s += SGinv[r + k * nu] * t2[k];
-            tu[r] = s;
-          }
+          if (idx < np) P[idx] = PP[idx];
+          else tu[idx - np] = t2[idx - np];
         }
       }
       c.sync();
-      // Save what the backward sweep needs.
+      if (i < N) solve_right_t(c, P, nx, SG, nu);
+      solve_lower(c, SG, nu, tu);
+      // Save what the backward sweep needs: the factors M and SG themselves.
       for (int idx = c.tid; idx < nx * nx; idx += C::nt) {
-        F[lay.f_minv + idx] = Minv[idx];
+        F[lay.f_minv + idx] = M[idx];
         F[lay.f_linv + idx] = Linv[idx];
         if (i < N) F[lay.f_am + idx] = AM[idx];
       }
@@ -807,7 +811,7 @@ struct MpcProblem {
         F[lay.f_sm + idx] = SM[idx];
         if (i < N) F[lay.f_p + idx] = P[idx];
       }
-      for (int idx = c.tid; idx < nu * nu; idx += C::nt) F[lay.f_sginv + idx] = SGinv[idx];
+      for (int idx = c.tid; idx < nu * nu; idx += C::nt) F[lay.f_sginv + idx] = SG[idx];
       for (int r = c.tid; r < nx; r += C::nt) {
         F[lay.f_tx + r] = tx[r];
         F[lay.f_th + r] = th[r];

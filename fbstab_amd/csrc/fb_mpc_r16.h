@@ -171,6 +171,19 @@ struct MpcR16 {
   // five wait states follow (the compiler's hazard recognizer does not look inside the
   // block: a DPP instruction of its own must not sit in the shadow of the last v_cmpx).
   static constexpr bool kAsmImages = FB_R16_ASM_IMAGES && RQ == 1 && NS == 16 && NX == 12;
+  // The row-pair instances (stages up to 32 wide) SUBSTITUTE with Lc where the one-row instances multiply
+  // with its explicit inverse (fb_row16.h, subst_rows): the factor record then holds Lc itself - rows of
+  // the packed triangle, the diagonal as its reciprocal - and t = inv(Lc) g, s = t - inv(Lc) u and
+  // [dx; du] = inv(Lc)' s are the reference's three triangular solves (riccati_linear_solver.cc:241-249,
+  // :299-325 do them blockwise with M and SG).  On 16-wide stages the explicit inverse stays two orders
+  // under the tolerance (and is what the headline's time is made of); on stages wider than that, with
+  // nx > N nu, it left up to 4.6e-6 where the oracle leaves 1e-7 - the one deviation round 4's fuzz found
+  // (tests/test_gpu_components.py::test_one_step_qp_...).
+#ifndef FB_R16_SUBST
+#define FB_R16_SUBST 2  // substitute on the instances with at least this many rows per QP (1: all, 3: none)
+#endif
+  static constexpr bool kSubst = RQ >= FB_R16_SUBST;
+  static_assert(!(kSubst && kAsmImages), "the hand-written image blocks move the inverse's columns");
   static FB_DEV unsigned lds_addr(lds_ptr p) { return (unsigned)(unsigned long)p; }
 #define FB_IMG_WP(cc, off) "v_cmpx_le_i32_e32 vcc, " #cc ", %[ro]\n\tds_write_b64 %[rb], %[p" #cc "] offset:" #off "\n\t"
 #define FB_IMG_WX(j, off) "v_cmpx_ge_i32_e32 vcc, " #j ", %[ro]\n\tds_write_b64 %[rb], %[c" #j "] offset:" #off "\n\t"
@@ -2237,7 +2250,11 @@ struct MpcR16 {
       FB_STAMP_LAP(3);
       FB_SB();
       ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
-      tri_inv_cols_solve<NS, RQ>(K, XC, W, ro);
+      if constexpr (kSubst) {
+        tri_solve_right<NS, RQ>(K, W, ro);
+      } else {
+        tri_inv_cols_solve<NS, RQ>(K, XC, W, ro);
+      }
       FB_STAMP_LAP(4);
       FB_SB();
       // columns of inv(Lc) to the linear image of its lower triangle; rows (for t) and
@@ -2250,6 +2267,14 @@ struct MpcR16 {
         c.sync();
         sfor<0, NS>([&](auto J) { XR[decltype(J)::value] = 0.0; });
         img_read_xrow_slots(Tr + kXl + tri_r, Tr + kXl + ro, ro, XR, Xp);
+      } else if constexpr (kSubst) {
+        // rows of Lc itself (K[c] = L[r][c] for c < r, K[r] = 1 / L[r][r]) to the image of the triangle
+        sfor<0, NS>([&](auto Cc) {
+          constexpr int cc = decltype(Cc)::value;
+          Tr[(cc <= ro && ro < NS) ? kXl + tri_r + cc : kDump] = K[cc];
+        });
+        c.sync();
+        sfor<0, nXs>([&](auto S_) { Xp[decltype(S_)::value] = Tr[kXl + LPQ * decltype(S_)::value + r]; });
       } else {
       sfor<0, NS>([&](auto J) {
         constexpr int j = decltype(J)::value;
@@ -2266,7 +2291,9 @@ struct MpcR16 {
       if (LPQ * (nXs - 1) + r >= kXTri) Xp[nXs - 1] = 0.0;
       FB_SB();
       // t = inv(Lc) g
-      const double tvec = bc_dot<0, NS, RQ>(XR, gv);
+      double tvec;
+      if constexpr (kSubst) tvec = subst_rows<NS, RQ>(K, gv, ro);
+      else tvec = bc_dot<0, NS, RQ>(XR, gv);
       Xp[nXs] = tvec;
       stv<fX, nXs + 1>(R, Xp);
       FB_STAMP_LAP(5);
@@ -2420,12 +2447,20 @@ struct MpcR16 {
         sfor<0, NS>([&](auto J) { XR[decltype(J)::value] = 0.0; });
         img_read_xrow(Tr + kXl + tri_r, ro, XR);
       }
-      const double s = tcur - bc_dot<0, NS, RQ>(XR, u);
+      double s;  // (kSubst: XR, XC are row r and column r of Lc itself, the diagonal as its reciprocal)
+      if constexpr (kSubst) s = tcur - subst_rows<NS, RQ>(XR, u, ro);
+      else s = tcur - bc_dot<0, NS, RQ>(XR, u);
       if constexpr (kAsmImages) {
         sfor<0, NS>([&](auto J) { XC[decltype(J)::value] = 0.0; });
         img_read_xcol(Tr + kXl + ro, ro, XC);
       }
-      const double dzu = bc_dot<0, NS, RQ>(XC, s);
+      double dzu;
+      if constexpr (kSubst) {
+        dzu = subst_cols_t<NS, RQ>(XC, s, ro);
+        if (NS < LPQ && ro >= NS) dzu = 0.0;  // (lanes without a row: their image reads are not theirs)
+      } else {
+        dzu = bc_dot<0, NS, RQ>(XC, s);
+      }
       // dl = -inv(Pi)(theta + dx), form (a); form (b) follows A'dv below
       double dli = 0.0;
       if constexpr (!ROW) {

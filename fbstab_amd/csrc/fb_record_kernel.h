@@ -41,7 +41,8 @@ __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_op
     p.residual(ctx);
     double a, b, lin2;
     const bool ok = p.newton_step(ctx, opts.sigma0, opts.alpha, &a, &b, &lin2);
-    // the solver's own rule for refining a step (Solver::wants_refinement), no inner tolerance in play
+    // the solver's own rule for refining a step (Solver::wants_refinement: an option, off by default), no
+    // inner tolerance in play
     Solver<P, C> rule(p, ctx, opts);
     if (ok && rule.wants_refinement(lin2, opts.abs_tol, opts.abs_tol))
       p.refine_step(ctx, opts.sigma0, opts.alpha, &a, &b, &lin2);

@@ -440,6 +440,82 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
   });
 }
 
+// ---- substitution with the row-held factor (the reference's solveInPlace; round 5) ----------------------
+// The sweeps of the one-row instances multiply with an explicitly inverted Lc (tri_inv_cols): every
+// product is an independent stream of broadcast-FMAs, but the result is forward stable only - the
+// residual of Lc x = b grows with cond(Lc), where a substitution's stays at eps |Lc| |x| whatever the
+// conditioning (what RiccatiLinearSolver::Solve relies on, riccati_linear_solver.cc:234-325).  On the
+// 16-wide stages that difference stays two orders under the tolerance; on wide stages whose Pi_i keeps
+// eigenvalues of order sigma (nx > N nu) it reached 4.6e-6 and cost a QP an iteration.  The
+// row-pair instances therefore substitute: a chain of N dependent steps, each one multiply (the solved
+// entry), one broadcast-FMA into the entries still open.
+//
+// W <- W inv(Lc)' alone (tri_inv_cols_solve without the inverse): w[c] = B[r][c] on entry.
+template <int N, int R = 1>
+FB_DEV void tri_solve_right(const double (&a)[N], double (&w)[N], int r) {
+  (void)r;
+  double dg = bcr<R, 0>(a[0]);  // 1 / L[k][k], fetched one column ahead
+  sfor<0, N>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    if constexpr (k == 0) w[0] *= dg;
+    const double nw = -w[k];
+    if constexpr (k + 1 < N) dg = bcr<R, k + 1>(a[k + 1]);
+    const Spread<R> aks = spread<R>(a[k]);
+    FB_SB();
+    sfor<0, N - k - 1>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (kFmacDpp<R>) {
+        fmac_bcs<R, k + 1 + i, k + 1>(w[k + 1 + i], aks, nw);
+      } else {
+        w[k + 1 + i] = fma(bcs<R, k + 1 + i>(aks), nw, w[k + 1 + i]);
+      }
+      if constexpr (i == 0) {
+        w[k + 1] *= dg;  // final: columns < k + 1 are all folded in
+        FB_SB();
+      }
+    });
+  });
+}
+// x = inv(L) b for the factor of chol_rows held by ROWS (lane r: a[k] = L[r][k] for k < r, a[r] = 1 / L[r][r];
+// entries beyond the diagonal are ignored), b and x one entry per lane.  Column-oriented: once x_k is
+// final (lane k) it is folded into every later lane's sum.
+template <int N, int R = 1>
+FB_DEV double subst_rows(const double (&a)[N], double b, int r) {
+  double dinv = 0.0;
+  sfor<0, N>([&](auto J) { dinv = (r == decltype(J)::value) ? a[decltype(J)::value] : dinv; });
+  double acc = b;
+  sfor<0, N - 1>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    const double xk = acc * dinv;                 // lane k: x_k
+    const double m = (k < r) ? a[k] : 0.0;        // L[r][k] on the lanes below row k
+    if constexpr (kFmacDpp<R>) {
+      fmac_bcs<R, k, k, true, true, true>(acc, spread<R>(xk), m);
+    } else {
+      acc = fma(-m, bcr<R, k>(xk), acc);
+    }
+  });
+  return acc * dinv;
+}
+// x = inv(L)' b for the factor held by COLUMNS (lane r: a[j] = L[j][r] for j > r, a[r] = 1 / L[r][r];
+// entries before the diagonal are ignored): the same chain from the last row upwards.
+template <int N, int R = 1>
+FB_DEV double subst_cols_t(const double (&a)[N], double b, int r) {
+  double dinv = 0.0;
+  sfor<0, N>([&](auto J) { dinv = (r == decltype(J)::value) ? a[decltype(J)::value] : dinv; });
+  double acc = b;
+  sfor<0, N - 1>([&](auto KK) {
+    constexpr int k = N - 1 - decltype(KK)::value;
+    const double xk = acc * dinv;                 // lane k: x_k
+    const double m = (k > r) ? a[k] : 0.0;        // L[k][r] on the lanes above row k
+    if constexpr (kFmacDpp<R>) {
+      fmac_bcs<R, k, k, true, true, true>(acc, spread<R>(xk), m);
+    } else {
+      acc = fma(-m, bcr<R, k>(xk), acc);
+    }
+  });
+  return acc * dinv;
+}
+
 // acc = sum_c m[c] * (lane c's v), c in [B, E): four partial sums so that the
 // FMAs do not form one dependent chain.
 template <int B, int E, int R = 1, int N>

@@ -214,18 +214,16 @@ int fbstab_hip_mpc_query(fbstab_mpc_handle_t handle, long long* scratch_bytes,
  * "fbstab_mpc_kernel<64>" (any shape, one QP per wavefront). */
 const char* fbstab_hip_mpc_kernel_name(fbstab_mpc_handle_t handle);
 
-/* Newton steps of the most recent solve_batch / receding_sweep call on this handle that the kernel
- * REFINED (waits for that launch; -1 if there was none).  The reference solves the Newton system by
- * substitution with its Cholesky factors (RiccatiLinearSolver::Solve,
- * fbstab/components/riccati_linear_solver.cc:234-325: backward stable); the kernels multiply with
- * explicitly inverted factors, which on ill-conditioned (wide) stages can leave a residual of the
- * system orders above the reference's.  The kernels measure that residual with every step (it is the
- * z and l share of the first line-search trial's norm) and, where it ALONE exceeds the tolerance the
- * solver's next tests compare against - the step could not pass them however good the iterate -, solve
- * once more for the residual with the same factors and add the correction (one step of iterative
- * refinement: eps |V| |dx| in every block row afterwards).  Every other step is computed bit for bit as
- * without the mechanism - BASELINE configs[2]: 0 of 155,251 steps refined.
- * fbstab_options_t::reserved = -1 switches it off. */
+/* Iterative refinement of the Newton steps - an option, OFF by default (fbstab_options_t::reserved = 0).
+ * The kernels measure with every Newton step what the linear solve left of the Newton system (the z and l
+ * share of the first line-search trial's norm).  With reserved = k > 0 a step whose leftover exceeds
+ * 2^(1 - k) of the tolerance the solver's next tests compare against is solved once more for its
+ * residual with the same factors and corrected (eps |V| |dx| in every block row afterwards): a linear
+ * solve more accurate than RiccatiLinearSolver::Solve's (fbstab/components/riccati_linear_solver.cc:
+ * 212-344), hence not the default - iteration counts then part from the reference's where the reference's
+ * own rounding decides a stopping test.  This call returns the number of Newton steps of the most recent
+ * solve_batch / receding_sweep call that were refined (waits for that launch; -1 if there was none;
+ * 0 with the option off). */
 int fbstab_hip_mpc_refined_steps(fbstab_mpc_handle_t handle, long long* steps);
 
 /* Diagnostics used by the parity tests: runs ONE Newton step of the device path

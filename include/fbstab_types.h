@@ -100,9 +100,8 @@ typedef struct fbstab_options_t {
   int check_feasibility;       /* bool */
   int nonmonotone_linesearch;  /* bool */
   int display_level;           /* enum fbstab_display */
-  int reserved;                /* 0.  (Developer switch of the MPC kernels' refinement rule, fbstab_hip.h
-                                * fbstab_hip_mpc_refined_steps: k > 0 refines a Newton step whose linear residual
-                                * exceeds 2^-k of the tolerance in play instead of the tolerance, k < 0 never.) */
+  int reserved;                /* 0.  (k > 0: the MPC kernels refine a Newton step whose linear residual exceeds
+                                * 2^(1 - k) of the tolerance in play - fbstab_hip.h, fbstab_hip_mpc_refined_steps.) */
 } fbstab_options_t;
 
 /* AlgorithmParameters::DefaultParameters, fbstab_algorithm-impl.h:33-59. */

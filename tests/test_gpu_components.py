@@ -278,13 +278,12 @@ def test_one_step_qp_on_a_29_wide_stage_takes_the_oracles_counts(hip, oracle, mo
     """The deviation round 4 found and pinned (tools/fuzz_shapes.py seed 42, shape 128: N=3, nx=23, nu=6,
     nc=1, <24,8,16>), now closed: a QP with no active constraint converges in ONE Newton step to the
     accuracy of the linear solve; the oracle's step leaves 3.7e-7 - under abs_tol = 1e-6, done after one
-    proximal iteration - and the kernels', which multiply with explicitly inverted factors, left 4.6e-6
-    in the z block (forward stable, not backward stable: riccati_linear_solver.cc:234-325 substitutes) and
-    took one more iteration of each kind.  Both kernels now measure what the linear solve left over with
-    every step and refine a step whose leftover alone exceeds the tolerance in play
-    (Solver::wants_refinement): counts EQUAL to the oracle's on every QP, on the record kernel and on
-    the flat-vector kernel.  With the rule switched off (reserved = -1) the deviation is back - the
-    test then sees exactly what round 4 saw, which shows it is this mechanism that closes it."""
+    proximal iteration - and the kernels', which multiplied with explicitly inverted factors, left 4.6e-6
+    in the z block (forward stable, not backward stable) and took one more iteration of each kind.  The
+    row-pair record instances and the flat-vector kernel now SUBSTITUTE with the Cholesky factors, as
+    riccati_linear_solver.cc:234-325 does (fb_row16.h subst_rows / subst_cols_t, fb_mpc.h solve_lower):
+    counts EQUAL to the oracle's on every QP, on both kernels - and with the refinement option on top
+    (reserved = 1) as well."""
     monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kernel == "generic" else "0")
     p, o = H.fuzz_stream_shape(42, 127)
     N, nx, nu, nc = p.sizes()
@@ -292,8 +291,7 @@ def test_one_step_qp_on_a_29_wide_stage_takes_the_oracles_counts(hip, oracle, mo
     assert (N, nx, nu, nc, B) == (3, 23, 6, 1, 10)
     c = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
     oc = c[4]
-    res = {}
-    for reserved in (0, -1):
+    for reserved in (0, 1):
         s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
         assert s.kernel_name() == ("fbstab_mpc_r32_kernel<24,8,16>" if kernel == "record" else "fbstab_mpc_kernel<64>")
         h = _opts(hip, o)
@@ -301,20 +299,15 @@ def test_one_step_qp_on_a_29_wide_stage_takes_the_oracles_counts(hip, oracle, mo
         s.UpdateOptions(h)
         z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
         out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
-        res[reserved] = (out, z, s.refined_steps())
+        refined = s.refined_steps()
         s.close()
-    out, z, refined = res[0]
-    assert np.array_equal(out["eflag"], oc["eflag"]) and (out["eflag"] == 0).all()
-    assert np.array_equal(out["prox_iters"], oc["prox_iters"]), (out["prox_iters"], oc["prox_iters"])
-    assert np.array_equal(out["newton_iters"], oc["newton_iters"]), (out["newton_iters"], oc["newton_iters"])
-    assert (out["residual"] <= 1e-6).all()
-    scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
-    assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all()
-    assert 1 <= refined <= int(oc["newton_iters"].sum())  # the rule fired - and not on every step
-    out_off, _, refined_off = res[-1]
-    assert refined_off == 0
-    dp = out_off["prox_iters"].astype(int) - oc["prox_iters"].astype(int)
-    assert (dp >= 0).all() and dp.sum() >= 1, dp
+        assert np.array_equal(out["eflag"], oc["eflag"]) and (out["eflag"] == 0).all()
+        assert np.array_equal(out["prox_iters"], oc["prox_iters"]), (reserved, out["prox_iters"], oc["prox_iters"])
+        assert np.array_equal(out["newton_iters"], oc["newton_iters"]), (reserved, out["newton_iters"], oc["newton_iters"])
+        assert (out["residual"] <= 1e-6).all()
+        scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
+        assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all()
+        assert refined == 0 if reserved == 0 else refined >= 0
 
 
 @pytest.mark.parametrize("kernel", ["record", "generic"])
@@ -322,22 +315,21 @@ def test_one_step_qp_on_a_29_wide_stage_takes_the_oracles_counts(hip, oracle, mo
 def test_newton_system_residual_against_the_oracles_at_sigma_1e_8(hip, oracle, monkeypatch, kernel, case):
     """|V dx - r| of ONE Newton step at sigma = 1e-8 (cond(V) ~ 1e11), block row by block
     row, in extended precision, device against oracle - on the BASELINE shape (cold start and near the
-    solution; the record kernel's row form of the costate step; never refined: its leftover is 1e-12) and on
-    all ten QPs of the 29-wide shape of the fuzz stream's deviation, where the rule (Solver::wants_refinement:
-    a leftover above the tolerance) refines three.  Asserted for every QP probed:
-      * the 2-norm of the device's residual is not larger than the oracle's (record kernel) or of its class
-        (3 x; the flat-vector kernel takes the reference's form of every formula and leaves, like the oracle,
-        1e-8 in the z rows) - or under the rule's threshold abs_tol, below which a step is deliberately left
-        as it is (tests/test_hostsim.py: a step more accurate than the reference's also parts from it);
+    solution: the one-row record instance, explicit inverses, row form of the costate step) and on all ten
+    QPs of the 29-wide shape of the fuzz stream's deviation (row-pair instance: substitution).  Asserted for
+    every QP probed:
+      * the 2-norm of the device's residual is within 3 x the oracle's (same class; on the BASELINE shape the
+        record kernel's is in fact 10 to 4e4 times SMALLER);
       * every block row is within 10 x the oracle's SAME block row - or, where the formulations leave their
-        rounding error in different block rows, below a tenth of the larger of the oracle's whole residual
-        and abs_tol.  Where the second clause is needed, so that nobody has to find it: the row form
-        satisfies the z rows identically (3e-14 against the oracle's 5e-8 at the cold start) and carries
-        dz's forward error in the l rows (1e-12 against the oracle's 2e-15, whose substitutions put theirs
-        in the z rows): a residual 4e4 times SMALLER overall at the cold start and ten times smaller near
-        the solution, 600 to 4000 times the oracle's in that one block; and the reference form on the wide
-        shape leaves 1e-8 in the l rows (the product with the explicit inv(Pi)) where the oracle has 1e-14.
-        Closing those blocks too would take a refinement sweep on every step."""
+        rounding error in different block rows, below half the oracle's whole residual.  Where the second
+        clause is needed, so that nobody has to find it: the row form satisfies the z rows identically
+        (3e-14 against the oracle's 5e-8 at the cold start) and carries dz's forward error in the l rows
+        (1e-12 against the oracle's 2e-15, whose substitutions put theirs in the z rows); and the
+        reference's form of the costate step leaves 1e-8 in the l rows of the wide shape (the product with
+        the explicit inv(Pi), which the reference forms too but applies by substitution) where the oracle
+        has 1e-14 - each time a residual no larger overall, hundreds of times the oracle's in that block.
+    With the refinement option (reserved = 1 ... ) every block row goes to rounding level; that is a test of
+    its own below."""
     monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kernel == "generic" else "0")
     if case == "baseline":
         p, o = fx.synthetic_mpc_batch(4), default_options()
@@ -369,20 +361,41 @@ def test_newton_system_residual_against_the_oracles_at_sigma_1e_8(hip, oracle, m
         ostep = {"dz": dx[:p.nz], "dl": dx[p.nz:p.nz + p.nl], "dv": dx[p.nz + p.nl:p.nz + p.nl + p.nv]}
         eb, en = H.newton_system_residual(p, q, g, x, x, o.sigma0, o.alpha)
         ob, on = H.newton_system_residual(p, q, ostep, x, x, o.sigma0, o.alpha)
-        assert en <= max((1.0 if kernel == "record" else 3.0) * on, o.abs_tol), (case, kernel, q, eb, ob)
+        assert en <= 3.0 * on, (case, kernel, q, eb, ob)
         for k in range(3):
-            assert eb[k] <= max(10 * ob[k], 0.1 * max(on, o.abs_tol), 1e-15), (case, kernel, q, k, eb, ob)
+            assert eb[k] <= max(10 * ob[k], 0.5 * on, 1e-15), (case, kernel, q, k, eb, ob)
     s.close()
 
 
-def test_the_refinement_rule_leaves_the_baseline_workload_untouched(hip, oracle):
-    """"Typical QPs untouched => bitwise as today": on the BASELINE workload (cold start, default options) no
-    Newton step's linear residual comes near a tolerance (1e-12 against 1e-6) - fbstab_hip_mpc_refined_steps = 0 - and the
-    outputs with the rule in place are bit for bit those with it switched off (reserved = -1)."""
+@pytest.mark.parametrize("kernel", ["record", "generic"])
+def test_refinement_option_takes_every_block_row_to_rounding_level(hip, monkeypatch, kernel):
+    """The option (fbstab_options_t::reserved = k > 0; Solver::wants_refinement) on the Newton-step probe:
+    with a threshold of 2^-40 of abs_tol every step of the 29-wide shape is refined, and |V dx - r| ends at
+    rounding level in every block row on both kernels (1e-7 without)."""
+    monkeypatch.setenv("FBSTAB_HIP_GENERIC", "1" if kernel == "generic" else "0")
+    p, o = H.fuzz_stream_shape(42, 127)
+    N, nx, nu, nc = p.sizes()
+    s = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=1)
+    h = _opts(hip, o)
+    h.reserved = 41
+    s.UpdateOptions(h)
+    zero = lambda n: np.zeros(n)
+    for q in range(p.batch):
+        g = s.debug_newton({k: a[q] for k, a in p.arrays.items()}, zero(p.nz), zero(p.nl), zero(p.nv), zero(p.nz), zero(p.nl), zero(p.nv))
+        assert g["ok"]
+        eb, en = H.newton_system_residual(p, q, g, None, None, o.sigma0, o.alpha)
+        assert max(eb) <= 1e-12, (q, eb)
+    s.close()
+
+
+def test_the_refinement_option_leaves_the_baseline_workload_untouched(hip, oracle):
+    """On the BASELINE workload (cold start, default options) no Newton step's linear residual comes near a
+    tolerance (1e-12 against 1e-6): even with the option on (reserved = 1) fbstab_hip_mpc_refined_steps = 0,
+    and the outputs are bit for bit those with it off."""
     B = 512
     p = fx.synthetic_mpc_batch(B)
     res = []
-    for reserved in (0, -1):
+    for reserved in (1, 0):
         s = hip.FBstabMpcBatch(*p.sizes(), max_batch=B)
         h = _opts(hip, default_options())
         h.reserved = reserved

@@ -110,58 +110,59 @@ def _newton_system_residual(p, q, step):
     return H.newton_system_residual(p, q, step)[0]
 
 
-def test_refinement_sweep_of_the_flat_vector_kernel_reaches_rounding_level(hostsim):
-    """the kernels multiply with explicitly inverted triangular factors where the
-    reference substitutes (riccati_linear_solver.cc:234-325); on the 29-wide stage of the fuzz stream's
-    one deviation the step leaves |V dx - r| ~ 1e-6 in the z block.  One refinement sweep with the same
-    factors (MpcProblem::refine_step) takes every block to rounding level, and the measure the solver
-    decides by (linear_residual2) sees both."""
+def test_substitution_keeps_the_wide_stage_in_the_oracles_class_and_a_refinement_sweep_reaches_rounding(hostsim, oracle):
+    """VERDICT r4 item 1.  Up to round 4 the kernels multiplied with explicitly inverted triangular factors
+    where the reference substitutes (riccati_linear_solver.cc:234-325); on the 29-wide stage of the fuzz
+    stream's one deviation the step left |V dx - r| = 4.6e-6 in the z block against the oracle's 1e-7.  The
+    flat-vector logic now substitutes with M and SG (solve_lower, solve_right_t): every one of the ten QPs
+    is left within 3 x the oracle's residual.  The optional refinement sweep (MpcProblem::refine_step) takes
+    every block to rounding level, and the measure the option decides by (linear_residual2) sees both."""
     p = _fuzz42_shape128()
     zero = lambda n: np.zeros(n)
     x = (zero(p.nz), zero(p.nl), zero(p.nv))
-    worst0, worst1 = 0.0, 0.0
+    N, nx, nu, nc = p.sizes()
     for q in range(p.batch):
         s0 = hostsim.newton_mpc(p, q, x, x, 1e-8, 0.95, 0)
         s1 = hostsim.newton_mpc(p, q, x, x, 1e-8, 0.95, 1)
         assert s0["ok"] and s1["ok"]
-        e0, e1 = _newton_system_residual(p, q, s0), _newton_system_residual(p, q, s1)
-        worst0, worst1 = max(worst0, max(e0[:2])), max(worst1, max(e1[:2]))
+        one = fx.MpcProblem(N, nx, nu, nc, {k: np.ascontiguousarray(a[q:q + 1]) for k, a in p.arrays.items()})
+        pr = oracle.probe(one, *x, *x, 1e-8, 0.95)
+        pr = oracle.probe(one, *x, *x, 1e-8, 0.95, r=-pr["inner"], want_dx=True)
+        dx = pr["dx"]
+        ostep = {"dz": dx[:p.nz], "dl": dx[p.nz:p.nz + p.nl], "dv": dx[p.nz + p.nl:p.nz + p.nl + p.nv]}
+        (e0, n0), (e1, n1), (eo, no) = (H.newton_system_residual(p, q, s) for s in (s0, s1, ostep))
+        assert n0 <= 3 * no, (q, e0, eo)
         assert max(e1) <= 1e-12, (q, e0, e1)
         assert e1[2] <= 1e-14 and e0[2] <= 1e-14  # the third block row holds exactly either way
-        # what the solver measures is the z and l residual itself (to the rounding of its own evaluation)
+        # what the option measures is the z and l residual itself (to the rounding of its own evaluation)
         assert abs(np.sqrt(s1["lin2_before"]) - np.sqrt(sum(np.square(e0[:2])))) <= 3 * max(e0[:2])
         assert np.sqrt(s1["lin2_after"]) <= 1e-11  # (evaluated in working precision: cancellation of O(1) terms)
-    assert worst0 > 2e-7 and worst1 < 1e-12, (worst0, worst1)
 
 
-def test_the_one_step_qp_takes_the_oracles_counts_with_the_refinement_rule(hostsim, oracle):
-    """The same ten QPs through the whole flat-vector solve: with the rule (Solver::wants_refinement) the
-    counts are the oracle's on every QP; without it (reserved = -1) the QP whose one Newton step ends at
-    the accuracy of the linear solve takes one more iteration of each kind - the deviation as round 4
-    found it."""
+def test_the_one_step_qp_takes_the_oracles_counts(hostsim, oracle):
+    """The same ten QPs through the whole flat-vector solve: the counts are the oracle's on every QP (the QP
+    whose one Newton step ends at the accuracy of the linear solve took one more iteration of each kind as
+    long as the kernels multiplied with explicit inverses) - with the refinement option off and on."""
     p = _fuzz42_shape128()
-    o = default_options()
-    b = oracle.solve_mpc(p, opts=o)
-    a = hostsim.solve_mpc(p, opts=o)
-    assert np.array_equal(a[4]["eflag"], b[4]["eflag"]) and (a[4]["eflag"] == 0).all()
-    assert np.array_equal(a[4]["prox_iters"], b[4]["prox_iters"]), (a[4]["prox_iters"], b[4]["prox_iters"])
-    assert np.array_equal(a[4]["newton_iters"], b[4]["newton_iters"]), (a[4]["newton_iters"], b[4]["newton_iters"])
-    off = default_options()
-    off.reserved = -1
-    c = hostsim.solve_mpc(p, opts=off)
-    dp = c[4]["prox_iters"].astype(int) - b[4]["prox_iters"].astype(int)
-    assert (dp >= 0).all() and dp.sum() >= 1, dp
+    b = oracle.solve_mpc(p, opts=default_options())
+    for reserved in (0, 1):
+        o = default_options()
+        o.reserved = reserved
+        a = hostsim.solve_mpc(p, opts=o)
+        assert np.array_equal(a[4]["eflag"], b[4]["eflag"]) and (a[4]["eflag"] == 0).all()
+        assert np.array_equal(a[4]["prox_iters"], b[4]["prox_iters"]), (reserved, a[4]["prox_iters"], b[4]["prox_iters"])
+        assert np.array_equal(a[4]["newton_iters"], b[4]["newton_iters"]), (reserved, a[4]["newton_iters"], b[4]["newton_iters"])
 
 
-def test_the_refinement_rule_is_minimal_because_a_more_accurate_step_also_parts_from_the_reference(hostsim, oracle):
-    """Why the rule refines only a step whose leftover ALONE exceeds the tolerance (Solver::wants_refinement)
-    and not every step with a measurable leftover: the reference's own linear solve has an error, and its
-    iteration counts are what parity compares with.  On the reference's servo-motor problem
-    (ocp_generator.cc:113-200) the second proximal iteration ends at a residual 11 % UNDER abs_tol; the
-    oracle's own leftover takes its residual over the tolerance there and it runs a third iteration - and so
-    does the device logic with the rule as it is (3 / 29 on both).  With the threshold at 1/16 of the
-    tolerance (reserved = 4) the refined step is more accurate than the oracle's and the solve stops one
-    proximal iteration EARLIER: 2 / 28.  The other generator problems do not care."""
+def test_refinement_is_an_option_because_a_more_accurate_step_also_parts_from_the_reference(hostsim, oracle):
+    """Why iterative refinement is not the default (Solver::wants_refinement): the reference's own linear
+    solve has an error, and its iteration counts are what parity compares with.  On the reference's
+    servo-motor problem (ocp_generator.cc:113-200) the second proximal iteration ends at a residual 11 %
+    UNDER abs_tol; the oracle's leftover takes its residual over the tolerance there and it runs a third
+    iteration - and so does the device logic as it is (3 / 29 on both).  With the option at its mildest
+    (reserved = 1: refine only a step whose leftover alone exceeds the tolerance) the refined step is more
+    accurate than the oracle's and the solve stops one proximal iteration EARLIER: 2 / 28.  The other
+    generator problems do not care."""
     for name in ("DoubleIntegrator", "ServoMotor", "SpacecraftRelativeMotion", "CopolymerizationReactor"):
         gen = fx.OcpGenerator()
         getattr(gen, name)()
@@ -173,8 +174,8 @@ def test_the_refinement_rule_is_minimal_because_a_more_accurate_step_also_parts_
         assert np.array_equal(a[4]["newton_iters"], b[4]["newton_iters"]), (name, a[4]["newton_iters"], b[4]["newton_iters"])
         if name == "ServoMotor":
             o = default_options()
-            o.reserved = 4
+            o.reserved = 1
             c = hostsim.solve_mpc(p, opts=o)
             assert (b[4]["prox_iters"][0], b[4]["newton_iters"][0]) == (3, 29)
             assert (c[4]["prox_iters"][0], c[4]["newton_iters"][0]) == (2, 28)
-            assert c[4]["residual"][0] <= 1e-6 and c[4]["residual"][0] >= 0.8e-6
+            assert 0.8e-6 <= c[4]["residual"][0] <= 1e-6
