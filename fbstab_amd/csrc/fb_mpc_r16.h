@@ -11,7 +11,11 @@
 //
 //   * Stage record i of a QP = kSlots slots of 16 doubles, lane r of the row
 //     owning element r of every slot:
-//       iterate vectors  z rz zb lb dz wz l rl dl wl+ | v y | vb | yb | dv adz gam rvm
+//       iterate vectors  ez rz zb lb dz wz el rl dl wl+ | v y | vb | yb | dv adz gam rvm
+//                        (ez = z - zbar, el = l - lbar: the DISPLACEMENT from the proximal centre, which is
+//                        all the sweeps and the line search need of z and l - sigma (z - zbar) - so that the
+//                        (zbar lbar) pair stays out of the Newton step and the trial passes; z = zbar + ez
+//                        is formed by the passes of the proximal level)
 //       constants        f h b                        (mpc_data.cc:240-289)
 //       factor record    inv(Lc) (rows and columns folded into one triangle
 //                        pair), inv(Pi), t, theta
@@ -672,10 +676,11 @@ struct MpcR16 {
       lds_off = -1;
       // constants f, h, b (mpc_data.cc:240-289)
       st2(R, sF, sm.f, sm.h);
-      // the guess and y = b - A z
+      // the guess - as the proximal centre, with a zero displacement - and y = b - A z
       const double zz = sm.zz, ll = sm.ll;
-      st2(R, sZ, zz, 0.0);
-      st2(R, sL, ll, 0.0);
+      st2(R, sZ, 0.0, 0.0);
+      st2(R, sZB, zz, ll);
+      st2(R, sL, 0.0, 0.0);
       st2(R, sDZ, 0.0, 0.0);
       st2(R, sDL, 0.0, 0.0);
       double zb[NS];
@@ -737,15 +742,17 @@ struct MpcR16 {
       ldl<pC, NC>(Lp, Cc);
       ldl<pABr, NS>(Lp, ABr);
       ldv<pABc, NX>(P0 + pofs, ABc);
-      const double zz = ld(R, sZ), ll = ld(R, sL);
+      const dbl2 cb = ld2(R, sZB);
+      const double zz = cb[0] + ld(R, sZ), ll = cb[1] + ld(R, sL);
       const dbl2 fh = ld2(R, sF);
       double vs[KS];
       sfor<0, KS>([&](auto S_) { vs[decltype(S_)::value] = ld(R, sV + 2 * decltype(S_)::value); });
       double ln = 0.0, zn = 0.0;  // l(i+1), z(i+1)
       double hn = 0.0;
       if (i < N_) {
-        ln = ld(R + kRec, sL);
-        zn = ld(R + kRec, sZ);
+        const dbl2 cbn = ld2(R + kRec, sZB);
+        ln = cbn[1] + ld(R + kRec, sL);
+        zn = cbn[0] + ld(R + kRec, sZ);
         hn = ld(R + kRec, sH);
       }
       double zb[NS], lnb[NX];
@@ -793,13 +800,12 @@ struct MpcR16 {
   // The light passes below are bound by load latency, not arithmetic: each keeps
   // the loads of stage i+1 in flight while stage i is processed.
   struct TrialIn {
-    dbl2 zr, bb, dw, lr, dwl;
+    dbl2 zr, dw, lr, dwl;
     dbl2 vy[KS], da[KS];
     double vb[KS];
   };
   static FB_DEV void load_trial(const double* R, TrialIn& in) {
     in.zr = ld2(R, sZ);
-    in.bb = ld2(R, sZB);
     in.dw = ld2(R, sDZ);
     in.lr = ld2(R, sL);
     in.dwl = ld2(R, sDL);
@@ -839,9 +845,9 @@ struct MpcR16 {
       sfor<0, K>([&](auto Kk) {
         constexpr int k = decltype(Kk)::value;
         const double rzt = fma(tt[k], cu.dw[1], cu.zr[1]);
-        const double rzi = rzt + sigma * (fma(tt[k], cu.dw[0], cu.zr[0]) - cu.bb[0]);
+        const double rzi = rzt + sigma * fma(tt[k], cu.dw[0], cu.zr[0]);
         const double rlt = fma(tt[k], wl, cu.lr[1]);
-        const double rli = rlt + sigma * (fma(tt[k], cu.dwl[0], cu.lr[0]) - cu.bb[1]);
+        const double rli = rlt + sigma * fma(tt[k], cu.dwl[0], cu.lr[0]);
         s[k] = fma(rzi, rzi, s[k]);
         s[k] = fma(rli, rli, s[k]);
         s[K + k] = fma(rzt, rzt, s[K + k]);
@@ -945,9 +951,9 @@ struct MpcR16 {
       sfor<0, K>([&](auto Kk) {
         constexpr int k = decltype(Kk)::value;
         const double rzt = fma(tt[k], cu.dw[1], cu.zr[1]);
-        const double rzi = rzt + sigma * (fma(tt[k], cu.dw[0], cu.zr[0]) - cu.bb[0]);
+        const double rzi = rzt + sigma * fma(tt[k], cu.dw[0], cu.zr[0]);
         const double rlt = fma(tt[k], wl, cu.lr[1]);
-        const double rli = rlt + sigma * (fma(tt[k], cu.dwl[0], cu.lr[0]) - cu.bb[1]);
+        const double rli = rlt + sigma * fma(tt[k], cu.dwl[0], cu.lr[0]);
         double a = s[k], b = s[K + k];
         a = fma(rzi, rzi, a);
         a = fma(rli, rli, a);
@@ -1043,16 +1049,16 @@ struct MpcR16 {
   // (z, l) blocks of stage i with the step t applied.  Called for i = 0, 1, 2, ...:
   // wln carries WLN from one stage to the next.
   static FB_DEV ZL stepped_zl(const double* R, double t, int i, bool rx, double& wln) {
-    const dbl2 zr = ld2(R, sZ), bb = ld2(R, sZB), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
+    const dbl2 zr = ld2(R, sZ), dw = ld2(R, sDZ), lr = ld2(R, sL), dwl = ld2(R, sDL);
     const double wl = wl_of_stage(i, rx, dw[0], wln);
     wln = dwl[1];
-    ZL o;
+    ZL o;  // (z, l: the displacements ez, el - which ARE dx = x - xbar)
     o.z = fma(t, dw[0], zr[0]);
     o.rz = fma(t, dw[1], zr[1]);
     o.l = fma(t, dwl[0], lr[0]);
     o.rl = fma(t, wl, lr[1]);
-    o.dz = o.z - bb[0];
-    o.dl = o.l - bb[1];
+    o.dz = o.z;
+    o.dl = o.l;
     return o;
   }
   FB_DEV int close_subproblem(const C& c, double tol, bool check, double* dx_norm) {
@@ -1202,14 +1208,20 @@ struct MpcR16 {
       in.fh = ld2(R, sF);
       sfor<0, KS>([&](auto S_) { in.vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
       in.zn = in.ln = in.hn = 0.0;
-      if (i < N_) {
-        in.zn = ld(R + kRec, sZ);
-        in.ln = ld(R + kRec, sL);
+      if (i < N_) {  // (x = xbar + displacement)
+        const dbl2 cbn = ld2(R + kRec, sZB);
+        in.zn = cbn[0] + ld(R + kRec, sZ);
+        in.ln = cbn[1] + ld(R + kRec, sL);
         in.hn = ld(R + kRec, sH);
       }
       ldv<pABc, NX>(P0 + po[i], in.ABc);
     };
-    dbl2 zl = {ld(R0, sZ), ld(R0, sL)};  // (z, l) of stage i, handed on
+    dbl2 zl;  // (z, l) of stage i, handed on
+    {
+      const dbl2 cb0 = ld2(R0, sZB);
+      zl[0] = cb0[0] + ld(R0, sZ);
+      zl[1] = cb0[1] + ld(R0, sL);
+    }
     OIn oin;
     load_o(0, oin);
     for (int i = 0; i <= N_; i++) {
@@ -1228,7 +1240,8 @@ struct MpcR16 {
       const dbl2 zln = {oc.zn, oc.ln};
       const double hn = oc.hn;
       const double zz = zl[0], ll = zl[1];
-      st2(R, sZB, zz, ll);
+      st2(R, sZB, zz, ll);  // xbar <- x: the displacement starts again from zero
+      st(R, sL, 0.0);
       double zb[NS], lnb[NX];
       bc_all<NS, RQ>(zz, zb);
       bc_all<NX, RQ>(zln[1], lnb);
@@ -1243,7 +1256,7 @@ struct MpcR16 {
         }
         s = (p[0] + p[1]) + (p[2] + p[3]);
       }
-      st(R, sRZ, s);
+      st2(R, sZ, 0.0, s);
       s_nat = fma(s, s, s_nat);
       if (i == 0) {
         const double rl0 = rx ? fh[1] + zz : 0.0;
@@ -1358,10 +1371,13 @@ struct MpcR16 {
       const double* Rn = R + (ii < N_ ? kRec : 0);
       in.fh = ld2(R, sF);
       sfor<0, KS>([&](auto S_) { in.vy[decltype(S_)::value] = ld2(R, sV + 2 * decltype(S_)::value); });
-      in.zz = ld(R, sZ);
-      in.ll = ld(R, sL);
-      in.zn = ld(Rn, sZ);
-      in.ln = ld(Rn, sL);
+      // x = xbar + displacement, of this stage and the next (all of it read before the trip stores
+      // anything: the row that takes stage i + 1 in this very trip rewrites what zn, ln are read from)
+      const dbl2 cb = ld2(R, sZB), cbn = ld2(Rn, sZB);
+      in.zz = cb[0] + ld(R, sZ);
+      in.ll = cb[1] + ld(R, sL);
+      in.zn = cbn[0] + ld(Rn, sZ);
+      in.ln = cbn[1] + ld(Rn, sL);
       in.hn = ld(Rn, sH);
     };
     for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
@@ -1412,8 +1428,9 @@ struct MpcR16 {
         vi = fma(pf, pf, vi);
       });
       if (live) {
-        st2(R, sZB, zz, ll);
-        st(R, sRZ, s);
+        st2(R, sZB, zz, ll);  // xbar <- x: the displacement starts again from zero
+        st2(R, sZ, 0.0, s);
+        st(R, sL, 0.0);
         double nat = s * s;
         if (i == 0) {
           st(R, sRL, rl0);
@@ -1470,8 +1487,8 @@ struct MpcR16 {
     // anything: the row that takes stage i + 1 in this very trip rewrites what `nxt` is read
     // from.  (WLN, from which the stage above takes its wl a trip later, is left as it is.)
     struct In {
-      dbl2 zr, bb, dw, lr, dwl;       // stage i
-      dbl2 nzr, nbb, ndw, nlr, ndwl;  // stage i + 1
+      dbl2 zr, dw, lr, dwl;       // stage i
+      dbl2 nzr, ndw, nlr, ndwl;   // stage i + 1
       double wlp;                     // WLN(i - 1)
       dbl2 vy[KS], da[KS], fh;
       double vb[KS], bs[KS];
@@ -1480,8 +1497,8 @@ struct MpcR16 {
       const int ii = i <= N_ ? i : N_;
       const double* R = R0 + (long)ii * kRec;
       const double* Rn = R + (ii < N_ ? kRec : 0);
-      in.zr = ld2(R, sZ); in.bb = ld2(R, sZB); in.dw = ld2(R, sDZ); in.lr = ld2(R, sL); in.dwl = ld2(R, sDL);
-      in.nzr = ld2(Rn, sZ); in.nbb = ld2(Rn, sZB); in.ndw = ld2(Rn, sDZ); in.nlr = ld2(Rn, sL); in.ndwl = ld2(Rn, sDL);
+      in.zr = ld2(R, sZ); in.dw = ld2(R, sDZ); in.lr = ld2(R, sL); in.dwl = ld2(R, sDL);
+      in.nzr = ld2(Rn, sZ); in.ndw = ld2(Rn, sDZ); in.nlr = ld2(Rn, sL); in.ndwl = ld2(Rn, sDL);
       in.wlp = ld(R - (ii > 0 ? kRec : 0), sWLN);
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
@@ -1517,12 +1534,12 @@ struct MpcR16 {
         cur.rz = fma(t, cu.dw[1], cu.zr[1]);
         cur.l = fma(t, cu.dwl[0], cu.lr[0]);
         cur.rl = fma(t, wl, cu.lr[1]);
-        cur.dz = cur.z - cu.bb[0];
-        cur.dl = cur.l - cu.bb[1];
+        cur.dz = cur.z;  // (the displacements ez, el are x - xbar already)
+        cur.dl = cur.l;
       }
       ZL nxt;
-      nxt.dz = has_next ? fma(t, cu.ndw[0], cu.nzr[0]) - cu.nbb[0] : 0.0;
-      nxt.dl = has_next ? fma(t, cu.ndwl[0], cu.nlr[0]) - cu.nbb[1] : 0.0;
+      nxt.dz = has_next ? fma(t, cu.ndw[0], cu.nzr[0]) : 0.0;
+      nxt.dl = has_next ? fma(t, cu.ndwl[0], cu.nlr[0]) : 0.0;
       dbl2 vy[KS], da[KS];
       double vb[KS];
       sfor<0, KS>([&](auto S_) {
@@ -1785,8 +1802,9 @@ struct MpcR16 {
         }
         if (r == 0) lp[ii] = own_copy ? ii * kPack : -1;
         st2(R, sF, f, h);
-        st2(R, sZ, zz, 0.0);
-        st2(R, sL, ll, 0.0);
+        st2(R, sZ, 0.0, 0.0);
+        st2(R, sZB, zz, ll);
+        st2(R, sL, 0.0, 0.0);
         st2(R, sDZ, 0.0, 0.0);
         st2(R, sDL, 0.0, 0.0);
         sfor<0, KS>([&](auto S_) {
@@ -1866,8 +1884,13 @@ struct MpcR16 {
     for (int i = 0; i <= N_; i++) {
       FB_PHASE(write_top);
       const double* R = R0 + (long)i * kRec;
-      const double zz = ld(R, WHICH == 0 ? sZ : (WHICH == 1 ? sZB : sDZ));
-      const double ll = ld(R, WHICH == 0 ? sL : (WHICH == 1 ? sLB : sDL));
+      double zz = ld(R, WHICH == 0 ? sZ : (WHICH == 1 ? sZB : sDZ));
+      double ll = ld(R, WHICH == 0 ? sL : (WHICH == 1 ? sLB : sDL));
+      if constexpr (WHICH == 0) {  // x = xbar + displacement
+        const dbl2 cb = ld2(R, sZB);
+        zz = cb[0] + zz;
+        ll = cb[1] + ll;
+      }
       if (r < nx_) uz[(long)i * (nx_ + nu_) + r] = zz;
       else if (r >= NX && r - NX < nu_) uz[(long)i * (nx_ + nu_) + nx_ + (r - NX)] = zz;
       if (r < nx_) ul[(long)i * nx_ + r] = ll;
@@ -1910,7 +1933,12 @@ struct MpcR16 {
     for (int i = 0; i <= N_; i++) {
       double* R = R0 + (long)i * kRec;
       const long zi = z_index(i, r);
-      st2(R, sZB, zi >= 0 ? dbg[zi] : 0.0, r < nx_ ? dbg[nz + (long)i * nx_ + r] : 0.0);
+      // (load_guess left the guess as the centre, with a zero displacement: x stays, xbar moves)
+      const dbl2 x0 = ld2(R, sZB);
+      const double zbn = zi >= 0 ? dbg[zi] : 0.0, lbn = r < nx_ ? dbg[nz + (long)i * nx_ + r] : 0.0;
+      st2(R, sZB, zbn, lbn);
+      st(R, sZ, x0[0] - zbn);
+      st(R, sL, x0[1] - lbn);
       sfor<0, KS>([&](auto S_) {
         constexpr int sl = decltype(S_)::value;
         const int k = r + LPQ * sl;
@@ -1957,7 +1985,7 @@ struct MpcR16 {
   // fbstab_algorithm-impl.h:283-290).  Returns false on a non-positive pivot
   // (riccati_linear_solver.cc:131-136).
   struct FwdIn {
-    dbl2 zr, bb, dw, lr, dwl;
+    dbl2 zr, dw, lr, dwl;
     dbl2 vy[KS], da[KS];
     double vb[KS];
   };
@@ -1972,7 +2000,6 @@ struct MpcR16 {
     }
 #endif
     in.zr = ld2(R, sZ);
-    in.bb = ld2(R, sZB);
     in.dw = ld2(R, sDZ);
     in.lr = ld2(R, sL);
     in.dwl = ld2(R, sDL);
@@ -1985,7 +2012,7 @@ struct MpcR16 {
   }
   // What a backward stage reads of its own iterate vectors (fetched a stage ahead).
   struct BwdIn {
-    dbl2 zr, bb, lr;
+    dbl2 zr, lr;
     dbl2 vy[KS], gr[KS];
     double vb[KS];
     dbl2 dw, dwl, da[KS];  // (refinement sweep only) the step in the record: (dz wz) (dl wl+) (dv adz)
@@ -1993,7 +2020,6 @@ struct MpcR16 {
   template <bool REFINE = false>
   static FB_DEV void load_bwd(const double* R, BwdIn& in) {
     in.zr = ld2(R, sZ);
-    in.bb = ld2(R, sZB);
     in.lr = ld2(R, sL);
     sfor<0, KS>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
@@ -2162,13 +2188,13 @@ struct MpcR16 {
       if constexpr (!REFINE) {
         st2(R, sZ, zz, rzz);
         st2(R, sL, ll, rll);
-        r1 = -(rzz + sigma * (zz - cur.bb[0]));  // zero where there is no row
-        r2 = rll + sigma * (ll - cur.bb[1]);
+        r1 = -(rzz + sigma * zz);  // zero where there is no row (zz, ll: the displacements z - zbar, l - lbar)
+        r2 = rll + sigma * ll;
       } else {
         // r - V dx in the z and l block rows = minus the inner residual's affine blocks at x + dx, formed
         // the way the backward sweep's trial norms form them (the v block row holds exactly: no rv term)
-        r1 = -((rzz + cur.dw[1]) + sigma * ((zz + cur.dw[0]) - cur.bb[0]));
-        r2 = (rll + wlcur) + sigma * ((ll + cur.dwl[0]) - cur.bb[1]);
+        r1 = -((rzz + cur.dw[1]) + sigma * (zz + cur.dw[0]));
+        r2 = (rll + wlcur) + sigma * (ll + cur.dwl[0]);
       }
       FB_SB();
       // next stage's inputs, a whole stage ahead (the last stage fetches itself once
@@ -2372,8 +2398,7 @@ struct MpcR16 {
     // allocation of a kernel at 491 of 512 registers moves with any change of its source; gpurun_out/r05_c..f.)
     float s_lin = 0.f;
     auto lin_acc = [](double ri, float acc) { const float rf = (float)ri; return fmaf(rf, rf, acc); };
-    dbl2 lrn = {0.0, 0.0};  // (l, rl) and lb of block i+1, handed down by stage i+1
-    double lbn = 0.0;
+    dbl2 lrn = {0.0, 0.0};  // (el, rl) of block i+1, handed down by stage i+1
     double Ac[NX];
     double Xp[nXs + 1], Pp[nPs + 1];  // the packed factor record of the stage: triangle slots, then t / theta
     auto load_fac = [&](const double* R) {
@@ -2518,8 +2543,8 @@ struct MpcR16 {
         if constexpr (ROW) {
           // form (b): the state rows of (H + sigma I) dz + G'dl + A'dv = -(rz + sigma (z - zbar))
           // inner residual, z block - (REFINE) at x + dx: what is left of the row
-          double rin = cu.zr[1] + sigma * (cu.zr[0] - cu.bb[0]);
-          if constexpr (REFINE) rin = (cu.zr[1] + cu.dw[1]) + sigma * ((cu.zr[0] + cu.dw[0]) - cu.bb[0]);
+          double rin = cu.zr[1] + sigma * cu.zr[0];
+          if constexpr (REFINE) rin = (cu.zr[1] + cu.dw[1]) + sigma * (cu.zr[0] + cu.dw[0]);
           dli = rx ? (w + sigma * dzu) + rin : 0.0;
           w -= dli;
         }
@@ -2539,7 +2564,7 @@ struct MpcR16 {
         if constexpr (REFINE) wlv += cu.dwl[1];  // (dzn is the correction's: wl(i + 1) of the step + its increment)
         const double lr = lrn[1] + wlv;
         const double li = lrn[0] + (REFINE ? lpt : lp);
-        const double ri = lr + sigma * (li - lbn);
+        const double ri = lr + sigma * li;
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
         s_lin = lin_acc(ri, s_lin);
@@ -2548,7 +2573,7 @@ struct MpcR16 {
         st2(R, sDZ, dzt, wt);
         const double zrr = cu.zr[1] + wt;
         const double zi = cu.zr[0] + dzt;
-        const double ri = zrr + sigma * (zi - cu.bb[0]);
+        const double ri = zrr + sigma * zi;
         s_in = fma(ri, ri, s_in);
         s_out = fma(zrr, zrr, s_out);
         s_lin = lin_acc(ri, s_lin);
@@ -2559,7 +2584,7 @@ struct MpcR16 {
         const double wl0 = rx ? dzt : 0.0;
         const double lr = cu.lr[1] + wl0;
         const double li = cu.lr[0] + dlt;
-        const double ri = lr + sigma * (li - cu.bb[1]);
+        const double ri = lr + sigma * li;
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
         s_lin = lin_acc(ri, s_lin);
@@ -2568,7 +2593,6 @@ struct MpcR16 {
       if constexpr (REFINE) lpt = dlt;
       dzn = rx ? dzu : 0.0;
       lrn = cu.lr;
-      lbn = cu.bb[1];
       FB_STAMP_LAP(10);
       FB_PHASE(bwd_end);
     }
