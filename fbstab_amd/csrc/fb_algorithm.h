@@ -518,6 +518,9 @@ struct Solver : TraceState<TRACE> {
     const double sigma = o.sigma0;
     double combo_tol = 0.0, Ek = 0.0, E0 = 0.0, rk_last = 0.0, inner_tol = 0.0, dx_norm = 0.0;
     double Ei = 0.0, Eo = 0.0, Eo_top = 0.0, Ei0 = 0.0;
+    // (kCoop) squared norms of the z and l blocks of the inner and of the natural residual at x: the line
+    // search's A of P::trial_zl() - set by open_prox (x = xbar), advanced with every accepted step
+    [[maybe_unused]] double Azi = 0.0, Azo = 0.0;
     double merit[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int newton = 0, prox = 0, k = 0, inner_i = 0;
     [[maybe_unused]] bool fetch_now = true;  // (align_rows) the wavefront has just released its waiting rows
@@ -717,11 +720,12 @@ struct Solver : TraceState<TRACE> {
           }
           while (wo != 0ull) {
             const int owner = __builtin_ctzll(wo);
-            double ek, ei0;
-            p.open_prox_coop(owner, o.alpha, &ek, &ei0);
+            double ek, ei0, nat2;
+            p.open_prox_coop(owner, o.alpha, &ek, &ei0, &nat2);
             if (((threadIdx.x ^ owner) & 63 & ~(C::nt - 1)) == 0) {
               Ek = ek;
               Ei0 = ei0;
+              Azi = Azo = nat2;
               phase = kAfterOpen;
             }
             wo &= ~(kRowMask << (owner & ~(C::nt - 1)));
@@ -747,18 +751,25 @@ struct Solver : TraceState<TRACE> {
           sv[15] = __longlong_as_double((long long)(out - out_base));
           sv[16] = Ei;
           sv[17] = __hiloint2double(phase, 0);
+          sv[18] = Azi;
+          sv[19] = Azo;
         }
         bool searching = false, taken = false;
         double t = 1.0, cm = 0.0, m0 = 0.0, Et = 0.0, Eot = 0.0;
         int fails = 0;  // failed sufficient-decrease tests so far
+        // the step's sums of the z and l blocks (P::StepOut): S = the blocks' share of the t = 1 norms,
+        // B = sum b^2; with A (sv[18], sv[19]) they give the blocks' share at every other step length
+        double Szi = 0.0, Szo = 0.0, Bzi = 0.0, Bzo = 0.0;
         if (phase == kNewton) {
           double ti2, to2, lin2;
-          const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+          typename P::StepOut so;
+          const bool stepped = p.newton_step(c, sigma, o.alpha, &ti2, &to2, &lin2, &so);
           auto sv = qu.save_area();
           if (stepped && wants_refinement(lin2, sv[4], sv[0])) {
             qu.count_refinement();
-            p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+            p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2, &so);
           }
+          Szi = so.lin2; Szo = so.zo2; Bzi = so.bi2; Bzo = so.bo2;
           if (!stepped) {
             out = out_base + __double_as_longlong(sv[15]);
             p.flush(c);
@@ -791,8 +802,8 @@ struct Solver : TraceState<TRACE> {
           for (int m = 0; m < KT; m++) Em[m] = Eom[m] = 0.0;
           while (need != 0ull) {
             const int owner = __builtin_ctzll(need);
-            double Ec[KT], Eoc[KT];
-            p.template norms_at_multi_coop<KT>(owner, t, o.beta, sigma, o.alpha, Ec, Eoc);
+            double Ec[KT], Eoc[KT];  // the constraint blocks' share, squared (the pass reads nothing else)
+            p.template trial_v_coop<KT>(owner, t, o.beta, sigma, o.alpha, Ec, Eoc);
             const bool mine = ((threadIdx.x ^ owner) & 63 & ~(C::nt - 1)) == 0;
 #pragma unroll
             for (int m = 0; m < KT; m++) {
@@ -800,6 +811,16 @@ struct Solver : TraceState<TRACE> {
               Eom[m] = mine ? Eoc[m] : Eom[m];
             }
             need &= ~(((C::nt == 64) ? ~0ull : ((1ull << C::nt) - 1ull)) << (owner & ~(C::nt - 1)));
+          }
+          {  // ... plus the z and l blocks' share at t beta^m (P::trial_zl), and the root
+            auto sv = qu.save_area();
+            double tm = t;
+#pragma unroll
+            for (int m = 0; m < KT; m++) {
+              Em[m] = sqrt(Em[m] + P::trial_zl(sv[18], Szi, Bzi, tm));
+              Eom[m] = sqrt(Eom[m] + P::trial_zl(sv[19], Szo, Bzo, tm));
+              tm *= o.beta;
+            }
           }
 #pragma unroll
           for (int m = 0; m < KT; m++) {
@@ -829,9 +850,14 @@ struct Solver : TraceState<TRACE> {
           out = out_base + __double_as_longlong(sv[15]);
           Ei = sv[16];
           phase = __double2hiint(sv[17]);
+          Azi = sv[18];
+          Azo = sv[19];
           if (taken) {
             // merit FIFO (impl:276-278), the step and its norms
             merit[4] = sv[11]; merit[3] = sv[10]; merit[2] = sv[9]; merit[1] = sv[8]; merit[0] = cm;
+            // the z and l blocks' norms at the accepted point (t = 1: the sums themselves)
+            Azi = t == 1.0 ? Szi : P::trial_zl(Azi, Szi, Bzi, t);
+            Azo = t == 1.0 ? Szo : P::trial_zl(Azo, Szo, Bzo, t);
             p.pend_t = t;
             Ei = Et;
             Eo = Eot;

@@ -88,16 +88,16 @@ struct MpcR16 {
   static constexpr int sVB = sV + 2 * KS;             // KS slots vbar (every sweep reads them)
   static constexpr int sYB = sVB + ((KS + 1) & ~1);   // KS slots ybar (results only)
   static constexpr int sDV = sYB + ((KS + 1) & ~1);   // pairs (DV_s, ADZ_s)
-  // The barrier terms gamma = g0 / mu and rv / mu of the Newton system
-  // (riccati_linear_solver.cc:91-99) travel in the record from the forward to the
-  // backward sweep.  (Measured and dropped, build knob FB_R16_RECOMPUTE_GAMMA: the
-  // backward sweep forming them again from (v, y, vbar) saves 8 slots of traffic
-  // per stage and costs 90 instructions there - 6 % slower end to end.)
-#if defined(FB_R16_RECOMPUTE_GAMMA)
-  static constexpr bool kStoreGamma = false;
-#else
-  static constexpr bool kStoreGamma = true;
+  // The barrier terms gamma = g0 / mu and rv / mu of the Newton system (riccati_linear_solver.cc:91-99):
+  // on the row-pair instances they travel in the record from the forward to the backward sweep; the one-row
+  // instances form them AGAIN in the backward sweep from (v, y, vbar), which it reads anyway - 8 slots of
+  // traffic per stage less, 90 instructions more.  (Rounds 1-2 measured that at -6 %; with the fused
+  // broadcast-FMAs the kernel sits nearer its memory wall and it is +1.1 % pipelined, +1 % one launch at a
+  // time - gpurun_out/r05_j; same bits either way: the same function of the same stored values.)
+#ifndef FB_R16_RECOMPUTE_GAMMA
+#define FB_R16_RECOMPUTE_GAMMA 1  // 0: never; 1: on the one-row instances; 2: everywhere
 #endif
+  static constexpr bool kStoreGamma = !(FB_R16_RECOMPUTE_GAMMA == 2 || (FB_R16_RECOMPUTE_GAMMA == 1 && RQ == 1));
   static constexpr int sGAM = sDV + 2 * KS;  // (kStoreGamma) pairs (GAM_s, RVM_s)
   static constexpr int sF = sGAM + (kStoreGamma ? 2 * KS : 0), sH = sF + 1;
   static constexpr int sB = sH + 1;          // KS slots
@@ -896,10 +896,24 @@ struct MpcR16 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
                             __builtin_amdgcn_readlane(__double2loint(x), lane));
   }
+  // The constraint blocks' share of the trial norms: sum pfb(...)^2 and sum pnr(...)^2 over the stages,
+  // K step lengths per pass (the z and l blocks are affine in x: StepOut, trial_zl()).
   template <int K>
   struct TrialNorms {
-    double ei[K], eo[K];
+    double vi[K], vo[K];
   };
+  struct TrialInV {
+    dbl2 vy[KS], da[KS];
+    double vb[KS];
+  };
+  static FB_DEV void load_trial_v(const double* R, TrialInV& in) {
+    sfor<0, KS>([&](auto S_) {
+      constexpr int sl = decltype(S_)::value;
+      in.vy[sl] = ld2(R, sV + 2 * sl);
+      in.da[sl] = ld2(R, sDV + 2 * sl);
+    });
+    ldv<sVB, KS>(R, in.vb);
+  }
   // R0: the owner's record base with this lane's offset within ITS row (2 * r)
   template <int K>
 #ifndef FB_R16_COOP_INLINE
@@ -914,12 +928,11 @@ struct MpcR16 {
 #endif
     constexpr int QW = kQpPerWave;
     const int lane = threadIdx.x & 63;
-    const int q = lane / LPQ, r = lane & (LPQ - 1);
+    const int q = lane / LPQ;
     double tt[K], s[2 * K];
     tt[0] = t0;
     sfor<1, K>([&](auto Kk) { tt[decltype(Kk)::value] = tt[decltype(Kk)::value - 1] * beta; });
     sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
-    const bool rx = r < NX;
     auto stage_ptr = [&](int i) { return R0 + (long)(i < N_ ? i : N_) * kRec; };
     // (The slots of a trip are requested a trip ahead - this pass stores nothing.  At the top
     // of their own trip, FB_R16_TRIAL_AHEAD=0: 485 k against 533 k QP/s, gpurun_out/r03_ap;
@@ -928,51 +941,39 @@ struct MpcR16 {
 #ifndef FB_R16_TRIAL_AHEAD
 #define FB_R16_TRIAL_AHEAD 1
 #endif
-    TrialIn in;
-    double wln_in;  // WLN of the stage below (stage 0: unused)
-    if constexpr (FB_R16_TRIAL_AHEAD != 0) {
-      load_trial(stage_ptr(q), in);
-      wln_in = ld(stage_ptr(q > 0 ? q - 1 : 0), sWLN);
-    }
-    for (int i = q; i - q <= N_; i += QW) {  // (the same trip count in every row)
+    // TS stages per trip and row (stages i, i + QW, ...): the pass is bound by the latency of a trip's
+    // loads, not by their bytes - with the z and l slots gone a trip of one stage moves five slot pairs,
+    // so two stages per trip keep as many loads in flight as the pass had before and halve the trips.
+#ifndef FB_R16_TRIAL_STAGES
+#define FB_R16_TRIAL_STAGES 1  // (2: one launch at a time 2 % faster, eight in flight 0.7 % slower; 4: +3 % / -7 %; gpurun_out/r05_m)
+#endif
+    constexpr int TS = FB_R16_TRIAL_STAGES;
+    TrialInV in[TS];
+    if constexpr (FB_R16_TRIAL_AHEAD != 0)
+      sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(q + QW * decltype(J)::value), in[decltype(J)::value]); });
+    for (int i = q; i - q <= N_; i += TS * QW) {  // (the same trip count in every row)
       FB_PHASE(trip_top);
-      if constexpr (FB_R16_TRIAL_AHEAD == 0) {
-        load_trial(stage_ptr(i), in);
-        wln_in = ld(stage_ptr(i > 0 ? i - 1 : 0), sWLN);
-      }
-      const TrialIn cu = in;
-      const double wlp = wln_in;
-      if constexpr (FB_R16_TRIAL_AHEAD != 0) {
-        load_trial(stage_ptr(i + QW), in);
-        wln_in = ld(stage_ptr(i + QW - 1), sWLN);
-      }
-      const bool live = i <= N_;
-      const double wl = wl_of_stage(i, rx, cu.dw[0], wlp);
-      sfor<0, K>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        const double rzt = fma(tt[k], cu.dw[1], cu.zr[1]);
-        const double rzi = rzt + sigma * fma(tt[k], cu.dw[0], cu.zr[0]);
-        const double rlt = fma(tt[k], wl, cu.lr[1]);
-        const double rli = rlt + sigma * fma(tt[k], cu.dwl[0], cu.lr[0]);
-        double a = s[k], b = s[K + k];
-        a = fma(rzi, rzi, a);
-        a = fma(rli, rli, a);
-        b = fma(rzt, rzt, b);
-        b = fma(rlt, rlt, b);
-        s[k] = live ? a : s[k];
-        s[K + k] = live ? b : s[K + k];
-      });
-      sfor<0, KS>([&](auto S_) {
-        constexpr int sl = decltype(S_)::value;
-        sfor<0, K>([&](auto Kk) {
-          constexpr int k = decltype(Kk)::value;
-          const double vi = fma(tt[k], cu.da[sl][0], cu.vy[sl][0]);
-          const double yi = fma(-tt[k], cu.da[sl][1], cu.vy[sl][1]);
-          const double ys = yi + sigma * (vi - cu.vb[sl]);
-          const double ph = pfb(ys, vi, alpha);
-          const double pn = pnr(yi, vi, alpha);
-          s[k] = live ? fma(ph, ph, s[k]) : s[k];
-          s[K + k] = live ? fma(pn, pn, s[K + k]) : s[K + k];
+      if constexpr (FB_R16_TRIAL_AHEAD == 0)
+        sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * decltype(J)::value), in[decltype(J)::value]); });
+      TrialInV cu[TS];
+      sfor<0, TS>([&](auto J) { cu[decltype(J)::value] = in[decltype(J)::value]; });
+      if constexpr (FB_R16_TRIAL_AHEAD != 0)
+        sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * (TS + decltype(J)::value)), in[decltype(J)::value]); });
+      sfor<0, TS>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const bool live = i + QW * j <= N_;
+        sfor<0, KS>([&](auto S_) {
+          constexpr int sl = decltype(S_)::value;
+          sfor<0, K>([&](auto Kk) {
+            constexpr int k = decltype(Kk)::value;
+            const double vi = fma(tt[k], cu[j].da[sl][0], cu[j].vy[sl][0]);
+            const double yi = fma(-tt[k], cu[j].da[sl][1], cu[j].vy[sl][1]);
+            const double ys = yi + sigma * (vi - cu[j].vb[sl]);
+            const double ph = pfb(ys, vi, alpha);
+            const double pn = pnr(yi, vi, alpha);
+            s[k] = live ? fma(ph, ph, s[k]) : s[k];
+            s[K + k] = live ? fma(pn, pn, s[K + k]) : s[K + k];
+          });
         });
       });
       FB_PHASE(trip_end);
@@ -983,14 +984,23 @@ struct MpcR16 {
       const double rs = qp_reduce<RQ, OpSum16>(s[k]);  // the row's (row pair's) stages
       double tot = lane_value(rs, 0);
       sfor<1, QW>([&](auto Q_) { tot += lane_value(rs, LPQ * decltype(Q_)::value); });
-      if constexpr (k < K) out.ei[k] = sqrt(tot);
-      else out.eo[k - K] = sqrt(tot);
+      if constexpr (k < K) out.vi[k] = tot;
+      else out.vo[k - K] = tot;
     });
     return out;
   }
+  // The z and l blocks' share of the squared trial norms at x + t dx, from four sums of the Newton step.
+  // Both residuals are affine there: with a = the inner (natural) residual's z, l blocks at x and b its
+  // increment along dx (b = W + sigma dx for the inner one, b = W for the natural one),
+  //   sum (a + t b)^2 = A (1 - t) + t S + B (t^2 - t),   A = sum a^2, S = sum (a + b)^2, B = sum b^2,
+  // so a trial pass has nothing to read of z, l, their steps and residuals - 11 of the 21 slots per stage
+  // it used to move.  (Not used at t = 1, where S is the sum itself; for t <= beta the three terms cancel
+  // by a factor t / (1 - t) <= 3 at most.)
+  static FB_DEV double trial_zl(double A, double S, double B, double t) { return fma(B, t * t - t, fma(A, 1.0 - t, t * S)); }
+  // Vi, Vo: the squared norms' constraint-block shares for t0 beta^k, k < K, of the owner's QP
   template <int K>
-  FB_DEV void norms_at_multi_coop(int owner, double t0, double beta, double sigma, double alpha,
-                                  double (&Ei)[K], double (&Eo)[K]) const {
+  FB_DEV void trial_v_coop(int owner, double t0, double beta, double sigma, double alpha, double (&Vi)[K],
+                           double (&Vo)[K]) const {
     FB_WAVE_COUNT(24);
     FB_WAVE_TIMER(23);
     // (the owner's records were written by the owner's lanes: their stores are complete
@@ -1006,8 +1016,8 @@ struct MpcR16 {
     const TrialNorms<K> n = trial_pass_coop<K>(R0, __builtin_amdgcn_readlane(N, own0), lane_value(t0, own0), beta,
                                                sigma, alpha);
     sfor<0, K>([&](auto Kk) {
-      Ei[decltype(Kk)::value] = n.ei[decltype(Kk)::value];
-      Eo[decltype(Kk)::value] = n.eo[decltype(Kk)::value];
+      Vi[decltype(Kk)::value] = n.vi[decltype(Kk)::value];
+      Vo[decltype(Kk)::value] = n.vo[decltype(Kk)::value];
     });
   }
 
@@ -1457,7 +1467,9 @@ struct MpcR16 {
     return o;
   }
   // every lane of the wavefront calls this; every lane gets the owner's norms
-  FB_DEV void open_prox_coop(int owner, double alpha, double* Ek, double* Ei0) const {
+  // nat2: the squared norm of the natural residual's z and l blocks at x = xbar (where it is the inner
+  // residual's too): the line search's A of trial_zl() at the start of a subproblem
+  FB_DEV void open_prox_coop(int owner, double alpha, double* Ek, double* Ei0, double* nat2) const {
     FB_WAVE_COUNT(25);
     FB_WAVE_TIMER(22);
     pass_fence();
@@ -1466,6 +1478,7 @@ struct MpcR16 {
     pass_fence();
     *Ek = sqrt(o.nat + o.vo);
     *Ei0 = sqrt(o.nat + o.vi);
+    *nat2 = o.nat;
   }
 
   struct CloseSums {
@@ -2051,11 +2064,12 @@ struct MpcR16 {
   // what the linear solve left over.  It decides whether the step is refined (refine_step()).
   struct StepOut {
     double in2, out2, lin2;
+    double zo2, bi2, bo2;  // z, l share of out2; sum b^2 of the inner and of the natural residual (trial_zl)
     int loff;  // matrix copy left resident in LDS
     bool ok;
   };
   FB_DEV bool newton_step(const C& c, double sigma, double alpha, double* trial_inner2,
-                          double* trial_outer2, double* lin2 = nullptr) {
+                          double* trial_outer2, double* lin2 = nullptr, StepOut* sums = nullptr) {
     FB_WAVE_COUNT(27);  // Newton steps executed by the wavefront (any row active)
     FB_WAVE_TIMER(20);
     // (row-uniform; rows of a wavefront that disagree run one form after the other)
@@ -2068,6 +2082,7 @@ struct MpcR16 {
     *trial_inner2 = o.in2;
     *trial_outer2 = o.out2;
     if (lin2) *lin2 = o.lin2;
+    if (sums) *sums = o;
     return o.ok;
   }
   // ---- one refinement of the step in the record ---------------------------------
@@ -2108,7 +2123,7 @@ struct MpcR16 {
   }
   // No step may be pending (the Newton step that wrote the record has consumed it).
   FB_DEV bool refine_step(const C&, double sigma, double alpha, double* trial_inner2, double* trial_outer2,
-                          double* lin2) {
+                          double* lin2, StepOut* sums = nullptr) {
     StepOut o;
     if (rowdl) o = refine_row_form(rec, pack, lpo, lds, N, bounds, lds_off, sigma, alpha);
     else o = refine_ref_form(rec, pack, lpo, lds, N, bounds, lds_off, sigma, alpha);
@@ -2117,6 +2132,7 @@ struct MpcR16 {
     *trial_inner2 = o.in2;
     *trial_outer2 = o.out2;
     *lin2 = o.lin2;
+    if (sums) *sums = o;
     return true;
   }
 
@@ -2133,7 +2149,7 @@ struct MpcR16 {
     lds_ptr Cl = lds_row + kPackLds;
     const bool rx = r < NX;
     StepOut ret;
-    ret.in2 = ret.out2 = ret.lin2 = 0.0;
+    ret.in2 = ret.out2 = ret.lin2 = ret.zo2 = ret.bi2 = ret.bo2 = 0.0;
     ret.ok = false;
 
     double Pinv[NX];  // row r of inv(Pi_i); Pi_0 = sigma I (riccati_linear_solver.cc:127)
@@ -2391,13 +2407,20 @@ struct MpcR16 {
     double dzn = 0.0;   // dx(i+1), lanes < NX
     [[maybe_unused]] double lpt = 0.0;  // (REFINE) dl(i+1) of the refined step; lp and dzn are then the correction's
     double s_in = 0.0, s_out = 0.0;
-    // the z and l blocks' share of s_in (StepOut::lin2).  It feeds a threshold test only: summed in single
-    // precision, one 32-bit register held across the sweep.  (What it costs was measured - a double, a float
-    // and a sum kept in LDS with ds_add_f64 all put the headline 2 % under a build without it, and so does a
-    // build in which the optimiser removes the sum again because nobody reads it: not the sum, the register
-    // allocation of a kernel at 491 of 512 registers moves with any change of its source; gpurun_out/r05_c..f.)
-    float s_lin = 0.f;
-    auto lin_acc = [](double ri, float acc) { const float rf = (float)ri; return fmaf(rf, rf, acc); };
+    // The z and l blocks on their own: their share of s_in and s_out (sum (a + b)^2) and sum b^2 of both
+    // residuals - what the line search needs of them for every step length but the first (trial_zl()).
+    // (Measured when the first of them was added as a single-precision sum for the refinement option: a
+    // double, a float and a sum kept in LDS all put the headline 2 % under a build without it, and so did
+    // a build in which the optimiser removed the sum again - not the sum, the register allocation of a
+    // kernel at 491 of 512 registers moves with any change of its source; gpurun_out/r05_c..f.)
+    double s_zi = 0.0, s_zo = 0.0, s_bi = 0.0, s_bo = 0.0;
+    auto zl_acc = [&](double ri, double ro_, double bo, double dstep) {
+      const double bi = fma(sigma, dstep, bo);  // increment of the inner residual along the step
+      s_zi = fma(ri, ri, s_zi);
+      s_zo = fma(ro_, ro_, s_zo);
+      s_bi = fma(bi, bi, s_bi);
+      s_bo = fma(bo, bo, s_bo);
+    };
     dbl2 lrn = {0.0, 0.0};  // (el, rl) of block i+1, handed down by stage i+1
     double Ac[NX];
     double Xp[nXs + 1], Pp[nPs + 1];  // the packed factor record of the stage: triangle slots, then t / theta
@@ -2567,7 +2590,7 @@ struct MpcR16 {
         const double ri = lr + sigma * li;
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
-        s_lin = lin_acc(ri, s_lin);
+        zl_acc(ri, lr, wlv, REFINE ? lpt : lp);
       }
       {
         st2(R, sDZ, dzt, wt);
@@ -2576,7 +2599,7 @@ struct MpcR16 {
         const double ri = zrr + sigma * zi;
         s_in = fma(ri, ri, s_in);
         s_out = fma(zrr, zrr, s_out);
-        s_lin = lin_acc(ri, s_lin);
+        zl_acc(ri, zrr, wt, dzt);
       }
       st2(R, sDL, dlt, wlv);
       if (i == 0) {
@@ -2587,7 +2610,7 @@ struct MpcR16 {
         const double ri = lr + sigma * li;
         s_in = fma(ri, ri, s_in);
         s_out = fma(lr, lr, s_out);
-        s_lin = lin_acc(ri, s_lin);
+        zl_acc(ri, lr, wl0, dlt);
       }
       lp = dli;
       if constexpr (REFINE) lpt = dlt;
@@ -2599,7 +2622,10 @@ struct MpcR16 {
     ret.loff = loff;
     ret.in2 = qp_reduce<RQ, OpSum16>(s_in);
     ret.out2 = qp_reduce<RQ, OpSum16>(s_out);
-    ret.lin2 = qp_reduce<RQ, OpSum16>((double)s_lin);
+    ret.lin2 = qp_reduce<RQ, OpSum16>(s_zi);
+    ret.zo2 = qp_reduce<RQ, OpSum16>(s_zo);
+    ret.bi2 = qp_reduce<RQ, OpSum16>(s_bi);
+    ret.bo2 = qp_reduce<RQ, OpSum16>(s_bo);
     ret.ok = true;
     return ret;
   }
