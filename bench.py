@@ -194,8 +194,9 @@ def main():
     class Lane:
         """One pipeline lane: solver handle (own device scratch), stream, outputs."""
 
-        def __init__(self, p, gather):
-            self.solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=p.batch, device=local_rank)
+        def __init__(self, p, gather, lanes):
+            # (every lane's handle is told how many lanes share the device: fbstab_hip_mpc_create_in_flight)
+            self.solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=p.batch, device=local_rank, handles_in_flight=lanes)
             self.stream = torch.cuda.Stream(device=dev)
             nvar = p.nz + p.nl + 2 * p.nv
             # z, l, v, y and the SolverOut record (5 doubles) of a QP side by side: the
@@ -215,7 +216,7 @@ def main():
 
     def run_mpc(p, data, P, steps, warmup, gather):
         """`steps` timed solves of the batch `p`, P in flight.  Returns a dict."""
-        lanes = [Lane(p, gather) for _ in range(P)]
+        lanes = [Lane(p, gather, P) for _ in range(P)]
 
         def step(k, timed):
             ln = lanes[k % P]

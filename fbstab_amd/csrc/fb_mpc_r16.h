@@ -1998,19 +1998,21 @@ struct MpcR16 {
   // fbstab_algorithm-impl.h:283-290).  Returns false on a non-positive pivot
   // (riccati_linear_solver.cc:131-136).
   struct FwdIn {
+#if defined(FB_R16_EXTRA_READS)
+    dbl2 junk[3];
+#endif
     dbl2 zr, dw, lr, dwl;
     dbl2 vy[KS], da[KS];
     double vb[KS];
   };
   static FB_DEV void load_fwd(const double* R, FwdIn& in) {
 #if defined(FB_R16_EXTRA_READS)
-    {  // (experiment: up to three more slot pairs per stage and forward sweep - pairs no sweep touches:
-       //  ybar, (f h), b - read and thrown away: what a per cent of record traffic costs)
-      const dbl2 j0 = ld2(R, sYB);
-      asm volatile("" ::"v"(j0));
-      if constexpr (FB_R16_EXTRA_READS > 1) { const dbl2 j1 = ld2(R, sF); asm volatile("" ::"v"(j1)); }
-      if constexpr (FB_R16_EXTRA_READS > 2) { const dbl2 j2 = ld2(R, sB); asm volatile("" ::"v"(j2)); }
-    }
+    // (experiment: up to three more slot pairs per stage and forward sweep - pairs no sweep touches: ybar,
+    //  (f h), b - requested with the stage's own and thrown away where the stage's own are used, a stage
+    //  later: what a per cent of record READS costs)
+    in.junk[0] = ld2(R, sYB);
+    if constexpr (FB_R16_EXTRA_READS > 1) in.junk[1] = ld2(R, sF);
+    if constexpr (FB_R16_EXTRA_READS > 2) in.junk[2] = ld2(R, sB);
 #endif
     in.zr = ld2(R, sZ);
     in.dw = ld2(R, sDZ);
@@ -2193,6 +2195,11 @@ struct MpcR16 {
           if constexpr (kStoreGamma) st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
         }
       });
+#if defined(FB_R16_EXTRA_READS)
+      asm volatile("" ::"v"(cur.junk[0]));
+      if constexpr (FB_R16_EXTRA_READS > 1) asm volatile("" ::"v"(cur.junk[1]));
+      if constexpr (FB_R16_EXTRA_READS > 2) asm volatile("" ::"v"(cur.junk[2]));
+#endif
       // pending step on (z, rz), (l, rl); eliminated right-hand side (:222-225)
       const double zz = fma(tp, cur.dw[0], cur.zr[0]);
       const double rzz = fma(tp, cur.dw[1], cur.zr[1]);
@@ -2228,7 +2235,11 @@ struct MpcR16 {
       FB_PHASE(krhs_end);
       if (bnd) {
         FB_PHASE(k_bounds);
-        // one nonzero per constraint row: only the diagonal entry K[r][r] changes
+        // one nonzero per constraint row: only the diagonal entry K[r][r] changes.  (Round 5 measured the
+        // term kept beside the row and joined to the pivot inside chol_rows - no select of the diagonal out
+        // of and back into the row's registers, 80 instructions fewer: +0.8 % pipelined, -3.5 % one launch
+        // at a time, and the spacecraft problem's counts part from the oracle's: K_rr + barrier - sum L^2
+        // is not (K_rr - sum L^2) + barrier in the last bit.  Dropped; gpurun_out/r05_r.)
         double s = 0.0;
         sfor<0, NS>([&](auto Cc) { s = (ro == decltype(Cc)::value) ? K[decltype(Cc)::value] : s; });
         sfor<0, NC>([&](auto Kk) {
@@ -2338,6 +2349,13 @@ struct MpcR16 {
       else tvec = bc_dot<0, NS, RQ>(XR, gv);
       Xp[nXs] = tvec;
       stv<fX, nXs + 1>(R, Xp);
+#if defined(FB_R16_EXTRA_WRITES)
+      if constexpr (ROW) {  // (experiment: what a slot pair WRITTEN per stage costs - the row form leaves the
+                            //  inv(Pi) slots of the record unused)
+        st2(R, fP, Xp[0], Xp[1]);
+        if constexpr (FB_R16_EXTRA_WRITES > 1) st2(R, fP + 2, Xp[2], Xp[3]);
+      }
+#endif
       FB_STAMP_LAP(5);
       FB_SB();
       // theta(i+1) partial = -W t.  (Outside the branch below on purpose: with W used

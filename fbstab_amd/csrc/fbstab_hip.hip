@@ -586,7 +586,13 @@ int fbstab_hip_device_count(void) {
 // ---------------------------------------------------------------------------
 int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int device,
                           fbstab_mpc_handle_t* handle) {
+  return fbstab_hip_mpc_create_in_flight(N, nx, nu, nc, max_batch, device, 1, handle);
+}
+
+int fbstab_hip_mpc_create_in_flight(int N, int nx, int nu, int nc, int max_batch, int device, int handles_in_flight,
+                                    fbstab_mpc_handle_t* handle) {
   if (!handle) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null handle pointer");
+  if (handles_in_flight < 1) return fail(FBSTAB_HIP_ERR_ARGUMENT, "handles_in_flight must be positive");
   *handle = nullptr;
   // fbstab_mpc.cc:62-65
   if (N < 1 || nx < 1 || nu < 1 || nc < 1)
@@ -647,6 +653,9 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
   cus = prop.multiProcessorCount;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
+  // a handle that shares the device with others takes its share of the resident workgroups (and of the
+  // scratch memory that goes with them), at least one per CU: the launches of the other handles fill the rest
+  per_cu = (per_cu + handles_in_flight - 1) / handles_in_flight;
   const char* env = getenv("FBSTAB_HIP_WGS_PER_CU");
   if (env && atoi(env) > 0) per_cu = atoi(env);
   s->workgroups = cus * per_cu;

@@ -160,6 +160,8 @@ def load_library() -> C.CDLL:
     lib.fbstab_hip_mpc_receding_sweep_sharded.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                           C.c_void_p, C.c_void_p]
     lib.fbstab_hip_mpc_create.argtypes = [C.c_int] * 6 + [C.c_void_p]
+    if hasattr(lib, "fbstab_hip_mpc_create_in_flight"):  # (absent from a build of an earlier round loaded for an A/B)
+        lib.fbstab_hip_mpc_create_in_flight.argtypes = [C.c_int] * 7 + [C.c_void_p]
     lib.fbstab_hip_dense_create.argtypes = [C.c_int] * 5 + [C.c_void_p]
     lib.fbstab_hip_dense_set_factorisation.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fbstab_hip_dense_get_factorisation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -173,7 +175,7 @@ EXPORTED_SYMBOLS = (
     "fbstab_hip_mpc_get_options", "fbstab_hip_mpc_solve_batch", "fbstab_hip_mpc_solve_batch_final",
     "fbstab_hip_mpc_solve_traced", "fbstab_hip_mpc_receding_sweep",
     "fbstab_hip_mpc_last_kernel_ms", "fbstab_hip_mpc_query", "fbstab_hip_mpc_kernel_name",
-    "fbstab_hip_mpc_refined_steps",
+    "fbstab_hip_mpc_refined_steps", "fbstab_hip_mpc_create_in_flight",
     "fbstab_hip_mpc_debug_newton", "fbstab_hip_debug_stamps",
     "fbstab_hip_dense_create", "fbstab_hip_dense_destroy", "fbstab_hip_dense_set_options",
     "fbstab_hip_dense_get_options", "fbstab_hip_dense_solve_batch", "fbstab_hip_dense_solve_batch_final",
@@ -358,10 +360,15 @@ class FBstabMpcBatch(_SolverBase):
     _kind = "mpc"
 
     def __init__(self, N: int, nx: int, nu: int, nc: int, max_batch: int = 1,
-                 device: int = 0):
+                 device: int = 0, handles_in_flight: int = 1):
+        """handles_in_flight: how many such solvers the caller keeps busy on the device at the same time
+        (fbstab_hip_mpc_create_in_flight: each then takes its share of the resident workgroups)."""
         super().__init__()
-        _check(self._lib, self._lib.fbstab_hip_mpc_create(
-            N, nx, nu, nc, max_batch, device, C.byref(self._h)))
+        if hasattr(self._lib, "fbstab_hip_mpc_create_in_flight"):
+            _check(self._lib, self._lib.fbstab_hip_mpc_create_in_flight(
+                N, nx, nu, nc, max_batch, device, handles_in_flight, C.byref(self._h)))
+        else:  # (a build of an earlier round, loaded for an A/B)
+            _check(self._lib, self._lib.fbstab_hip_mpc_create(N, nx, nu, nc, max_batch, device, C.byref(self._h)))
         self.N, self.nx, self.nu, self.nc = N, nx, nu, nc
         self.nz, self.nl, self.nv = (N + 1) * (nx + nu), (N + 1) * nx, (N + 1) * nc
         self.seq_len = [(N + 1) * nx * nx, (N + 1) * nu * nu, (N + 1) * nu * nx,
