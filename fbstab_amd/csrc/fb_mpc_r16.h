@@ -150,10 +150,16 @@ struct MpcR16 {
   static constexpr int TS = (kDump + 16 + LPQ - 1) / LPQ;  // LPQ * TS doubles hold them
   static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
   static constexpr bool kPackInLds = true;
-  static constexpr int kPackLds = kPackInLds ? LPQ * kPackLdsSlots : 0;
+  static constexpr int kPackLds = kPackInLds ? LPQ * kPackLdsSlots : 0;  // doubles of one QP's image
+  // The images of a wavefront's QPs share ONE area in front of the QPs' own regions, interleaved pair by
+  // pair: pair p of QP q at p * kPackPair + q * 2 LPQ, lane r at + 2 r.  A slot pair of all the wavefront's
+  // lanes is then 1 KiB of consecutive LDS in lane order - what an LDS-DMA load writes
+  // (global_load_lds_dwordx4: wave-uniform base + lane x 16 bytes; stage_pack_dma below).
+  static constexpr int kPackPair = 2 * LPQ * kQpPerWave;  // doubles between consecutive slot pairs of a QP's image
+  static constexpr int kPackArea = kQpPerWave * kPackLds;  // doubles of the wavefront's area
   // this lane's view of the matrix copy in use
   typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
-  static constexpr int kLdsDoubles = kPackLds + LPQ * (CS > TS ? CS : TS);
+  static constexpr int kLdsDoubles = LPQ * (CS > TS ? CS : TS);  // a QP's own region: transpose buffer / triangle images
   // region stride: 16 doubles mod 32 (bank placement of neighbouring QPs) and at least
   // 24 spare doubles behind the images for the solver loop's parked scalars
   static constexpr int kLdsBase = ((kLdsDoubles + 31) & ~31) + 16;
@@ -359,7 +365,8 @@ struct MpcR16 {
   // serve.
   bool rowdl = false;
   float cmax2 = 0.f, hmax = 0.f;  // max_r sum_k C[k][r]^2 and max_r sum_c |H[r][c]| over the stages (load_guess)
-  lds_ptr lds;
+  lds_ptr lds;  // this QP's own LDS region (transpose buffer / triangle images, parked scalars)
+  lds_ptr lpk;  // this QP's image in the wavefront's matrix-copy area (its lanes' offsets not included)
   const MpcBatchPtrs* data;  // kernel arguments (uniform)
   const VarBatchPtrs* var;
   long q;  // QP index
@@ -378,8 +385,9 @@ struct MpcR16 {
   // next forward sweep applies it stage by stage, everything else flushes first.
   double pend_t;
 
-  FB_DEV void bind(double* ws_row, lds_ptr lds_row, lds_iptr lpo_row, const MpcBatchPtrs* d,
+  FB_DEV void bind(double* ws_row, lds_ptr lds_row, lds_ptr lpk_row, lds_iptr lpo_row, const MpcBatchPtrs* d,
                    const VarBatchPtrs* x, long q_, int N_, int lane) {
+    lpk = lpk_row;
     lds_off = -1;
     poff = reinterpret_cast<int*>(ws_row);
     lpo = lpo_row;
@@ -395,7 +403,8 @@ struct MpcR16 {
   // A row that never gets a QP (batch < row slots of the grid) still takes part in the
   // cooperative passes of its wavefront - with its own LDS region as scratch
   // (close_subproblem_coop) - so what those read is set before the first fetch.
-  FB_DEV void bind_idle(lds_ptr lds_row, lds_iptr lpo_row, int N_) {
+  FB_DEV void bind_idle(lds_ptr lds_row, lds_ptr lpk_row, lds_iptr lpo_row, int N_) {
+    lpk = lpk_row;
     lds_off = -1;
     poff = nullptr;
     lpo = lpo_row;
@@ -444,7 +453,7 @@ struct MpcR16 {
   // Makes the matrix copy at offset `off` the one resident in LDS (row-uniform).
   template <bool L = kPackInLds>
   FB_DEV auto pack_view(const C& c) const {
-    if constexpr (L) return lds + 2 * c.tid;
+    if constexpr (L) return lpk + 2 * c.tid;
     else return static_cast<const double*>(pack);
   }
   FB_DEV void stage_pack(const C& c, pk_ptr& view, int off) { stage_pack_s(c, pack, view, lds_off, off); }
@@ -453,7 +462,9 @@ struct MpcR16 {
     cur = off;
   }
   static FB_DEV void stage_pack_s(const C& c, const double* pack0, lds_ptr& view, int& cur, int off) {
+#if !defined(FB_R16_ALWAYS_STAGE)  // (experiment: what staging a matrix copy at every stage costs a time-invariant plant)
     if (off == cur) return;
+#endif
     cur = off;
     lds_ptr dst = view;
     const double* src = pack0 + off;
@@ -465,7 +476,7 @@ struct MpcR16 {
       dbl2 t[kChunk];
       sfor<0, cn>([&](auto I) { t[decltype(I)::value] = *reinterpret_cast<const dbl2*>(src + (c0 + decltype(I)::value) * 2 * LPQ); });
       sfor<0, cn>([&](auto I) {
-        *reinterpret_cast<FB_LDS dbl2*>(dst + (c0 + decltype(I)::value) * 2 * LPQ) = t[decltype(I)::value];
+        *reinterpret_cast<FB_LDS dbl2*>(dst + (c0 + decltype(I)::value) * kPackPair) = t[decltype(I)::value];
       });
     });
     c.sync();
@@ -480,7 +491,7 @@ struct MpcR16 {
     static_assert((S0 & 1) == 0 && S0 + CNT <= kPackLdsSlots, "inside the LDS image, on a pair");
     sfor<0, (CNT + 1) / 2>([&](auto P_) {
       constexpr int pr = decltype(P_)::value;
-      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + (S0 / 2 + pr) * 2 * LPQ);
+      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + (S0 / 2 + pr) * kPackPair);
       out[2 * pr] = t[0];
       if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
     });
@@ -536,7 +547,7 @@ struct MpcR16 {
     const bool rin = r >= NX && ru < nu_;      // lane holds a real input row
     const bool rs_ = rx || rin;
     double* const R0 = rec;
-    lds_ptr Cl = lds + kPackLds;
+    lds_ptr Cl = lds;
     const double *Q = arr(FBSTAB_MPC_Q), *Rm = arr(FBSTAB_MPC_R), *S = arr(FBSTAB_MPC_S),
                  *pq = arr(FBSTAB_MPC_q), *pr = arr(FBSTAB_MPC_r), *A = arr(FBSTAB_MPC_A),
                  *B = arr(FBSTAB_MPC_B), *pc = arr(FBSTAB_MPC_c), *E = arr(FBSTAB_MPC_E),
@@ -1082,7 +1093,7 @@ struct MpcR16 {
     const double* const P0 = pack;
     const lds_iptr po = lpo;
     pk_ptr Lp = pack_view(c);  // this lane's view of the matrix copy in use
-    lds_ptr Cl = lds + kPackLds;
+    lds_ptr Cl = lds;
     double m_adz = -1e300, m_gdz = 0.0, m_hdz = 0.0, m_dz = 0.0, m_atv = 0.0, m_u = 0.0;
     double s_fdz = 0.0, s_p2 = 0.0, s_dx = 0.0;
     struct VIn {
@@ -1656,7 +1667,7 @@ struct MpcR16 {
     const int own0 = owner & ~(LPQ - 1);
     const double t = lane_value(pend_t, own0);
     if (((threadIdx.x ^ owner) & 63 & ~(LPQ - 1)) == 0) pend_t = 0.0;
-    const CloseSums o = close_pass_coop(ov.R0, ov.P0, ov.po, lds + kPackLds, ov.N, t, check);
+    const CloseSums o = close_pass_coop(ov.R0, ov.P0, ov.po, lds, ov.N, t, check);
     pass_fence();
     *dx_norm = sqrt(o.dx2);
     if (!check) return kFeasible;
@@ -1870,7 +1881,7 @@ struct MpcR16 {
     const VarBatchPtrs* x = reinterpret_cast<const VarBatchPtrs*>(lane64((unsigned long long)var));
     const long qp = (long)lane64((unsigned long long)q);
     const int nx_ = EXACT ? NX : d->nx, nu_ = EXACT ? NU : d->nu, nc_ = EXACT ? NC : d->nc;
-    const LoadSums o = load_pass_coop(ov.R0, P0w, pog, ov.po, lds + kPackLds, d, x, qp, ov.N, nx_, nu_, nc_);
+    const LoadSums o = load_pass_coop(ov.R0, P0w, pog, ov.po, lds, d, x, qp, ov.N, nx_, nu_, nc_);
     pass_fence();
     if (((threadIdx.x ^ owner) & 63 & ~(LPQ - 1)) == 0) {
       pend_t = 0.0;
@@ -2102,33 +2113,26 @@ struct MpcR16 {
   // (BASELINE workload: 1e-12 against 1e-6) and run bitwise as before.
   // Real calls (no inlining): a second copy of the sweeps inside the solver loop would cost the common
   // path its register allocation.  They take scalars only, like the cooperative passes.
-  template <bool L = kPackInLds>
-  static FB_DEV auto view_of(const C& c, lds_ptr lds_row, const double* P0) {
-    if constexpr (L) return lds_row + 2 * c.tid;
-    else return P0;
-  }
   static __device__ __attribute__((noinline)) StepOut refine_row_form(double* R0, const double* P0, lds_iptr po,
-                                                                      lds_ptr lds_row, int N_, bool bnd, int loff,
+                                                                      lds_ptr lds_row, pk_ptr Lp, int N_, bool bnd, int loff,
                                                                       double sigma, double alpha) {
     C c;
     c.tid = threadIdx.x & (LPQ - 1);
-    pk_ptr Lp = view_of(c, lds_row, P0);
     return newton_core<true, true>(c, R0, P0, po, lds_row, Lp, N_, bnd, 0.0, loff, sigma, alpha);
   }
   static __device__ __attribute__((noinline)) StepOut refine_ref_form(double* R0, const double* P0, lds_iptr po,
-                                                                      lds_ptr lds_row, int N_, bool bnd, int loff,
+                                                                      lds_ptr lds_row, pk_ptr Lp, int N_, bool bnd, int loff,
                                                                       double sigma, double alpha) {
     C c;
     c.tid = threadIdx.x & (LPQ - 1);
-    pk_ptr Lp = view_of(c, lds_row, P0);
     return newton_core<false, true>(c, R0, P0, po, lds_row, Lp, N_, bnd, 0.0, loff, sigma, alpha);
   }
   // No step may be pending (the Newton step that wrote the record has consumed it).
-  FB_DEV bool refine_step(const C&, double sigma, double alpha, double* trial_inner2, double* trial_outer2,
+  FB_DEV bool refine_step(const C& c, double sigma, double alpha, double* trial_inner2, double* trial_outer2,
                           double* lin2, StepOut* sums = nullptr) {
     StepOut o;
-    if (rowdl) o = refine_row_form(rec, pack, lpo, lds, N, bounds, lds_off, sigma, alpha);
-    else o = refine_ref_form(rec, pack, lpo, lds, N, bounds, lds_off, sigma, alpha);
+    if (rowdl) o = refine_row_form(rec, pack, lpo, lds, pack_view(c), N, bounds, lds_off, sigma, alpha);
+    else o = refine_ref_form(rec, pack, lpo, lds, pack_view(c), N, bounds, lds_off, sigma, alpha);
     lds_off = o.loff;
     if (!o.ok) return false;  // (cannot happen: the same factorisation has just succeeded; the step stands)
     *trial_inner2 = o.in2;
@@ -2147,8 +2151,8 @@ struct MpcR16 {
                                     int loff, double sigma, double alpha) {
     // Locals only below: the lambdas capture no object.
     const int r = c.tid;
-    lds_ptr Tr = lds_row + kPackLds;
-    lds_ptr Cl = lds_row + kPackLds;
+    lds_ptr Tr = lds_row;
+    lds_ptr Cl = lds_row;
     const bool rx = r < NX;
     StepOut ret;
     ret.in2 = ret.out2 = ret.lin2 = ret.zo2 = ret.bi2 = ret.bo2 = 0.0;

@@ -182,7 +182,12 @@ struct R16Queue {
   static __device__ __forceinline__ int home() { return blockIdx.x * P::kQpPerWave + row(); }
   static __device__ __forceinline__ lds_ptr lds() {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
-    return (lds_ptr)smem_ + row() * P::kLdsPerRow;
+    return (lds_ptr)smem_ + P::kPackArea + row() * P::kLdsPerRow;
+  }
+  // this row's image in the wavefront's matrix-copy area (in front of the rows' own regions)
+  static __device__ __forceinline__ lds_ptr pack_lds() {
+    extern __shared__ __attribute__((aligned(16))) double smem_[];
+    return (lds_ptr)smem_ + row() * 2 * P::LPQ;
   }
   // Twenty spare doubles of the row's LDS region: the solver loop parks its scalars
   // there while a Newton step and its line search run (Solver::solve_stream).
@@ -190,7 +195,7 @@ struct R16Queue {
   // the row's table of matrix-copy offsets, behind the four row regions
   __device__ __forceinline__ typename P::lds_iptr lpo() const {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
-    return (typename P::lds_iptr)((lds_ptr)smem_ + P::kQpPerWave * P::kLdsPerRow) + row() * P::lpo_ints(N);
+    return (typename P::lds_iptr)((lds_ptr)smem_ + P::kPackArea + P::kQpPerWave * P::kLdsPerRow) + row() * P::lpo_ints(N);
   }
   __device__ __forceinline__ double* slot_ptr(long slot) const { return scratch + slot * P::ws_doubles(N); }
   // ctl[1]: Newton steps of this launch that were refined (fbstab_hip_mpc_refined_steps)
@@ -215,7 +220,7 @@ struct R16Queue {
         if (done > 0) gone = receding_plant_step(sweep, x, out, batch, q, done - 1, tid(), P::LPQ, gone);
         if (done >= sweep->steps) return -1;
         swept = (done + 1) | (gone ? (1 << 30) : 0);
-        pp.bind(slot_ptr(home()), lds(), lpo(), data, x, q, N, tid());
+        pp.bind(slot_ptr(home()), lds(), pack_lds(), lpo(), data, x, q, N, tid());
         pp.reuse = reuse || done > 0;
         return q;
       }
@@ -226,7 +231,7 @@ struct R16Queue {
       q = bcri<P::LPQ / 16, 0>(q);
     }
     if (q >= batch) return -1;
-    pp.bind(slot_ptr(home()), lds(), lpo(), data, x, q, N, tid());
+    pp.bind(slot_ptr(home()), lds(), pack_lds(), lpo(), data, x, q, N, tid());
     if constexpr (KEEP) pp.reuse = reuse;
     return q;
   }
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
     qu.out = out;
   }
 #if !defined(FB_R16_NO_BIND_IDLE)  // (the switch exists to show what the rows' unbound policy objects did: DESIGN.md section 7)
-  p.bind_idle(qu.lds(), qu.lpo(), N);
+  p.bind_idle(qu.lds(), qu.pack_lds(), qu.lpo(), N);
 #endif
   if constexpr (DBG) {
     if (qu.fetch(p) >= 0) newton_probe(p, ctx, opts, dbg);
@@ -282,7 +287,7 @@ long long r16_ws_doubles(int N) { return fbk::MpcR16<NX, NU, NC, true, false, R>
 template <int NX, int NU, int NC, int R>
 int r16_lds_bytes(int N) {
   typedef fbk::MpcR16<NX, NU, NC, true, false, R> P;
-  return P::kQpPerWave * (P::kLdsPerRow * (int)sizeof(double) + P::lpo_ints(N) * (int)sizeof(int));
+  return (P::kPackArea + P::kQpPerWave * P::kLdsPerRow) * (int)sizeof(double) + P::kQpPerWave * P::lpo_ints(N) * (int)sizeof(int);
 }
 // R: 16-lane rows of the wavefront per QP (1: four QPs per wavefront, stage width
 // <= 16; 2: two QPs per wavefront, stage width <= 32)
