@@ -135,14 +135,14 @@ struct MpcR16 {
 
   static constexpr int off(int slot) { return (slot >> 1) * 2 * LPQ + (slot & 1); }
 
-  // LDS of one row:
-  //   [0, kPackLds)   the matrix copy the current stage uses, minus the [A B]
-  //                   columns (same pair-interleaved image as in HBM): loaded
-  //                   when poff[i] changes, i.e. three to five times per sweep
-  //                   pair for a time-invariant plant, and read by every pass
-  //                   with 16-byte LDS loads;
-  //   [kPackLds, ..)  C as [col][k] (A z products) or the 16 x 16 transpose
-  //                   buffer (forward sweep); odd strides.
+  // LDS of a workgroup (one wavefront):
+  //   the matrix-copy area   the copy each QP's current stage uses, minus the [A B] columns (the
+  //                          pair-interleaved image of HBM, the QPs' images interleaved pair by pair:
+  //                          kPackPair): loaded when poff[i] changes, i.e. three to five times per sweep
+  //                          pair for a time-invariant plant, and read by every pass with 16-byte loads;
+  //   one region per QP      C as [col][k] (A z products) or the triangle images (sweeps); odd strides;
+  //                          behind it the solver loop's parked scalars;
+  //   the tables of matrix-copy offsets (lpo).
   static constexpr int CS = NC | 1;
   // the triangle images: inv(Lc) at 0, inv(Pi) behind it, one dump word for the
   // lanes that have no element to write
@@ -481,6 +481,39 @@ struct MpcR16 {
     });
     c.sync();
   }
+  // The same by LDS-DMA (round 5; build knob FB_R16_PACK_DMA, OFF): global_load_lds_dwordx4 moves 16 bytes
+  // per lane from the lane's own address to LDS at a wave-uniform base + lane x 16 - one slot pair of the
+  // wavefront's area per instruction, no register in between, nothing waits.  The sweeps of the Newton step
+  // issue it for the NEXT stage's copy as soon as the current stage has read the image for the last time
+  // and wait for it at the top of the next stage, so that a plant whose matrices change from stage to
+  // stage (31 stagings per sweep instead of three to five) does not pay a trip to memory and back per
+  // stage.  Built, correct (same checksums, 161 parity tests) - and measured: the time-varying workload
+  // +1.8 % one launch at a time, +-0 with eight in flight (427-432 k either way), the headline +-0
+  // (gpurun_out/r05_v).  That workload is bound by the BYTES of its 31 matrix copies per QP (LABNOTES
+  // Part II), which a different way of fetching them does not change.  Left in as a knob, not the default.
+  // Lp: this lane's view; the lanes of a QP whose copy does not change sit the call out (EXEC).
+#ifndef FB_R16_PACK_DMA
+#define FB_R16_PACK_DMA 0
+#endif
+  static constexpr bool kPackDma = FB_R16_PACK_DMA != 0 && kPackInLds;
+  static FB_DEV void stage_pack_dma(const double* src, lds_ptr Lp) {
+    // (the area's base: the view minus the lane's place in the wavefront - the same in every lane)
+    FB_LDS char* const area = reinterpret_cast<FB_LDS char*>(Lp - 2 * (threadIdx.x & 63));
+    sfor<0, kPackLdsSlots / 2>([&](auto I) {
+      constexpr int pr = decltype(I)::value;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pr * 2 * LPQ),
+                                       (FB_LDS void*)(area + pr * kPackPair * 8), 16, 0, 0);
+    });
+  }
+  // ... and the wait for it: every lane of the wavefront calls this at the top of a stage; `issued` says
+  // whether this lane's QP had a copy on its way
+  static FB_DEV void stage_pack_dma_wait(bool issued) {
+    if (__ballot(issued) != 0ull) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
   // slots [S0, S0 + CNT) of the LDS-resident copy into out[0..CNT)
   template <int S0, int CNT, int NOUT>
   static FB_DEV void ldl(const double* G, double (&out)[NOUT]) {
@@ -2170,12 +2203,14 @@ struct MpcR16 {
     double wln = 0.0;  // WLN of the previous stage = wl of this one
     // offsets of the matrix copies of stages i and i+1 (fetched a stage ahead)
     int pcur = po[0], pnxt = po[N_ > 0 ? 1 : 0];
+    [[maybe_unused]] bool dma_out = false;  // (kPackDma) this QP's next matrix copy is on its way into the image
     load_fwd(R0, cur);  // (loff: the copy resident in LDS)
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
       FB_PHASE(fwd_top);
       double* R = R0 + (long)i * kRec;
       const int pnn = po[i + 2 <= N_ ? i + 2 : N_];
+      if constexpr (kPackDma) stage_pack_dma_wait(dma_out);
       stage_pack_s(c, P0, Lp, loff, pcur);
       // Lane id made opaque per iteration: (ro == j) selects are then recomputed
       // where used instead of being hoisted out of the loop as 16+ live masks.
@@ -2307,6 +2342,15 @@ struct MpcR16 {
       FB_STAMP_LAP(3);
       FB_SB();
       ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
+      if constexpr (kPackDma) {
+        // the image has been read for the last time in this stage: the next stage's copy on its way
+        dma_out = i < N_ && pnxt != loff;
+        if (dma_out) {
+          c.sync();
+          stage_pack_dma(P0 + pnxt, Lp);
+          loff = pnxt;
+        }
+      }
       if constexpr (kSubst) {
         tri_solve_right<NS, RQ>(K, W, ro);
       } else {
@@ -2451,6 +2495,7 @@ struct MpcR16 {
       if constexpr (!ROW) ldv<fP, nPs + 1>(R, Pp);
     };
     BwdIn bin;
+    dma_out = false;
     pcur = po[N_];
     {
       const double* R = R0 + (long)N_ * kRec;
@@ -2462,6 +2507,7 @@ struct MpcR16 {
       FB_PHASE(bwd_top);
       double* R = R0 + (long)i * kRec;
       const double* Rp = i > 0 ? R - kRec : R;  // the stage fetched next (stage 0 once more at the end)
+      if constexpr (kPackDma) stage_pack_dma_wait(dma_out);
       stage_pack_s(c, P0, Lp, loff, pcur);
       pcur = po[i > 0 ? i - 1 : 0];
       int ro = r;
@@ -2547,6 +2593,15 @@ struct MpcR16 {
       bc_all<NS, RQ>(dzu, dzb);
       ldl<pK, NS>(Lp, Hr);
       ldl<pABr, NS>(Lp, AB);
+      if constexpr (kPackDma) {
+        // (pcur is the stage below's already) its copy on its way while this stage finishes
+        dma_out = i > 0 && pcur != loff;
+        if (dma_out) {
+          c.sync();
+          stage_pack_dma(P0 + pcur, Lp);
+          loff = pcur;
+        }
+      }
       FB_STAMP_LAP(9);
       // ---- A dz and dv (:329-341) through the LDS copy of C
       C_to_lds(c, Cl, Cc_, r);
