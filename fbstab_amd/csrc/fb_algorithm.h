@@ -322,15 +322,6 @@ struct Solver : TraceState<TRACE> {
           return Eo;
         }
         if constexpr (can_refine_of<P>::value) {
-#if defined(FB_HOSTSIM) && defined(FB_HOSTSIM_TRACE_REFINE)
-          {
-            double dzm = 0.0, dlm = 0.0;
-            for (int q = 0; q < p.nz; q++) dzm = fmax(dzm, fabs(p.dz[q]));
-            for (int q = 0; q < p.nl; q++) dlm = fmax(dlm, fabs(p.dl[q]));
-            fprintf(stderr, "newton %d: Ei %.3e Eo %.3e lin %.3e tol %.3e combo %.3e |dz| %.3e |dl| %.3e\n", *newton_iters, Ei, Eo,
-                    sqrt(p.linear_residual2(c, sigma)), tol, combo_tol_, dzm, dlm);
-          }
-#endif
           if (wants_refinement(p.linear_residual2(c, sigma), tol, combo_tol_)) {
             p.refine_step(c, sigma);
             refined_++;

@@ -54,7 +54,6 @@
 
 namespace fbk {
 
-#if !defined(FB_HOSTSIM)
 
 // Sub-phase cycles of the factorisation loop (diagnostic builds): summed in registers,
 // one atomic per factorisation (an atomic per lap would be most of what is measured).
@@ -1051,6 +1050,5 @@ struct DenseWave {
   }
 };
 
-#endif  // !FB_HOSTSIM
 
 }  // namespace fbk

@@ -19,7 +19,6 @@
 
 namespace fbk {
 
-#if !defined(FB_HOSTSIM)
 
 FB_DEV double wave_sum(double x) {
 #pragma unroll
@@ -174,6 +173,5 @@ __global__ __launch_bounds__(64) void fbstab_dense_final_norms_kernel(DenseNormA
   }
 }
 
-#endif  // !FB_HOSTSIM
 
 }  // namespace fbk

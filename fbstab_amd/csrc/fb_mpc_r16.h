@@ -43,7 +43,6 @@
 
 namespace fbk {
 
-#if !defined(FB_HOSTSIM)
 
 // Batch descriptors as the kernel receives them (one base + stride per array).
 struct MpcBatchPtrs {
@@ -2708,6 +2707,5 @@ struct MpcR16 {
   }
 };
 
-#endif  // !FB_HOSTSIM
 
 }  // namespace fbk

@@ -24,7 +24,6 @@
 
 namespace fbk {
 
-#if !defined(FB_HOSTSIM)
 
 // ---- compile-time loops ------------------------------------------------------
 template <int B, class F, int... I>
@@ -580,6 +579,5 @@ FB_DEV double dot4(const double (&m)[NM], const double (&b)[NB], double init = 0
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
-#endif  // !FB_HOSTSIM
 
 }  // namespace fbk
