@@ -69,6 +69,22 @@ def test_argument_validation_without_gpu(lib):
         assert lib.fbstab_hip_mpc_create(30, 80, 4, 20, 1, 0, C.byref(h)) == 2
 
 
+def test_create_in_flight_validates_its_arguments_without_gpu(lib):
+    """fbstab_hip_mpc_create_in_flight (round 5): the plain create with one more argument; rejected
+    arguments are rejected before any device is touched."""
+    h = C.c_void_p()
+    lib.fbstab_hip_mpc_create_in_flight.argtypes = [C.c_int] * 7 + [C.c_void_p]
+    assert lib.fbstab_hip_mpc_create_in_flight(30, 12, 4, 20, 8, 0, 0, C.byref(h)) == 1   # handles_in_flight < 1
+    assert b"handles_in_flight" in lib.fbstab_hip_last_error()
+    assert lib.fbstab_hip_mpc_create_in_flight(30, 12, 4, 20, 8, 0, 8, None) == 1          # null handle pointer
+    assert lib.fbstab_hip_mpc_create_in_flight(0, 12, 4, 20, 8, 0, 8, C.byref(h)) == 1    # fbstab_mpc.cc:62-65
+    assert h.value is None
+    n = C.c_longlong(0)
+    lib.fbstab_hip_mpc_refined_steps.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.fbstab_hip_mpc_refined_steps(None, C.byref(n)) == 1
+    assert b"null solver handle" in lib.fbstab_hip_last_error()
+
+
 def test_factorisation_option_of_the_dense_handle_without_gpu(lib):
     """fbstab_hip_dense_set_factorisation / _get_factorisation (round 4): the enum of the
     header, the binding's constants and the argument checks agree; the variant library of the

@@ -112,3 +112,16 @@ def test_round4_blocks_of_the_bench_line():
     assert abs(lat["gpu_batch1_over_cpu_same_qp"] - lat["device_pointers"]["1"]["ms_median"] / c["ms_median"]) < 1e-9
     if r["roofline"]["traffic"] is not None:
         assert isinstance(r["roofline"]["traffic_build_matches"], bool)
+
+
+def test_round_5_fields_of_the_bench_line():
+    """the line says how far the kernel is from the memory wall of its own counter
+    traffic (hbm_ceiling_qps = batch / (traffic / 6.29 TB/s)), how many untimed steps really ran (every lane's
+    first solve is untimed: max(W, lanes)), and the launch geometry of a handle that shares the device."""
+    r, path = _latest_line()
+    rf = r["roofline"]
+    if rf["traffic"] is not None:
+        assert abs(rf["hbm_ceiling_qps"] - r["config"]["batch_per_gpu"] / (rf["traffic"] / 6.29e12)) < 1e-6 * rf["hbm_ceiling_qps"], path
+        assert rf["hbm_ceiling_qps"] > r["value"] / r["n_gpus"]  # the kernel is not at that wall
+    assert r["config"]["untimed_steps"] >= max(r["warmup"], min(r["config"]["steps_in_flight"], r["steps"])), path
+    assert r["launch"]["workgroups"] >= 256 and r["launch"]["scratch_bytes"] > 0

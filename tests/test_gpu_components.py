@@ -388,6 +388,27 @@ def test_refinement_option_takes_every_block_row_to_rounding_level(hip, monkeypa
     s.close()
 
 
+def test_a_handle_created_for_eight_in_flight_gives_the_same_bits(hip):
+    """fbstab_hip_mpc_create_in_flight: a handle that shares the device takes its share of the resident
+    workgroups (and of the scratch memory) - the queue hands the same QPs to fewer rows, nothing else:
+    outputs bitwise equal to a handle that has the device to itself."""
+    B = 2048
+    p = fx.synthetic_mpc_batch(B)
+    res = []
+    for k in (1, 8):
+        s = hip.FBstabMpcBatch(*p.sizes(), max_batch=B, handles_in_flight=k)
+        q = s.query()
+        z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
+        out = s.Solve({k_: np.ascontiguousarray(a) for k_, a in p.arrays.items()}, z, l, v, y)
+        res.append((z, l, v, y, out, q))
+        s.close()
+    assert res[1][5]["workgroups"] * 2 <= res[0][5]["workgroups"] and res[1][5]["scratch_bytes"] * 2 <= res[0][5]["scratch_bytes"]
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert np.array_equal(a, b)
+    for f in ("eflag", "residual", "newton_iters", "prox_iters"):
+        assert np.array_equal(res[0][4][f], res[1][4][f]), f
+
+
 def test_the_refinement_option_leaves_the_baseline_workload_untouched(hip, oracle):
     """On the BASELINE workload (cold start, default options) no Newton step's linear residual comes near a
     tolerance (1e-12 against 1e-6): even with the option on (reserved = 1) fbstab_hip_mpc_refined_steps = 0,

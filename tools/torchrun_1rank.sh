@@ -1,6 +1,8 @@
 #!/bin/bash
 # Developer tool (GPU box): the headline as the driver launches it for N > 1, with ONE rank - the gather
 # path (RCCL process group, one gather per batch) on one device - beside the plain single-process run.
+# Prints one summary line per run (the bench lines themselves: pipe bench.py's stdout through
+# `grep '^{'` - RCCL writes its banner to the same stream, and a file that starts with it is not JSON).
 # usage: tools/torchrun_1rank.sh <rounds>
 R=${1:-2}
 show() { python3 -c "
