@@ -515,6 +515,41 @@ def random_ltv_mpc(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
     return p
 
 
+def random_ltv_mpc_bounds(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
+    """random_ltv_mpc with BOUND constraints: every constraint row has one entry, +1 or -1, on a stage
+    variable drawn at random (at most four rows per variable) - the constraints the record kernels' row
+    form of the costate step serves (fb_mpc_r16.h: choose_costate_form) - strictly feasible by construction."""
+    p = random_ltv_mpc(rng, batch, N, nx, nu, nc, dyn_noise)
+    ns = nx + nu
+    E = np.zeros((batch, N + 1, nx, nc)); L = np.zeros((batch, N + 1, nu, nc))
+    for b in range(batch):
+        for i in range(N + 1):
+            load = np.zeros(ns, dtype=int)
+            for k in range(nc):
+                free = np.flatnonzero(load < 4)
+                c = int(free[rng.integers(0, len(free))]) if len(free) else int(rng.integers(0, ns))
+                load[c] += 1
+                sgn = 1.0 if rng.random() < 0.5 else -1.0
+                if c < nx: E[b, i, c, k] = sgn
+                else: L[b, i, c - nx, k] = sgn
+    p.arrays["E"] = np.ascontiguousarray(E.reshape(batch, -1))
+    p.arrays["L"] = np.ascontiguousarray(L.reshape(batch, -1))
+    A = np.transpose(p.arrays["A"].reshape(batch, N, nx, nx), (0, 1, 3, 2))
+    Bm = np.transpose(p.arrays["B"].reshape(batch, N, nu, nx), (0, 1, 3, 2))
+    Em = np.transpose(E, (0, 1, 3, 2)); Lm = np.transpose(L, (0, 1, 3, 2))
+    cm = p.arrays["c"].reshape(batch, N, nx)
+    d = np.zeros((batch, N + 1, nc))
+    for b in range(batch):
+        x = p.arrays["x0"][b].copy()
+        for i in range(N + 1):
+            u = 0.2 * rng.standard_normal(nu)
+            d[b, i] = -(Em[b, i] @ x + Lm[b, i] @ u) - (0.05 + 0.5 * rng.random(nc))
+            if i < N:
+                x = A[b, i] @ x + Bm[b, i] @ u + cm[b, i]
+    p.arrays["d"] = np.ascontiguousarray(d.reshape(batch, -1))
+    return p
+
+
 def synthetic_dense_batch(batch: int, nz: int, nl: int, nv: int,
                           first_id: int = 0,
                           seed: int = MASTER_SEED) -> DenseProblem:

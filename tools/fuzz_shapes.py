@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: random MPC shapes over every record instance (and the flat-vector
 kernel) against the oracle: exit flags, proximal counts equal; Newton counts equal on
-all but a few.  argv: number of shapes [seed] [r16].  With `r16` every shape is drawn inside the
+all but a few.  argv: number of shapes [seed] [r16] [bounds].  With `bounds` the constraints are bounds on single stage
+variables (fixtures.random_ltv_mpc_bounds).  With `r16` every shape is drawn inside the
 headline instance <12,4,20> (nx <= 12, nu <= 4, nc <= 20); a shape is flagged ("CHECK") as soon as ANY
 count differs from the oracle's (strict), otherwise when flags / proximal counts differ, a Newton
 count differs by more than two or the solutions part.  The last column counts the Newton steps the kernel
@@ -14,7 +15,8 @@ from tools import fixtures as fx
 from oracle.oracle_py import Oracle, default_options
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-r16 = len(sys.argv) > 3 and sys.argv[3] == "r16"
+r16 = len(sys.argv) > 3 and "r16" in sys.argv[3:]
+bounds = "bounds" in sys.argv[3:]  # bound constraints (one +-1 entry per row): the row form of the costate step
 strict = r16 or os.environ.get("FUZZ_STRICT", "1") != "0"
 nqp = nref = 0
 orc = Oracle(False)
@@ -28,7 +30,7 @@ for it in range(n):
     o = default_options()
     if rng.random() < 0.3:
         o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
-    p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    p = fx.random_ltv_mpc_bounds(rng, B, N, nx, nu, nc) if bounds else fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
     s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
     h = hip_api.Options()
     for name, _ in h._fields_:
