@@ -110,9 +110,11 @@ def newton_system_residual(p, q, step, x=None, xbar=None, sigma=1e-8, alpha=0.95
     return blocks, float(np.sqrt((e1 * e1).sum() + (e2 * e2).sum() + (e3 * e3).sum()))
 
 
-def fuzz_stream_shape(seed, index):
-    """Shape number ``index`` (from 0) of tools/fuzz_shapes.py's stream for ``seed``: (problem, options)."""
+def fuzz_stream_shape(seed, index, family="random"):
+    """Shape number ``index`` (from 0) of tools/fuzz_shapes.py's stream for ``seed``: (problem, options).
+    ``family``: "random" (the default stream), "bounds" or "sparse" (the tool's options of those names)."""
     from oracle.oracle_py import default_options
+    gen = {"random": fx.random_ltv_mpc, "bounds": fx.random_ltv_mpc_bounds, "sparse": fx.random_ltv_mpc_sparse_rows}[family]
     rng = np.random.default_rng(seed)
     for it in range(index + 1):
         nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
@@ -120,7 +122,7 @@ def fuzz_stream_shape(seed, index):
         o = default_options()
         if rng.random() < 0.3:
             o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
-        p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+        p = gen(rng, B, N, nx, nu, nc)
     return p, o
 
 

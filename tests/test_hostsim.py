@@ -179,3 +179,54 @@ def test_refinement_is_an_option_because_a_more_accurate_step_also_parts_from_th
             assert (b[4]["prox_iters"][0], b[4]["newton_iters"][0]) == (3, 29)
             assert (c[4]["prox_iters"][0], c[4]["newton_iters"][0]) == (2, 28)
             assert 0.8e-6 <= c[4]["residual"][0] <= 1e-6
+
+
+def test_a_count_that_only_the_references_rounding_decides(hostsim, oracle):
+    """The limit of count parity, pinned.  tools/fuzz_shapes.py's sparse-row family (seed 301, shape 144:
+    N = 8, nx = 10, nu = 2, one constraint row of two or three entries, nine QPs) holds ONE QP in ~8,400 whose
+    counts part from the oracle's on every kernel: a one-step QP (no constraint active).  The exact Newton step
+    lands on the proximal point, residual sigma |z - zbar| = 2.0e-7; the device logic's step leaves 3e-8 of
+    the Newton system behind and stops there, 1 / 1.  The ORACLE's own step leaves 1.2e-6 - above abs_tol
+    by itself (two inputs cannot reach a state of ten in one stage: Pi = sigma I + [A B] inv(K) [A B]' has
+    eigenvalues of order sigma, and what is left of dl after the cancellation depends on the order of every
+    sum) - and it runs a second iteration, 2 / 2.  Both end within 3e-7 of each other, a third of the tolerance.
+    No arrangement of the device arithmetic short of the reference's own operation order AND rounding
+    reproduces that leftover: the refined step agrees with the device's, not with the oracle's, and the
+    oracle itself takes 1 / 1 once its compiler may contract a * b + c (last assertion)."""
+    p, o = H.fuzz_stream_shape(301, 143, "sparse")
+    assert p.sizes() == (8, 10, 2, 1) and p.batch == 9
+    N, nx, nu, nc = p.sizes()
+    b = oracle.solve_mpc(p, opts=o)
+    a = hostsim.solve_mpc(p, opts=o)
+    others = np.arange(9) != 4
+    assert (a[4]["eflag"] == 0).all() and (b[4]["eflag"] == 0).all()
+    assert np.array_equal(a[4]["prox_iters"][others], b[4]["prox_iters"][others])
+    assert np.array_equal(a[4]["newton_iters"][others], b[4]["newton_iters"][others])
+    assert (a[4]["prox_iters"][4], a[4]["newton_iters"][4]) == (1, 1)
+    assert (b[4]["prox_iters"][4], b[4]["newton_iters"][4]) == (2, 2)
+    assert a[4]["residual"][4] <= 2.2e-7 and np.abs(a[0][4] - b[0][4]).max() <= 3e-7
+    # the Newton step from the cold start, three ways: its leftover in the Newton system
+    x = (np.zeros(p.nz), np.zeros(p.nl), np.zeros(p.nv))
+    one = fx.MpcProblem(N, nx, nu, nc, {k: np.ascontiguousarray(v[4:5]) for k, v in p.arrays.items()})
+    pr = oracle.probe(one, *x, *x, 1e-8, 0.95)
+    dx = oracle.probe(one, *x, *x, 1e-8, 0.95, r=-pr["inner"], want_dx=True)["dx"]
+    ostep = {"dz": dx[:p.nz], "dl": dx[p.nz:p.nz + p.nl], "dv": dx[p.nz + p.nl:p.nz + p.nl + p.nv]}
+    s0 = hostsim.newton_mpc(p, 4, x, x, 1e-8, 0.95, 0)
+    s1 = hostsim.newton_mpc(p, 4, x, x, 1e-8, 0.95, 1)
+    n0, n1, no = (H.newton_system_residual(p, 4, s)[1] for s in (s0, s1, ostep))
+    assert no > 1e-6 > 10 * n0 and n1 <= 1e-13
+    assert np.abs(s0["dl"] - s1["dl"]).max() <= 0.1 * np.abs(ostep["dl"] - s1["dl"]).max()
+    # ... and the oracle ITSELF, compiled once more with fused multiply-adds allowed (same algorithm, same order
+    # of operations - tools/oracle_rounding_sensitivity_mpc.py), takes the device's counts on this QP
+    import ctypes, os, subprocess, tempfile
+    from oracle.oracle_py import Oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "liboracle_fma.so")
+        subprocess.check_call(["g++", "-O3", "-std=c++11", "-fPIC", "-fopenmp", "-ffp-contract=fast", "-mfma", "-shared",
+                               "-o", so, os.path.join(root, "oracle", "oracle_capi.cc")])
+        fma = Oracle(False)
+        fma.lib = ctypes.CDLL(so)
+        fma.lib.fbo_last_error.restype = ctypes.c_char_p
+        f = fma.solve_mpc(p, opts=o)[4]
+    assert np.array_equal(f["prox_iters"], a[4]["prox_iters"]) and np.array_equal(f["newton_iters"], a[4]["newton_iters"])

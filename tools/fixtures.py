@@ -515,7 +515,15 @@ def random_ltv_mpc(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
     return p
 
 
-def random_ltv_mpc_bounds(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
+def random_ltv_mpc_sparse_rows(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
+    """random_ltv_mpc with SPARSE constraint rows: two or three entries of magnitude 0.3 .. 0.8 per row on
+    stage variables drawn at random (at most four rows per variable) - rows for which the record kernels
+    take the row form of the costate step without being bounds (choose_costate_form: nzmax x cmax2 <= 8),
+    like the bench line's time-varying workload."""
+    return random_ltv_mpc_bounds(rng, batch, N, nx, nu, nc, dyn_noise, entries=(2, 3))
+
+
+def random_ltv_mpc_bounds(rng, batch, N, nx, nu, nc, dyn_noise=0.15, entries=None):
     """random_ltv_mpc with BOUND constraints: every constraint row has one entry, +1 or -1, on a stage
     variable drawn at random (at most four rows per variable) - the constraints the record kernels' row
     form of the costate step serves (fb_mpc_r16.h: choose_costate_form) - strictly feasible by construction."""
@@ -526,12 +534,14 @@ def random_ltv_mpc_bounds(rng, batch, N, nx, nu, nc, dyn_noise=0.15):
         for i in range(N + 1):
             load = np.zeros(ns, dtype=int)
             for k in range(nc):
-                free = np.flatnonzero(load < 4)
-                c = int(free[rng.integers(0, len(free))]) if len(free) else int(rng.integers(0, ns))
-                load[c] += 1
-                sgn = 1.0 if rng.random() < 0.5 else -1.0
-                if c < nx: E[b, i, c, k] = sgn
-                else: L[b, i, c - nx, k] = sgn
+                for _e in range(1 if entries is None else int(rng.integers(entries[0], entries[1] + 1))):
+                    free = np.flatnonzero(load < 4)
+                    c = int(free[rng.integers(0, len(free))]) if len(free) else int(rng.integers(0, ns))
+                    load[c] += 1
+                    sgn = 1.0 if rng.random() < 0.5 else -1.0
+                    if entries is not None: sgn *= 0.3 + 0.5 * rng.random()
+                    if c < nx: E[b, i, c, k] = sgn
+                    else: L[b, i, c - nx, k] = sgn
     p.arrays["E"] = np.ascontiguousarray(E.reshape(batch, -1))
     p.arrays["L"] = np.ascontiguousarray(L.reshape(batch, -1))
     A = np.transpose(p.arrays["A"].reshape(batch, N, nx, nx), (0, 1, 3, 2))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: random MPC shapes over every record instance (and the flat-vector
 kernel) against the oracle: exit flags, proximal counts equal; Newton counts equal on
-all but a few.  argv: number of shapes [seed] [r16] [bounds].  With `bounds` the constraints are bounds on single stage
+all but a few.  argv: number of shapes [seed] [r16] [bounds | sparse].  With `bounds` the constraints are bounds on single stage
 variables (fixtures.random_ltv_mpc_bounds).  With `r16` every shape is drawn inside the
 headline instance <12,4,20> (nx <= 12, nu <= 4, nc <= 20); a shape is flagged ("CHECK") as soon as ANY
 count differs from the oracle's (strict), otherwise when flags / proximal counts differ, a Newton
@@ -17,6 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r16 = len(sys.argv) > 3 and "r16" in sys.argv[3:]
 bounds = "bounds" in sys.argv[3:]  # bound constraints (one +-1 entry per row): the row form of the costate step
+sparse = "sparse" in sys.argv[3:]  # two or three entries of order one per row: the row form without the bounds' shortcut
 strict = r16 or os.environ.get("FUZZ_STRICT", "1") != "0"
 nqp = nref = 0
 orc = Oracle(False)
@@ -30,7 +31,8 @@ for it in range(n):
     o = default_options()
     if rng.random() < 0.3:
         o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
-    p = fx.random_ltv_mpc_bounds(rng, B, N, nx, nu, nc) if bounds else fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    p = (fx.random_ltv_mpc_bounds(rng, B, N, nx, nu, nc) if bounds else
+         fx.random_ltv_mpc_sparse_rows(rng, B, N, nx, nu, nc) if sparse else fx.random_ltv_mpc(rng, B, N, nx, nu, nc))
     s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
     h = hip_api.Options()
     for name, _ in h._fields_:

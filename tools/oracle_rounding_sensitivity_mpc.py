@@ -3,7 +3,7 @@
 the restatement compiled a second time with fused multiply-adds allowed (-ffp-contract=fast -mfma; the
 checked-in build uses -ffp-contract=off, as the reference's CMake build does) into gpurun_out/ (scratch).
 Same algorithm, same order of operations; only the rounding of a*b+c differs.  The shapes are
-tools/fuzz_shapes.py's stream for the seed.  argv: number of shapes [seed]"""
+tools/fuzz_shapes.py's stream for the seed (and its `bounds` / `sparse` family).  argv: number of shapes [seed] [bounds | sparse]"""
 import ctypes as C
 import os, subprocess, sys
 import numpy as np
@@ -22,6 +22,7 @@ b.lib = C.CDLL(so)
 b.lib.fbo_last_error.restype = C.c_char_p
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 42)
+gen = fx.random_ltv_mpc_bounds if "bounds" in sys.argv[3:] else fx.random_ltv_mpc_sparse_rows if "sparse" in sys.argv[3:] else fx.random_ltv_mpc
 nqp = nprox = nnewton = nflag = 0
 for it in range(n):
     nx = int(rng.integers(1, 27)); nu = int(rng.integers(1, 10)); nc = int(rng.integers(1, 34)); N = int(rng.integers(1, 13))
@@ -29,7 +30,7 @@ for it in range(n):
     o = default_options()
     if rng.random() < 0.3:
         o = default_options(max_linesearch_iters=int(rng.integers(1, 12)), nonmonotone_linesearch=int(rng.random() < 0.5))
-    p = fx.random_ltv_mpc(rng, B, N, nx, nu, nc)
+    p = gen(rng, B, N, nx, nu, nc)
     oa = a.solve_mpc(p, opts=o, nthreads=a.num_threads())[4]
     ob = b.solve_mpc(p, opts=o, nthreads=a.num_threads())[4]
     dn = oa["newton_iters"].astype(int) - ob["newton_iters"].astype(int)
