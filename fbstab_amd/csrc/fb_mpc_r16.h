@@ -130,7 +130,9 @@ struct MpcR16 {
   static constexpr int kPack = LPQ * kPackSlots;
   // poff[N+1] ints, the flag word and the two scale words of the costate form (below)
   static constexpr long hdr_doubles(int N) { return ((N + 5) / 2 + 15) & ~15L; }
-  static constexpr long ws_doubles(int N) { return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1); }
+  static constexpr long ws_doubles(int N) {
+    return hdr_doubles(N) + (long)(kRec + kPack) * (N + 1) + (2 * (NC - LPQ * (KS - 1)) <= LPQ ? kRec : 0);  // (+ the spare record)
+  }
 
   static constexpr int off(int slot) { return (slot >> 1) * 2 * LPQ + (slot & 1); }
 
@@ -429,6 +431,37 @@ struct MpcR16 {
     dbl2 t = {a, b};
     *reinterpret_cast<dbl2*>(R + off(even_slot)) = t;
   }
+  // The LAST constraint slot of a lane holds an entry on the first kTail lanes only (NC = 20: 4 of 16).  The
+  // other lanes' entries are zero from load_guess() on and stay zero - every pass computes zeros there.  In
+  // the sweeps and the trial pass those lanes therefore take the slot from ONE spare record per QP (record
+  // N + 1, zeroed by load_guess(), cache-resident) instead of the stage's own: the same instructions, the same
+  // values in every lane bit for bit, and three quarters of the slot's bytes stay out of HBM.  (With the
+  // lanes masked out of the accesses instead - `if (tail_lane())` - the counters showed the same bytes and
+  // the headline lost 7 %: five conditional regions per stage pair cut the sweeps' basic blocks and the
+  // waits at their joins, gpurun_out/r05_t1.)
+#ifndef FB_R16_TAIL_CUT
+#define FB_R16_TAIL_CUT 1
+#endif
+  static constexpr int kTail = NC - LPQ * (KS - 1);
+  static constexpr bool kTailCut = FB_R16_TAIL_CUT != 0 && 2 * kTail <= LPQ;
+  static constexpr int kSpareRecords = kTailCut ? 1 : 0;
+  static FB_DEV bool tail_lane() { return (int)(threadIdx.x & (LPQ - 1)) < kTail; }
+  // where this lane finds the last constraint slot of the stage whose record is R (Rd: the spare record)
+  template <class P>
+  static FB_DEV P tail_of(P R, P Rd) {
+    if constexpr (kTailCut) return tail_lane() ? R : Rd;
+    else return R;
+  }
+  static FB_DEV void zero_spare(double* R0, int N_) {
+    if constexpr (kTailCut) {
+      double* const Rd = spare_of(R0, N_);
+      st2(Rd, sV + 2 * (KS - 1), 0.0, 0.0);
+      st2(Rd, sDV + 2 * (KS - 1), 0.0, 0.0);
+      if constexpr (kStoreGamma) st2(Rd, sGAM + 2 * (KS - 1), 0.0, 0.0);
+    }
+  }
+  static FB_DEV const double* spare_of(const double* R0, int N_) { return R0 + (long)(N_ + 1) * kRec; }
+  static FB_DEV double* spare_of(double* R0, int N_) { return R0 + (long)(N_ + 1) * kRec; }
   // slots [S0, S0 + CNT) into out[0..CNT); S0 even
   template <int S0, int CNT, int NOUT>
   static FB_DEV void ldv(const double* R, double (&out)[NOUT]) {
@@ -741,6 +774,7 @@ struct MpcR16 {
         st2(R, sDV + 2 * s, 0.0, 0.0);
       });
     }
+    zero_spare(rec, N_);
     {
       bool fresh_all = true;
       if constexpr (KEEP) fresh_all = !reuse;
@@ -959,11 +993,12 @@ struct MpcR16 {
     dbl2 vy[KS], da[KS];
     double vb[KS];
   };
-  static FB_DEV void load_trial_v(const double* R, TrialInV& in) {
+  static FB_DEV void load_trial_v(const double* R, const double* Rd, TrialInV& in) {
+    const double* const Rt = tail_of(R, Rd);
     sfor<0, KS>([&](auto S_) {
       constexpr int sl = decltype(S_)::value;
-      in.vy[sl] = ld2(R, sV + 2 * sl);
-      in.da[sl] = ld2(R, sDV + 2 * sl);
+      in.vy[sl] = ld2(sl == KS - 1 ? Rt : R, sV + 2 * sl);
+      in.da[sl] = ld2(sl == KS - 1 ? Rt : R, sDV + 2 * sl);
     });
     ldv<sVB, KS>(R, in.vb);
   }
@@ -987,6 +1022,7 @@ struct MpcR16 {
     sfor<1, K>([&](auto Kk) { tt[decltype(Kk)::value] = tt[decltype(Kk)::value - 1] * beta; });
     sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
     auto stage_ptr = [&](int i) { return R0 + (long)(i < N_ ? i : N_) * kRec; };
+    const double* const Rd = spare_of(R0, N_);
     // (The slots of a trip are requested a trip ahead - this pass stores nothing.  At the top
     // of their own trip, FB_R16_TRIAL_AHEAD=0: 485 k against 533 k QP/s, gpurun_out/r03_ap;
     // two trips ahead: -6 %, round 2.  In the passes that also STORE records - open, close,
@@ -1003,15 +1039,15 @@ struct MpcR16 {
     constexpr int TS = FB_R16_TRIAL_STAGES;
     TrialInV in[TS];
     if constexpr (FB_R16_TRIAL_AHEAD != 0)
-      sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(q + QW * decltype(J)::value), in[decltype(J)::value]); });
+      sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(q + QW * decltype(J)::value), Rd, in[decltype(J)::value]); });
     for (int i = q; i - q <= N_; i += TS * QW) {  // (the same trip count in every row)
       FB_PHASE(trip_top);
       if constexpr (FB_R16_TRIAL_AHEAD == 0)
-        sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * decltype(J)::value), in[decltype(J)::value]); });
+        sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * decltype(J)::value), Rd, in[decltype(J)::value]); });
       TrialInV cu[TS];
       sfor<0, TS>([&](auto J) { cu[decltype(J)::value] = in[decltype(J)::value]; });
       if constexpr (FB_R16_TRIAL_AHEAD != 0)
-        sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * (TS + decltype(J)::value)), in[decltype(J)::value]); });
+        sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * (TS + decltype(J)::value)), Rd, in[decltype(J)::value]); });
       sfor<0, TS>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const bool live = i + QW * j <= N_;
@@ -1884,6 +1920,7 @@ struct MpcR16 {
       }
       FB_PHASE(trip_end);
     }
+    zero_spare(R0, N_);  // (every row writes the same zeros)
     LoadSums o;
     o.c2m = rows_max(c2m);
     o.hm = rows_max(hm);
@@ -2059,7 +2096,7 @@ struct MpcR16 {
     dbl2 vy[KS], da[KS];
     double vb[KS];
   };
-  static FB_DEV void load_fwd(const double* R, FwdIn& in) {
+  static FB_DEV void load_fwd(const double* R, const double* Rd, FwdIn& in) {
 #if defined(FB_R16_EXTRA_READS)
     // (experiment: up to three more slot pairs per stage and forward sweep - pairs no sweep touches: ybar,
     //  (f h), b - requested with the stage's own and thrown away where the stage's own are used, a stage
@@ -2072,10 +2109,11 @@ struct MpcR16 {
     in.dw = ld2(R, sDZ);
     in.lr = ld2(R, sL);
     in.dwl = ld2(R, sDL);
+    const double* const Rt = tail_of(R, Rd);
     sfor<0, KS>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
-      in.vy[s] = ld2(R, sV + 2 * s);
-      in.da[s] = ld2(R, sDV + 2 * s);
+      in.vy[s] = ld2(s == KS - 1 ? Rt : R, sV + 2 * s);
+      in.da[s] = ld2(s == KS - 1 ? Rt : R, sDV + 2 * s);
     });
     ldv<sVB, KS>(R, in.vb);
   }
@@ -2087,14 +2125,15 @@ struct MpcR16 {
     dbl2 dw, dwl, da[KS];  // (refinement sweep only) the step in the record: (dz wz) (dl wl+) (dv adz)
   };
   template <bool REFINE = false>
-  static FB_DEV void load_bwd(const double* R, BwdIn& in) {
+  static FB_DEV void load_bwd(const double* R, const double* Rd, BwdIn& in) {
     in.zr = ld2(R, sZ);
     in.lr = ld2(R, sL);
+    const double* const Rt = tail_of(R, Rd);
     sfor<0, KS>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
-      in.vy[s] = ld2(R, sV + 2 * s);
-      if constexpr (kStoreGamma) in.gr[s] = ld2(R, sGAM + 2 * s);
-      if constexpr (REFINE) in.da[s] = ld2(R, sDV + 2 * s);
+      in.vy[s] = ld2(s == KS - 1 ? Rt : R, sV + 2 * s);
+      if constexpr (kStoreGamma) in.gr[s] = ld2(s == KS - 1 ? Rt : R, sGAM + 2 * s);
+      if constexpr (REFINE) in.da[s] = ld2(s == KS - 1 ? Rt : R, sDV + 2 * s);
     });
     ldv<sVB, KS>(R, in.vb);
     if constexpr (REFINE) {
@@ -2214,7 +2253,8 @@ struct MpcR16 {
     // offsets of the matrix copies of stages i and i+1 (fetched a stage ahead)
     int pcur = po[0], pnxt = po[N_ > 0 ? 1 : 0];
     [[maybe_unused]] bool dma_out = false;  // (kPackDma) this QP's next matrix copy is on its way into the image
-    load_fwd(R0, cur);  // (loff: the copy resident in LDS)
+    double* const Rd = spare_of(R0, N_);  // (kTailCut: the padding lanes' place for the last constraint slot)
+    load_fwd(R0, Rd, cur);  // (loff: the copy resident in LDS)
     // ===================== forward sweep ===================================
     for (int i = 0; i <= N_; i++) {
       FB_PHASE(fwd_top);
@@ -2240,8 +2280,9 @@ struct MpcR16 {
         Gam[s] = bt[0];
         Rvm[s] = bt[1];
         if constexpr (!REFINE) {  // (the refinement sweep finds all of this in the record: tp = 0)
-          st2(R, sV + 2 * s, vk, yk);
-          if constexpr (kStoreGamma) st2(R, sGAM + 2 * s, Gam[s], Rvm[s]);
+          double* const Rs = s == KS - 1 ? tail_of(R, Rd) : R;
+          st2(Rs, sV + 2 * s, vk, yk);
+          if constexpr (kStoreGamma) st2(Rs, sGAM + 2 * s, Gam[s], Rvm[s]);
         }
       });
 #if defined(FB_R16_EXTRA_READS)
@@ -2271,7 +2312,7 @@ struct MpcR16 {
       FB_SB();
       // next stage's inputs, a whole stage ahead (the last stage fetches itself once
       // more: no branch here)
-      load_fwd(i < N_ ? R + kRec : R, cur);
+      load_fwd(i < N_ ? R + kRec : R, Rd, cur);
       FB_SB();
       FB_STAMP_LAP(0);
       // K row: H + sigma I (at pivot time) + inv(Pi) block + C' Gamma C (:101-123, :142-145)
@@ -2511,7 +2552,7 @@ struct MpcR16 {
       const double* R = R0 + (long)N_ * kRec;
       load_fac(R);
       ldv<pABc, NX>(P0 + pcur, Ac);
-      load_bwd<REFINE>(R, bin);
+      load_bwd<REFINE>(R, Rd, bin);
     }
     for (int i = N_; i >= 0; i--) {
       FB_PHASE(bwd_top);
@@ -2523,7 +2564,7 @@ struct MpcR16 {
       int ro = r;
       asm volatile("" : "+v"(ro));
       BwdIn cu = bin;
-      load_bwd<REFINE>(Rp, bin);
+      load_bwd<REFINE>(Rp, Rd, bin);
       if constexpr (!kStoreGamma) {
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
@@ -2641,7 +2682,7 @@ struct MpcR16 {
           s_in = fma(ph, ph, s_in);
           s_out = fma(pn, pn, s_out);
         }
-        st2(R, sDV + 2 * sl, dt, at);
+        st2(sl == KS - 1 ? tail_of(R, Rd) : R, sDV + 2 * sl, dt, at);
         dvs[sl] = d;
       });
       // ---- wz = H dz + G'dl + A'dv; (G'dl)_x = [A B]'dl(i+1) - dl(i)

@@ -132,8 +132,8 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
  * BASELINE shape), but with several launches in flight the others fill the device and a launch does better
  * with its share: each row of a wavefront then gets more QPs of the batch and the tail of the launch - rows
  * that have run out of QPs while their wavefront's last one finishes - shrinks (rows busy 0.95 instead of 0.82
- * per Newton step at eight in flight; +2.7 % throughput, and a quarter of the scratch memory: 0.43 instead
- * of 1.72 GB per handle).  handles_in_flight = 1 is fbstab_hip_mpc_create. */
+ * per Newton step at eight in flight; +2.7 % throughput, and a quarter of the scratch memory: 0.44 instead
+ * of 1.75 GB per handle).  handles_in_flight = 1 is fbstab_hip_mpc_create. */
 int fbstab_hip_mpc_create_in_flight(int N, int nx, int nu, int nc, int max_batch, int device,
                                     int handles_in_flight, fbstab_mpc_handle_t* handle);
 int fbstab_hip_mpc_destroy(fbstab_mpc_handle_t handle);
