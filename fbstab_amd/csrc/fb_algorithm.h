@@ -480,7 +480,6 @@ struct Solver : TraceState<TRACE> {
     return lin2 > tau * tau;
   }
 
-#if !defined(FB_HOSTSIM)  // (device intrinsics; the host simulation runs solve())
   // The whole solve as ONE flat loop over "Newton iterations of this row", for
   // policies that host several QPs per wavefront (fb_mpc_r16.h).  Each trip of the
   // outer loop first lets every row run the bookkeeping between two Newton
@@ -953,7 +952,7 @@ struct Solver : TraceState<TRACE> {
           norms_at(t, sigma, true, &Et, &Eot);
         }
       }
-#if defined(FB_CLOCKSTAMP) && !defined(FB_HOSTSIM)
+#if defined(FB_CLOCKSTAMP)
       {  // histogram of backtracking depth (row level), diagnostic builds only
         int depth = 0;
         for (double tq = t; tq < 0.999; tq /= o.beta) depth++;
@@ -980,7 +979,6 @@ struct Solver : TraceState<TRACE> {
     }
   }
 
-#endif  // !FB_HOSTSIM
 
   // FBstabAlgorithm::Solve (impl:113-224).
   FB_DEV void solve(fbstab_solver_out_t* out) const {

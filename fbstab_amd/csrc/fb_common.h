@@ -3,11 +3,13 @@
 // penalised Fischer-Burmeister function and its generalised gradient.
 //
 // The kernels are written against the small `Ctx` abstraction below instead of
-// raw threadIdx/__syncthreads so that the very same solver logic can also be
-// compiled as ordinary single-threaded C++ (FB_HOSTSIM) by tests/hostsim, which
-// lets the CPU test-suite exercise the kernel logic where no GPU exists.  That
-// build is a debugging aid owned by tests/; the product library contains the
-// gfx950 code only and has no CPU execution path.
+// raw threadIdx/__syncthreads, with the thread count as a template parameter: the
+// flat-vector solver logic is therefore also well-formed for a workgroup of ONE
+// thread, which is what tests/hostsim compiles with g++ against its own stand-in
+// for <hip/hip_runtime.h> (tests/hostsim/shim) so that the CPU test-suite can step
+// through the kernels' arithmetic where no GPU exists.  That build is a debugging
+// aid owned by tests/ and everything host-specific lives there; the product
+// library contains the gfx950 code only and has no CPU execution path.
 #pragma once
 
 #include <math.h>
@@ -15,15 +17,10 @@
 
 #include "../../include/fbstab_types.h"
 
-#if defined(FB_HOSTSIM)
-#define FB_DEV inline
-#define FB_LDS
-#else
 #include <hip/hip_runtime.h>
 #define FB_DEV __device__ __forceinline__
 // Explicit LDS address space: every access through an lds_ptr is a ds_* op.
 #define FB_LDS __attribute__((address_space(3)))
-#endif
 
 namespace fbk {
 
@@ -32,7 +29,7 @@ typedef FB_LDS double* lds_ptr;
 // In-kernel phase timing for diagnostic builds (-DFB_STAMP): per-phase shader
 // cycles summed over all waves into g_stamps (read with
 // fbstab_hip_debug_stamps).  Production builds compile the macro away.
-#if defined(FB_STAMP) && !defined(FB_HOSTSIM)
+#if defined(FB_STAMP)
 extern __device__ unsigned long long g_stamps[32];
 struct StampClock {
   unsigned long long t0;
@@ -51,7 +48,7 @@ struct StampClock {
 #define FB_STAMP_DECL StampClock fb_clk_; fb_clk_.start()
 #define FB_STAMP_LAP(k) fb_clk_.lap(k)
 #define FB_STAMP_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], 1ull); } while (0)
-#elif defined(FB_PHASE_MARKERS) && !defined(FB_HOSTSIM)
+#elif defined(FB_PHASE_MARKERS)
 // tools/isa_ledger.py: the phase boundaries as comments in the assembly (no instruction;
 // the comment stays where the boundary is because the asm statement is volatile)
 #define FB_STAMP_DECL
@@ -63,14 +60,14 @@ struct StampClock {
 #define FB_STAMP_COUNT(k)
 #endif
 
-#if defined(FB_PHASE_MARKERS) && !defined(FB_HOSTSIM)
+#if defined(FB_PHASE_MARKERS)
 #define FB_PHASE(name) asm volatile("; FBPHASE " #name)
 #else
 #define FB_PHASE(name)
 #endif
 
 // Wave-level event counters of the light diagnostic build (-DFB_CLOCKSTAMP).
-#if (defined(FB_STAMP) || defined(FB_CLOCKSTAMP)) && !defined(FB_HOSTSIM)
+#if defined(FB_STAMP) || defined(FB_CLOCKSTAMP)
 #if !defined(FB_STAMP)
 extern __device__ unsigned long long g_stamps[32];
 #endif
@@ -129,7 +126,6 @@ struct Ctx {
   // operations stay in program order), so it waits on lgkmcnt alone and leaves
   // global loads/stores in flight; __syncthreads() would drain vmcnt too.
   FB_DEV void sync() const {
-#if !defined(FB_HOSTSIM)
 #if !defined(FB_NO_WAVE_SYNC)
     if (NT <= 64) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -139,17 +135,16 @@ struct Ctx {
     }
 #endif
     __syncthreads();
-#endif
   }
 
   // In-place reduction of K values over the NT threads; every thread gets the
   // result (bitwise identical in all threads, so branches on it are uniform).
   template <class Op, int K>
   FB_DEV void reduce(double (&v)[K]) const {
-#if !defined(FB_HOSTSIM)
     static_assert(K <= kMaxReduce, "too many values");
+    constexpr int kLanes = NT < 64 ? NT : 64;  // lanes of the (first) wavefront that hold a value
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = kLanes / 2; m >= 1; m >>= 1) {
 #pragma unroll
       for (int k = 0; k < K; k++) v[k] = Op::apply(v[k], __shfl_xor(v[k], m, 64));
     }
@@ -169,9 +164,6 @@ struct Ctx {
         v[k] = s;
       }
     }
-#else
-    (void)v;
-#endif
   }
   // argmax with ties resolved to the SMALLEST index (Eigen's maxCoeff(&index)
   // returns the first maximum): one pass over (value, index) pairs.
@@ -181,7 +173,6 @@ struct Ctx {
     v = take ? ov : v;
     ix = take ? oi : ix;
   }
-#if !defined(FB_HOSTSIM)
   template <int CTRL>
   static FB_DEV void better_dpp(double& v, int& ix) {
     const double ov = __builtin_amdgcn_update_dpp(0.0, v, CTRL, 0xf, 0xf, true);
@@ -208,9 +199,7 @@ struct Ctx {
     v = bv;
     ix = bi;
   }
-#endif
   FB_DEV void argmax_first(double* val, int* idx) const {
-#if !defined(FB_HOSTSIM)
     double v = *val;
     int ix = *idx;
     wave_argmax_first(v, ix);
@@ -235,7 +224,6 @@ struct Ctx {
     }
     *val = v;
     *idx = ix;
-#endif
   }
   template <int K>
   FB_DEV void sum(double (&v)[K]) const { reduce<OpSum, K>(v); }
@@ -263,9 +251,6 @@ FB_DEV double sat(double x, double lo, double hi) {
 // is NOT turned into NaN - it comes back as it is, like the other inputs outside the
 // +normal / +denormal classes; a caller that can produce one must test for it itself.
 FB_DEV double fsqrt(double x) {
-#if defined(FB_HOSTSIM)
-  return sqrt(x);
-#else
   const double r = __builtin_amdgcn_rsq(x);
   double g = x * r, h = 0.5 * r;
   const double d = fma(-h, g, 0.5);
@@ -274,7 +259,6 @@ FB_DEV double fsqrt(double x) {
   const double e = fma(-g, g, x);
   g = fma(e, h, g);
   return __builtin_amdgcn_class(x, 0x180 /* +denormal | +normal */) ? g : x;
-#endif
 }
 
 // phi(a,b) = alpha (a + b - sqrt(a^2+b^2)) + (1-alpha) max(0,a) max(0,b)
@@ -313,14 +297,10 @@ FB_DEV void pfb_gradient(double a, double b, double alpha, double* g0, double* g
 // divides but parity is by tolerance (never on a value that feeds a branch
 // directly).
 FB_DEV double rcp_fast(double x) {
-#if defined(FB_HOSTSIM)
-  return 1.0 / x;
-#else
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
-#endif
 }
 
 // phi(a,b) and its generalised gradient from ONE sqrt and ONE reciprocal

@@ -58,10 +58,7 @@ struct DenseLayout {
   // pivot bookkeeping sit behind it.
   int wave, o_rowbuf, o_dpiv, o_ord;
 
-#if !defined(FB_HOSTSIM)
-  __host__ __device__
-#endif
-  void init(int nz_, int nl_, int nv_, int nthreads) {
+  __host__ __device__ void init(int nz_, int nl_, int nv_, int nthreads) {
     wave = nz_ + nl_ <= 64;
     carve(nz_, nl_, nv_, nthreads, 0, 0);
     if ((long)lds_doubles * 8 > 160 * 1024 || k_doubles > (1L << 30)) {
@@ -71,10 +68,7 @@ struct DenseLayout {
     }
   }
 
-#if !defined(FB_HOSTSIM)
-  __host__ __device__
-#endif
-  void carve(int nz_, int nl_, int nv_, int nthreads, int kg, int vg) {
+  __host__ __device__ void carve(int nz_, int nl_, int nv_, int nthreads, int kg, int vg) {
     nz = nz_; nl = nl_; nv = nv_; nk = nz + nl;
     k_doubles = (long)nk * nk;
     k_global = kg;
@@ -293,8 +287,9 @@ struct DenseProblem {
       c.max(bad);
       if (bad[0] != 0.0) return false;
     }
-#if !defined(FB_HOSTSIM)
-    if constexpr (!KGLOBAL) {
+    // (the one-wavefront and the fused factorisations need a wavefront: a workgroup narrower than one -
+    //  tests/hostsim's single thread - takes the general loop)
+    if constexpr (!KGLOBAL && C::nt >= 64) {
       if (lay.wave) {
         // (the verdict travels through LDS: the other wavefronts wait at the barrier)
         FB_LDS int* okw = (FB_LDS int*)(lds + lay.o_ord) + 64;
@@ -306,14 +301,14 @@ struct DenseProblem {
         return *okw != 0;
       }
     }
-    if (!KGLOBAL && C::nt > 64 && lay.nk <= 64) return ldlt_fused(c);
-#endif
+    if constexpr (!KGLOBAL && C::nt > 64) {
+      if (lay.nk <= 64) return ldlt_fused(c);
+    }
     // (running the whole factorisation on one wavefront was measured too: 27.3 ms
     // against 23.3 on config 2 - the trailing update wants the four of them)
     return ldlt_impl(c);
   }
 
-#if !defined(FB_HOSTSIM)
   // Pivoted LDL' for n <= 64 on ONE wavefront with the matrix in registers: lane t
   // holds row t of the (full, symmetric) trailing matrix, Kr[j] = K[t][j].  Same
   // pivot rule as Eigen::LDLT (largest |diagonal| of what is left, the first maximum
@@ -456,9 +451,7 @@ struct DenseProblem {
     if (in) rhs[t] = x;
     c.sync();
   }
-#endif
 
-#if !defined(FB_HOSTSIM)
   // ldlt_impl for n <= 64 on a multi-wavefront workgroup with its phases fused:
   // the scaling of column k-1 rides along with the pivot search of step k (they
   // touch different entries), the search itself is DPP + v_readlane in the first
@@ -524,7 +517,6 @@ struct DenseProblem {
     }
     return true;
   }
-#endif
   FB_DEV void ldlt_solve(const C& c) const {
     on_first_wave(c, [&](const auto& w) {
       typedef typename std::remove_cv<typename std::remove_reference<decltype(w)>::type>::type W;
@@ -540,7 +532,6 @@ struct DenseProblem {
     });
   }
 
-#if !defined(FB_HOSTSIM)
   // One-wavefront substitutions for n <= 64 (same formulas as ldlt_solve_impl):
   // the right-hand side stays in registers, lane t owning entry t, the solved
   // entry is handed round by v_readlane, and the L columns are fetched from LDS
@@ -594,10 +585,6 @@ struct DenseProblem {
     if (in) rhs[pi] = x;  // P' w
     c.sync();
   }
-#else
-  template <class W>
-  FB_DEV void ldlt_solve_wave(const W& c) const { ldlt_solve_impl(c); }
-#endif
 
   // Pivoted LDL' of the lower triangle of K in place (Eigen::LDLT semantics).
   template <class W>
@@ -612,7 +599,6 @@ struct DenseProblem {
         const double a = fabs(K[i + i * n]);
         if (a > best) { best = a; p = i; }  // i ascending: first maximum kept
       }
-#if !defined(FB_HOSTSIM)
       if (W::nt > 64 && n - k <= 64) {
         // every candidate sits in the first wavefront: it decides, the others
         // read the result after the barrier below
@@ -623,7 +609,6 @@ struct DenseProblem {
         c.sync();
         p = perm[k];
       } else
-#endif
       {
         c.argmax_first(&best, &p);
         if (c.tid == 0) perm[k] = p;
@@ -728,7 +713,7 @@ struct DenseProblem {
     FB_WAVE_LAP(10);
     // K = [H + sigma I + A'Gamma A  .; G  -sigma I] (lower; :52-69) and the
     // eliminated right-hand side (:98-104).
-#if !defined(FB_HOSTSIM) && !defined(FB_DENSE_NO_MFMA)
+#if !defined(FB_DENSE_NO_MFMA)
     if (lay.a_lds && (C::nt & 63) == 0 && nz <= 64 && (nv & 3) == 0) {
       // E = H + sigma I + A' Gamma A on the matrix cores: one QP per workgroup, so
       // v_mfma_f64_16x16x4 fits - the 16x16 tiles of the lower triangle of the

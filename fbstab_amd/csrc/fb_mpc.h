@@ -60,10 +60,7 @@ struct MpcLayout {
   int wglobal, launch_lds_doubles;
   long v_carve;
 
-#if !defined(FB_HOSTSIM)
-  __host__ __device__
-#endif
-  void init(int N_, int nx_, int nu_, int nc_, int nthreads) {
+  __host__ __device__ void init(int N_, int nx_, int nu_, int nc_, int nthreads) {
     N = N_; nx = nx_; nu = nu_; nc = nc_;
     ns = nx + nu;
     nz = (N + 1) * ns;
@@ -124,11 +121,7 @@ struct MpcLayout {
 // the same synchronisation serves both.
 template <class C, bool WGLOBAL = false>
 struct MpcProblem {
-#if defined(FB_HOSTSIM)
-  typedef lds_ptr mptr;
-#else
   typedef typename std::conditional<WGLOBAL, double*, lds_ptr>::type mptr;
-#endif
   static constexpr bool kFusedTrial = false;  // see fb_algorithm.h
   static constexpr bool kOwnVectorOps = false;  // the Solver loops over the flat vectors below
   static constexpr bool kCanRefine = true;      // linear_residual2() / refine_step() below

@@ -14,12 +14,13 @@ _SO = os.path.join(_HERE, "libhostsim.so")
 
 def build():
     src = os.path.join(_HERE, "hostsim.cc")
-    deps = [src] + [os.path.join(_HERE, "..", "..", "fbstab_amd", "csrc", f)
-                    for f in ("fb_common.h", "fb_algorithm.h", "fb_mpc.h", "fb_dense.h")]
+    shim = os.path.join(_HERE, "shim")  # <hip/hip_runtime.h> for a host of one thread
+    deps = [src, os.path.join(shim, "hip", "hip_runtime.h")] + [
+        os.path.join(_HERE, "..", "..", "fbstab_amd", "csrc", f) for f in ("fb_common.h", "fb_algorithm.h", "fb_mpc.h", "fb_dense.h")]
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared",
-                           "-ffp-contract=off", "-o", _SO, src])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + shim,
+                           "-Wno-attributes", "-Wno-unknown-pragmas", "-o", _SO, src])
 
 
 class HostSim:

@@ -1,10 +1,10 @@
-// TEST INFRASTRUCTURE ONLY — single-threaded host compilation of the device
-// solver logic (fbstab_amd/csrc/fb_*.h with FB_HOSTSIM: one "thread", barriers
-// and workgroup reductions become no-ops).  It lets the CPU test-suite check
-// the kernel's arithmetic against the oracle where no GPU exists.  It is built
-// by tests/ only, is not part of libfbstab_hip.so, and the product never loads
-// it: the HIP library has no CPU execution path.
-#define FB_HOSTSIM 1
+// TEST INFRASTRUCTURE ONLY - single-threaded host compilation of the device solver logic: the flat-vector
+// headers of fbstab_amd/csrc instantiated for a workgroup of ONE thread (Ctx<1>) and compiled by g++ against
+// tests/hostsim/shim/hip/hip_runtime.h, the stand-in for the device environment (lane exchanges return the
+// caller's value, barriers are nothing).  It lets the CPU test-suite check the kernels' arithmetic against the
+// oracle where no GPU exists.  It is built by tests/ only, is not part of libfbstab_hip.so, and the product
+// never loads it: the HIP library has no CPU execution path, and its headers carry no host branch.
+#define FB_DENSE_NO_MFMA 1  // (the K assembly on the matrix cores needs four wavefronts; the scalar loop is the same sum)
 #include <cstring>
 #include <vector>
 
