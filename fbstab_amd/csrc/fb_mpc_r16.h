@@ -496,9 +496,7 @@ struct MpcR16 {
     cur = off;
   }
   static FB_DEV void stage_pack_s(const C& c, const double* pack0, lds_ptr& view, int& cur, int off) {
-#if !defined(FB_R16_ALWAYS_STAGE)  // (experiment: what staging a matrix copy at every stage costs a time-invariant plant)
     if (off == cur) return;
-#endif
     cur = off;
     lds_ptr dst = view;
     const double* src = pack0 + off;
@@ -2089,22 +2087,11 @@ struct MpcR16 {
   // fbstab_algorithm-impl.h:283-290).  Returns false on a non-positive pivot
   // (riccati_linear_solver.cc:131-136).
   struct FwdIn {
-#if defined(FB_R16_EXTRA_READS)
-    dbl2 junk[3];
-#endif
     dbl2 zr, dw, lr, dwl;
     dbl2 vy[KS], da[KS];
     double vb[KS];
   };
   static FB_DEV void load_fwd(const double* R, const double* Rd, FwdIn& in) {
-#if defined(FB_R16_EXTRA_READS)
-    // (experiment: up to three more slot pairs per stage and forward sweep - pairs no sweep touches: ybar,
-    //  (f h), b - requested with the stage's own and thrown away where the stage's own are used, a stage
-    //  later: what a per cent of record READS costs)
-    in.junk[0] = ld2(R, sYB);
-    if constexpr (FB_R16_EXTRA_READS > 1) in.junk[1] = ld2(R, sF);
-    if constexpr (FB_R16_EXTRA_READS > 2) in.junk[2] = ld2(R, sB);
-#endif
     in.zr = ld2(R, sZ);
     in.dw = ld2(R, sDZ);
     in.lr = ld2(R, sL);
@@ -2285,11 +2272,6 @@ struct MpcR16 {
           if constexpr (kStoreGamma) st2(Rs, sGAM + 2 * s, Gam[s], Rvm[s]);
         }
       });
-#if defined(FB_R16_EXTRA_READS)
-      asm volatile("" ::"v"(cur.junk[0]));
-      if constexpr (FB_R16_EXTRA_READS > 1) asm volatile("" ::"v"(cur.junk[1]));
-      if constexpr (FB_R16_EXTRA_READS > 2) asm volatile("" ::"v"(cur.junk[2]));
-#endif
       // pending step on (z, rz), (l, rl); eliminated right-hand side (:222-225)
       const double zz = fma(tp, cur.dw[0], cur.zr[0]);
       const double rzz = fma(tp, cur.dw[1], cur.zr[1]);
@@ -2448,13 +2430,6 @@ struct MpcR16 {
       else tvec = bc_dot<0, NS, RQ>(XR, gv);
       Xp[nXs] = tvec;
       stv<fX, nXs + 1>(R, Xp);
-#if defined(FB_R16_EXTRA_WRITES)
-      if constexpr (ROW) {  // (experiment: what a slot pair WRITTEN per stage costs - the row form leaves the
-                            //  inv(Pi) slots of the record unused)
-        st2(R, fP, Xp[0], Xp[1]);
-        if constexpr (FB_R16_EXTRA_WRITES > 1) st2(R, fP + 2, Xp[2], Xp[3]);
-      }
-#endif
       FB_STAMP_LAP(5);
       FB_SB();
       // theta(i+1) partial = -W t.  (Outside the branch below on purpose: with W used
