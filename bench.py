@@ -55,11 +55,17 @@ FP64_PEAK_TFLOPS = 78.6        # AMD public MI355X FP64 vector/matrix spec
 
 def cpu_baseline(sample_qps: int):
     """The oracle (CPU restatement, -O3) on a bounded sample of the same
-    workload: OpenMP-over-batch on all host cores, plus one thread."""
+    workload: OpenMP-over-batch on the host cores the process is granted (`cores` = the
+    threads used), plus one thread."""
     from tools import fixtures as fx
     from oracle.oracle_py import Oracle
     orc = Oracle(False)
     cores = orc.num_threads()
+    # (a cgroup that grants fewer CPUs than the box shows: more threads than the grant only take turns)
+    quota = cgroup_cpu_quota()
+    if quota is not None and quota >= 1.0:
+        cores = max(1, min(cores, int(quota + 0.999)))
+    cores = max(1, min(cores, len(os.sched_getaffinity(0))))
     p = fx.synthetic_mpc_batch(sample_qps)
     orc.solve_mpc(fx.synthetic_mpc_batch(2 * cores), nthreads=cores)  # warm threads
     t0 = time.perf_counter()
