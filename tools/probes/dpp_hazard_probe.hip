@@ -27,6 +27,18 @@
     out[lane] = acc;                                                                             \
     out[64 + lane] = yy;                                                                         \
   }
+// the same with a single-pass producer (v_mov_b64: the FP64 multiply above occupies the pipe for two passes)
+#define RULE1B(NAME, WAIT)                                                                       \
+  __global__ void NAME(const double* in, double* out) {                                          \
+    const int lane = threadIdx.x;                                                                \
+    double y = in[lane], acc = 0.25 * lane, yy = -7.0 - lane, one = 1.0;                         \
+    asm volatile("s_nop 7\n\t"                                                                   \
+                 "v_mov_b64 %[yy], %[y]\n\t" WAIT FMAC "s_nop 7"                                 \
+                 : [yy] "+v"(yy), [acc] "+v"(acc)                                                \
+                 : [y] "v"(y), [one] "v"(one));                                                  \
+    out[lane] = acc;                                                                             \
+    out[64 + lane] = yy;                                                                         \
+  }
 #define RULE3(NAME, WAIT)                                                                        \
   __global__ void NAME(const double* in, double* out) {                                          \
     const int lane = threadIdx.x;                                                                \
@@ -68,6 +80,7 @@
 
 #define ALL(R, P) R(P##0, W0) R(P##1, W1) R(P##2, W2) R(P##3, W3) R(P##4, W4) R(P##5, W5) R(P##6, W6) R(P##8, W8)
 ALL(RULE1, r1_)
+ALL(RULE1B, r1b_)
 ALL(RULE2, r2_)
 ALL(RULE3, r3_)
 
@@ -107,9 +120,11 @@ int main() {
   (void)hipMalloc(&dout, 128 * sizeof(double));
   (void)hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice);
   kern_t k1[8] = {r1_0, r1_1, r1_2, r1_3, r1_4, r1_5, r1_6, r1_8};
+  kern_t k1b[8] = {r1b_0, r1b_1, r1b_2, r1b_3, r1b_4, r1b_5, r1b_6, r1b_8};
   kern_t k2[8] = {r2_0, r2_1, r2_2, r2_3, r2_4, r2_5, r2_6, r2_8};
   kern_t k3[8] = {r3_0, r3_1, r3_2, r3_3, r3_4, r3_5, r3_6, r3_8};
   const int s1 = run_rule("rule 1: v_mul_f64 writes the DPP source pair, then v_fmac_f64_dpp (checker requires >= 2)", k1, din, dout);
+  const int s1b = run_rule("rule 1, single-pass producer: v_mov_b64 writes the DPP source pair, then v_fmac_f64_dpp (checker requires >= 2)", k1b, din, dout);
   const int s2 = run_rule("rule 2: v_cmpx writes EXEC, then v_fmac_f64_dpp (checker requires >= 5)", k2, din, dout);
   const int s3 = run_rule("rule 3: v_rcp_f64 writes the DPP source pair, then v_fmac_f64_dpp (checker requires >= 2)", k3, din, dout);
   // sanity of the reference itself: rule 1 at 8 wait states must be acc0 + 2 y(lane 5 of the row)
@@ -119,7 +134,7 @@ int main() {
   int bad = 0;
   for (int l = 0; l < 64; l++) bad += ref[l] != 0.25 * l + 2.0 * h[(l & ~15) + 5];
   printf("reference sequence (8 wait states) against the arithmetic: %s\n", bad ? "WRONG" : "ok");
-  printf("summary: hardware-safe distances %d / %d / %d against the checker's 2 / 5 / 2: the checker is %s\n", s1, s2, s3,
-         (s1 >= 0 && s1 <= 2 && s2 >= 0 && s2 <= 5 && s3 >= 0 && s3 <= 2 && !bad) ? "at least as strict as this chip needs" : "NOT COVERING what this chip shows");
+  printf("summary: hardware-safe distances %d (%d) / %d / %d against the checker's 2 / 5 / 2: the checker is %s\n", s1, s1b, s2, s3,
+         (s1 >= 0 && s1 <= 2 && s1b >= 0 && s1b <= 2 && s2 >= 0 && s2 <= 5 && s3 >= 0 && s3 <= 2 && !bad) ? "at least as strict as this chip needs" : "NOT COVERING what this chip shows");
   return 0;
 }
