@@ -28,6 +28,8 @@ Besides the contract's keys the line carries, measured in the same run at N = 1:
                   FBstabMpc::Solve through the C++ facade (host pointers, Display::OFF) -
                   the reference's only entry (fbstab/fbstab_mpc.h:181-195) - beside the
                   CPU restatement's single-thread ms per QP
+  wide            the row-pair record instances (stage widths 17..32), one launch at a time: 2048 random
+                  time-varying QPs of (30, 20, 6, 16) on <24,8,16>, the reference's reactor N = 80 on <18,5,10>
   cpu_baseline    the oracle on the host cores (bounded sample)
 """
 import argparse
@@ -151,6 +153,73 @@ def stored_traffic(batch: int):
     return found[0][1] if found else None
 
 
+# tools/probes/issue_rate_probe.hip (profiles/r05_g_issue_rate_probe.txt): ONE wavefront alone on its SIMD - the
+# record kernel's regime, 493 registers - issues an FP64 FMA (fused with a DPP broadcast or not) every 5.25
+# cycles, any other vector instruction every ~4.5.  The ceiling below prices EVERY vector instruction at the
+# FP64 figure, as VERDICT r5 did.
+ISSUE_CYCLES_PER_VALU = 5.25
+SIMDS = 1024                   # 256 CUs x 4
+
+
+def stored_issue_counters(batch: int):
+    """SQ_INSTS_VALU per launch of the record kernel and the shader clock it ran at, REPLAYED from the newest
+    committed sq-counter summary (profiles/r*_r16_sq_counters.json; the summary taken on THIS build is
+    preferred, like stored_traffic).  Returns None when there is none for this batch size."""
+    import glob
+    sha = library_sha256()
+    found = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_r16_sq_counters.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("batch", 8192) != batch or "SQ_INSTS_VALU" not in t:
+                continue
+            same = sha is not None and t.get("library_sha256") == sha
+            found.append((same, {"valu": float(t["SQ_INSTS_VALU"]),
+                                 "clock_mhz": float(t.get("mean_shader_clock_mhz", 2155.0)),
+                                 "clock_source": "this summary" if "mean_shader_clock_mhz" in t else
+                                                 "profiles/r05_zzz_r16_wave_time_shares.txt (2155 MHz, round 5)",
+                                 "build_matches": same,
+                                 "source": "profiles/" + os.path.basename(path) + " (replayed" +
+                                           ("" if same else "; NOT the library of this run") + ")"}))
+        except (OSError, ValueError, KeyError):
+            pass
+    for same, t in found:
+        if same:
+            return t
+    return found[0][1] if found else None
+
+
+def lane_buffers(torch, dev, batch, sizes, world, rank, gather):
+    """The device buffers of ONE pipeline lane (bench.py's Lane; a function of its own so that the CPU
+    suite can run exactly this plan under gloo at world size 8, tests/test_sharding.py): the record
+    (z, l, v, y and the 5 doubles of SolverOut of a QP side by side - the gather moves ONE buffer), the
+    views the solver writes through, the SolverOut bytes, and on rank 0 the receive list whose slot `rank`
+    IS the record (the root's own block is never copied)."""
+    from fbstab_amd import sharding
+    nz, nl, nv = sizes
+    nvar = nz + nl + 2 * nv
+    rec = torch.zeros((batch, nvar + sharding.OUT_DOUBLES), dtype=torch.float64, device=dev)
+    b = dict(rec=rec, x=rec[:, :nvar], z=rec[:, :nz], l=rec[:, nz:nz + nl], v=rec[:, nz + nl:nz + nl + nv],
+             y=rec[:, nz + nl + nv:nvar], out=torch.zeros((batch, 40), dtype=torch.uint8, device=dev), grec=None)
+    if gather and rank == 0:
+        b["grec"] = [rec if g == rank else torch.empty_like(rec) for g in range(world)]
+    return b
+
+
+def memory_plan(world, lanes, batch, sizes, data_bytes_per_qp, scratch_bytes_per_handle, rank=0):
+    """Bytes of HBM `rank` holds while the headline runs with `lanes` steps in flight (the plan main()
+    executes; asserted to fit for --gpus 8 by tests/test_sharding.py and stated in DESIGN.md section 6):
+    the resident problem data, per lane the record, the SolverOut bytes and the solver handle's scratch,
+    and on rank 0 the other ranks' receive buffers of every lane."""
+    nz, nl, nv = sizes
+    rec = batch * (nz + nl + 2 * nv + 5) * 8
+    per_lane = rec + batch * 40 + scratch_bytes_per_handle
+    recv = (world - 1) * rec * lanes if rank == 0 and world > 1 else 0
+    return dict(data=batch * data_bytes_per_qp, lanes=lanes * per_lane, receive=recv,
+                total=batch * data_bytes_per_qp + lanes * per_lane + recv, record_bytes=rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,20 +273,11 @@ def main():
             # (every lane's handle is told how many lanes share the device: fbstab_hip_mpc_create_in_flight)
             self.solver = hip_api.FBstabMpcBatch(*p.sizes(), max_batch=p.batch, device=local_rank, handles_in_flight=lanes)
             self.stream = torch.cuda.Stream(device=dev)
-            nvar = p.nz + p.nl + 2 * p.nv
-            # z, l, v, y and the SolverOut record (5 doubles) of a QP side by side: the
-            # gather moves ONE buffer
-            self.rec = torch.zeros((p.batch, nvar + sharding.OUT_DOUBLES), dtype=torch.float64, device=dev)
-            self.x = self.rec[:, :nvar]
-            self.z, self.l = self.rec[:, :p.nz], self.rec[:, p.nz:p.nz + p.nl]
-            self.v = self.rec[:, p.nz + p.nl:p.nz + p.nl + p.nv]
-            self.y = self.rec[:, p.nz + p.nl + p.nv:nvar]
-            self.out = torch.zeros((p.batch, 40), dtype=torch.uint8, device=dev)
-            self.grec = None
-            if gather and rank == 0:
-                # rank 0's own block is already where it has to be: its slot of the receive list IS its
-                # record (the gather then moves the other ranks' blocks only)
-                self.grec = [self.rec if g == rank else torch.empty_like(self.rec) for g in range(world)]
+            # (rank 0's own block is already where it has to be: its slot of the receive list IS its
+            # record - the gather then moves the other ranks' blocks only)
+            b = lane_buffers(torch, dev, p.batch, (p.nz, p.nl, p.nv), world, rank, gather)
+            self.rec, self.x, self.z, self.l, self.v, self.y = b["rec"], b["x"], b["z"], b["l"], b["v"], b["y"]
+            self.out, self.grec = b["out"], b["grec"]
             self.events = []
 
     def run_mpc(p, data, P, steps, warmup, gather):
@@ -311,6 +371,7 @@ def main():
         blocks["dense"] = bench_dense(torch, dev, fx, hip_api)
         blocks["receding"] = bench_receding(torch, dev, fx, hip_api)
         blocks["latency"] = bench_latency(torch, dev, fx, hip_api)
+        blocks["wide"] = bench_wide(torch, dev, fx, hip_api)
     if dist is not None and args.extras != 0 and (world > 1 or os.environ.get("FBSTAB_BENCH_SHARDED_SWEEP") == "1"):
         # N > 1: configs[4] sharded by trajectory (every rank takes part: one gather at
         # the end).  (The environment variable rehearses this branch with one rank.)
@@ -328,6 +389,10 @@ def main():
         achieved = ALG_BYTES_PER_QP * B * world / per_step_s / 1e9 / world  # per GPU
         k_ms = head["kernel_ms"]
         tr = stored_traffic(B)
+        ic = stored_issue_counters(B)
+        # the ceiling of the instruction stream: every SIMD issuing this launch's vector instructions back to
+        # back at the probed rate of a lone wavefront, at the clock the kernel ran at
+        issue_qps = (B / (ic["valu"] * ISSUE_CYCLES_PER_VALU / SIMDS / (ic["clock_mhz"] * 1e6))) if ic else None
         traffic = tr["corrected"] if tr else None
         rec = {
             "metric": "QPs/sec (batched MPC N=30 nx=12 nu=4 nc=20)",
@@ -346,8 +411,24 @@ def main():
             # batch (ms_per_step), per GPU; the per-launch figure (duration of one launch
             # as HIP events and rocprof see it, with `launches_in_flight` sharing the GPU)
             # is the named extra
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # `bound`: whichever of the two measured ceilings is the lower one - the memory wall of the record
+            # traffic (hbm_ceiling_qps) or the issue rate of the kernel's own instruction stream
+            # (issue_bound_qps): "hbm" or "issue".  achieved / peak / frac stay the ALGORITHMIC bytes over
+            # the HBM peak whatever the bound is called (the contract's accounting).
+            "roofline": {"bound": ("issue" if (issue_qps is not None and tr is not None and
+                                               issue_qps < B / (tr["corrected"] / HBM_ACHIEVABLE_BPS)) else "hbm"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "issue_bound_qps": issue_qps,
+                         "issue_bound": ({"valu_instructions_per_launch": ic["valu"],
+                                          "cycles_per_instruction": ISSUE_CYCLES_PER_VALU,
+                                          "cycles_source": "tools/probes/issue_rate_probe.hip (profiles/r05_g_issue_rate_probe.txt): "
+                                                           "one wavefront per SIMD, FP64 FMA fused with a DPP broadcast or not",
+                                          "simds": SIMDS, "shader_clock_mhz": ic["clock_mhz"],
+                                          "clock_source": ic["clock_source"], "counter_source": ic["source"],
+                                          "build_matches": ic["build_matches"],
+                                          "frac_of_issue_bound": (world * B * args.steps / elapsed / world) / issue_qps}
+                                         if ic else None),
                          # corrected counter bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), the raw
                          # sum beside it, their ratio to the algorithmic bytes and the regime the
                          # counters were taken in (the profiler serialises dispatches)
@@ -606,6 +687,67 @@ def bench_receding(torch, dev, fx, hip_api, trajectories=4096, steps=200, dist=N
            "host_syncs_per_step": 0}
     s.close()
     return res
+
+
+def mpc_alg_bytes(N, nx, nu, nc):
+    """Algorithmic bytes of one MPC QP (SURVEY 8d's accounting for any shape): the problem data, the guess
+    (z, l, v), the solution (z, l, v, y) and the 40-byte SolverOut."""
+    data = 8 * ((N + 1) * (nx * nx + nu * nu + nu * nx + nx + nu + nc * nx + nc * nu + nc) +
+                N * (nx * nx + nx * nu + nx) + nx)
+    nz, nl, nv = (N + 1) * (nx + nu), (N + 1) * nx, (N + 1) * nc
+    return data + 8 * (nz + nl + nv) + 8 * (nz + nl + 2 * nv) + 40
+
+
+def bench_wide(torch, dev, fx, hip_api, reps=3):
+    """The row-pair record instances (stage widths 17..32), one launch at a time, device pointers
+    (the kernel furthest below its roofline had no driver number):
+      ltv_30_20_6_16   2048 random time-varying QPs of (N, nx, nu, nc) = (30, 20, 6, 16) - 64 distinct problems
+                       tiled over the batch, tools/shape_bench.py's workload - on fbstab_mpc_r32_kernel<24,8,16>;
+      reactor_N80      1024 perturbed CopolymerizationReactor problems, N = 80, nx = 18, nu = 5, nc = 10
+                       (fbstab/test/ocp_generator.cc:73-174; tools/reactor_bench.py) on <18,5,10>.
+    `roofline`: the shape's own algorithmic bytes over the launch's duration against the HBM peak."""
+    out = {}
+    def run(name, p, what):
+        N, nx, nu, nc = p.sizes()
+        B = p.batch
+        s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+        data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
+        mk = lambda n: torch.zeros((B, n), dtype=torch.float64, device=dev)
+        ms = []
+        for rep in range(reps + 1):   # (the first launch is the handle's warm-up)
+            z, l, v, y = mk(p.nz), mk(p.nl), mk(p.nv), mk(p.nv)
+            o = hip_api.out_to_numpy(s.Solve(data, z, l, v, y))
+            if rep:
+                ms.append(s.last_kernel_ms())
+        k_ms = float(np.median(ms))
+        ab = mpc_alg_bytes(N, nx, nu, nc)
+        ach = ab * B / (k_ms * 1e-3) / 1e9
+        out[name] = {"workload": what, "shape": [N, nx, nu, nc], "batch": B, "kernel": s.kernel_name(),
+                     "value": B / (k_ms * 1e-3), "unit": "QPs/sec", "kernel_ms": k_ms, "launches_timed": reps,
+                     "mean_newton_iters": float(o["newton_iters"].mean()),
+                     "us_per_newton_step_and_qp": 1e3 * k_ms / (B * float(o["newton_iters"].mean())),
+                     "all_converged": bool((o["eflag"] == 0).all()), "not_converged": int((o["eflag"] != 0).sum()),
+                     "launch": s.query(),
+                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_qp": ab}}
+        s.close()
+        del data
+        torch.cuda.empty_cache()
+    one = fx.random_ltv_mpc(np.random.default_rng(5), 64, 30, 20, 6, 16)
+    p = fx.MpcProblem(30, 20, 6, 16)
+    p.arrays = {k: np.ascontiguousarray(np.tile(a, (32, 1))) for k, a in one.arrays.items()}
+    run("ltv_30_20_6_16", p, "2048 random time-varying QPs (64 distinct, tiled), N=30 nx=20 nu=6 nc=16, dense constraint rows, cold start")
+    gen = fx.OcpGenerator()
+    gen.CopolymerizationReactor(80)
+    one = gen.GetFBstabInput()
+    N, nx, nu, nc = one.sizes()
+    B = 1024
+    rng = np.random.default_rng(3)
+    p = fx.MpcProblem(N, nx, nu, nc)
+    p.arrays = {k: np.ascontiguousarray(np.broadcast_to(a, (B, a.shape[1]))).copy() for k, a in one.arrays.items()}
+    p.arrays["x0"] = p.arrays["x0"] * (1.0 + 0.2 * rng.standard_normal((B, nx)))
+    run("reactor_N80", p, "1024 CopolymerizationReactor problems (the reference's, N=80 nx=18 nu=5 nc=10), x0 perturbed by 20 %, cold start")
+    return out
 
 
 if __name__ == "__main__":

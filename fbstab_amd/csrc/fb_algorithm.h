@@ -322,7 +322,8 @@ struct Solver : TraceState<TRACE> {
           return Eo;
         }
         if constexpr (can_refine_of<P>::value) {
-          if (wants_refinement(p.linear_residual2(c, sigma), tol, combo_tol_)) {
+          // (the leftover is a pass over z and l plus a reduction: not evaluated with the option off)
+          if (o.reserved > 0 && wants_refinement(p.linear_residual2(c, sigma), tol, combo_tol_)) {
             p.refine_step(c, sigma);
             refined_++;
           }
@@ -389,7 +390,10 @@ struct Solver : TraceState<TRACE> {
         *fail = true;
         return Eo;
       }
-      if (wants_refinement(lin2, tol, o.abs_tol)) p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+      if (wants_refinement(lin2, tol, combo_tol_)) {
+        p.refine_step(c, sigma, o.alpha, &ti2, &to2, &lin2);
+        refined_++;
+      }
       (*newton_iters)++;
       FB_STAMP_LAP(17);
       FB_STAMP_COUNT(31);

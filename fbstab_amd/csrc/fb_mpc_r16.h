@@ -576,6 +576,20 @@ struct MpcR16 {
       out(S_, k < NC, dot4<NS>(clk, zb));
     });
   }
+  // The same with zz one entry per lane (lane c holds element c): the broadcast rides in the FMA
+  // (bc_dot: the same four partial sums in the same order as dot4 over broadcast copies - bitwise equal).
+  // A slot that lies wholly inside the NC rows is valid in every lane: said at compile time.
+  template <class Out>
+  static FB_DEV void rows_of_C_times_lane(lds_ptr Cl, double zz, int r, Out&& out) {
+    sfor<0, KS>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      const int k = r + LPQ * s;
+      const int kk = (LPQ * (s + 1) <= NC || k < NC) ? k : 0;
+      double clk[NS];
+      sfor<0, NS>([&](auto Cc) { clk[decltype(Cc)::value] = Cl[decltype(Cc)::value * CS + kk]; });
+      out(S_, LPQ * (s + 1) <= NC || k < NC, bc_dot<0, NS, RQ>(clk, zz));
+    });
+  }
   static FB_DEV void C_to_lds(const C& c, lds_ptr Cl, const double (&Cc)[NC], int r) {
     c.sync();
     sfor<0, NC>([&](auto Kk) { Cl[r * CS + decltype(Kk)::value] = Cc[decltype(Kk)::value]; });
@@ -1048,6 +1062,13 @@ struct MpcR16 {
         sfor<0, TS>([&](auto J) { load_trial_v(stage_ptr(i + QW * (TS + decltype(J)::value)), Rd, in[decltype(J)::value]); });
       sfor<0, TS>([&](auto J) {
         constexpr int j = decltype(J)::value;
+        // A row that has run out of stages (the last trip) re-reads the last stage - lines the row that owns
+        // that stage has just pulled into the cache - and its terms are selected away.  (Round 6 measured two
+        // ways of saving the four selects per step length and slot, both SLOWER although shorter: such rows
+        // pointed at an all-zero spare record, no select at all - 25 instructions fewer per trip, 595 k against
+        // 627 k QP/s: the spare's lines are cold and every pass ended on a trip to HBM for data nobody uses;
+        // and the trip's arithmetic behind a branch on `live` - 46 instructions fewer, 624 k against 637 k.
+        // gpurun_out/r06_b, r06_c.)
         const bool live = i + QW * j <= N_;
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
@@ -1083,7 +1104,11 @@ struct MpcR16 {
   // so a trial pass has nothing to read of z, l, their steps and residuals - 11 of the 21 slots per stage
   // it used to move.  (Not used at t = 1, where S is the sum itself; for t <= beta the three terms cancel
   // by a factor t / (1 - t) <= 3 at most.)
-  static FB_DEV double trial_zl(double A, double S, double B, double t) { return fma(B, t * t - t, fma(A, 1.0 - t, t * S)); }
+  // Clamped at zero: where a + t b all but vanishes the three terms cancel to an absolute error of eps A and
+  // the sum can come out a hair below zero - the caller takes its root.
+  static FB_DEV double trial_zl(double A, double S, double B, double t) {
+    return fmax(0.0, fma(B, t * t - t, fma(A, 1.0 - t, t * S)));
+  }
   // Vi, Vo: the squared norms' constraint-block shares for t0 beta^k, k < K, of the owner's QP
   template <int K>
   FB_DEV void trial_v_coop(int owner, double t0, double beta, double sigma, double alpha, double (&Vi)[K],
@@ -2263,7 +2288,7 @@ struct MpcR16 {
         const int k = r + LPQ * s;
         const double vk = fma(tp, cur.da[s][0], cur.vy[s][0]);
         const double yk = fma(-tp, cur.da[s][1], cur.vy[s][1]);
-        const dbl2 bt = barrier_terms(vk, yk, cur.vb[s], sigma, alpha, k < NC);
+        const dbl2 bt = barrier_terms(vk, yk, cur.vb[s], sigma, alpha, LPQ * (s + 1) <= NC || k < NC);
         Gam[s] = bt[0];
         Rvm[s] = bt[1];
         if constexpr (!REFINE) {  // (the refinement sweep finds all of this in the record: tp = 0)
@@ -2369,12 +2394,20 @@ struct MpcR16 {
       // ---- Lc = chol(K); columns of inv(Lc) and W = [A B] inv(Lc)' (AM and -P of
       // :149-175) from one pass over Lc
       double W[NS];
-      ok = chol_rows<NS, RQ>(K, ro, sigma) && ok;
-      if (!ok) { ret.loff = loff; return ret; }
       double XC[NS];
+      // (one-row instances, round 6: factorisation, inverse and W solve as ONE pass over the pivots -
+      // fb_row16.h, chol_inv_cols_solve; bitwise the two-pass results)
+      constexpr bool kFusedChol = FB_CHOL_FUSED != 0 && !kSubst && kFmacDpp<RQ> && FB_FMAC_DPP_SOLVE != 0;
+      if constexpr (kFusedChol) {
+        ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
+        ok = chol_inv_cols_solve<NS, RQ>(K, XC, W, ro, sigma) && ok;
+      } else {
+        ok = chol_rows<NS, RQ>(K, ro, sigma) && ok;
+      }
+      if (!ok) { ret.loff = loff; return ret; }
       FB_STAMP_LAP(3);
       FB_SB();
-      ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
+      if constexpr (!kFusedChol) ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
       if constexpr (kPackDma) {
         // the image has been read for the last time in this stage: the next stage's copy on its way
         dma_out = i < N_ && pnxt != loff;
@@ -2386,7 +2419,7 @@ struct MpcR16 {
       }
       if constexpr (kSubst) {
         tri_solve_right<NS, RQ>(K, W, ro);
-      } else {
+      } else if constexpr (!kFusedChol) {
         tri_inv_cols_solve<NS, RQ>(K, XC, W, ro);
       }
       FB_STAMP_LAP(4);
@@ -2460,12 +2493,19 @@ struct MpcR16 {
         // matrix copy - no select; the same holds for T and the rows of inv(Pi) below)
         FB_SB();
         FB_STAMP_LAP(7);
-        ok = chol_rows<NX, RQ>(Pn, ro, sigma) && ok;
-        if (!ok) { ret.loff = loff; return ret; }
-        FB_SB();
-        FB_PHASE(tinv12);
         double T[NX];
-        tri_inv_cols<NX, RQ>(Pn, T, ro);
+        if constexpr (FB_CHOL_FUSED != 0 && kFmacDpp<RQ>) {
+          ok = chol_inv_cols<NX, RQ>(Pn, T, ro, sigma) && ok;
+          if (!ok) { ret.loff = loff; return ret; }
+          FB_SB();
+          FB_PHASE(tinv12);
+        } else {
+          ok = chol_rows<NX, RQ>(Pn, ro, sigma) && ok;
+          if (!ok) { ret.loff = loff; return ret; }
+          FB_SB();
+          FB_PHASE(tinv12);
+          tri_inv_cols<NX, RQ>(Pn, T, ro);
+        }
         FB_SB();
         FB_PHASE(ttt);
         // inv(Pi)[r][cc] = sum_k T[k][r] T[k][cc], T[k][cc] = lane cc's T[k] (zero for k < cc)
@@ -2543,7 +2583,8 @@ struct MpcR16 {
       if constexpr (!kStoreGamma) {
         sfor<0, KS>([&](auto S_) {
           constexpr int sl = decltype(S_)::value;
-          cu.gr[sl] = barrier_terms(cu.vy[sl][0], cu.vy[sl][1], cu.vb[sl], sigma, alpha, r + LPQ * sl < NC);
+          cu.gr[sl] = barrier_terms(cu.vy[sl][0], cu.vy[sl][1], cu.vb[sl], sigma, alpha,
+                                    LPQ * (sl + 1) <= NC || r + LPQ * sl < NC);
         });
       }
       double Cc_[NC], Hr[NS], AB[NS];
@@ -2562,9 +2603,18 @@ struct MpcR16 {
       load_fac(Rp);
       FB_SB();
       // u = [A B]' dl(i+1) (zero at the terminal stage: lp = 0)
-      double lpb[NX];
-      bc_all<NX, RQ>(lp, lpb);
-      const double u = dot4<NX>(Ac, lpb);
+#ifndef FB_R16_BWD_FUSED_BC
+#define FB_R16_BWD_FUSED_BC 1  // 0: the round-5 form (a copy of the vector in every lane, plain dot products) for A/B runs
+#endif
+      constexpr bool kBwdFusedBc = FB_R16_BWD_FUSED_BC != 0;
+      double u;
+      if constexpr (kBwdFusedBc) {
+        u = bc_dot<0, NX, RQ>(Ac, lp);  // (round 6: was bc_all + dot4 - the same sums, 12 moves fewer)
+      } else {
+        double lpb[NX];
+        bc_all<NX, RQ>(lp, lpb);
+        u = dot4<NX>(Ac, lpb);
+      }
       ldv<pABc, NX>(P0 + pcur, Ac);
       c.sync();
       // column r and row r of inv(Lc), row r of inv(Pi)
@@ -2615,8 +2665,10 @@ struct MpcR16 {
         if (!rx) dli = 0.0;
       }
       FB_SB();
-      double dzb[NS];  // [dx; du](i), every lane
-      bc_all<NS, RQ>(dzu, dzb);
+      // ([dx; du](i) reaches the four products below through the fused broadcast-FMA: round 6, was a copy of
+      // it in every lane - bc_all, 16 moves - and plain dot products; bitwise the same sums)
+      [[maybe_unused]] double dzb[NS];
+      if constexpr (!kBwdFusedBc) bc_all<NS, RQ>(dzu, dzb);
       ldl<pK, NS>(Lp, Hr);
       ldl<pABr, NS>(Lp, AB);
       if constexpr (kPackDma) {
@@ -2632,7 +2684,11 @@ struct MpcR16 {
       // ---- A dz and dv (:329-341) through the LDS copy of C
       C_to_lds(c, Cl, Cc_, r);
       double dvs[KS];
-      rows_of_C_times(Cl, dzb, r, [&](auto S_, bool valid, double a) {
+      auto c_rows = [&](auto&& f) {
+        if constexpr (kBwdFusedBc) rows_of_C_times_lane(Cl, dzu, r, f);
+        else rows_of_C_times(Cl, dzb, r, f);
+      };
+      c_rows([&](auto S_, bool valid, double a) {
         constexpr int sl = decltype(S_)::value;
         double d = 0.0;
         double dt = 0.0, at = valid ? a : 0.0;  // what the record gets: the step, or (REFINE) the step + correction
@@ -2663,7 +2719,10 @@ struct MpcR16 {
       // ---- wz = H dz + G'dl + A'dv; (G'dl)_x = [A B]'dl(i+1) - dl(i)
       double w;
       {
-        double p[4] = {dot4<NS>(Hr, dzb) + (ROW ? u : u - dli), 0.0, 0.0, 0.0};
+        double hdz;
+        if constexpr (kBwdFusedBc) hdz = bc_dot<0, NS, RQ>(Hr, dzu);
+        else hdz = dot4<NS>(Hr, dzb);
+        double p[4] = {hdz + (ROW ? u : u - dli), 0.0, 0.0, 0.0};
         bc_cols_dot<NC, RQ>(Cc_, dvs, p);
         w = (p[0] + p[1]) + (p[2] + p[3]);
         if constexpr (ROW) {
@@ -2685,7 +2744,9 @@ struct MpcR16 {
       double wlv = 0.0;  // wl(i + 1)
       if (i < N_) {
         // l block i+1: wl = -(A dx + B du - dx(i+1)); trial norms (full_residual.cc:60-66)
-        const double abz = dot4<NS>(AB, dzb);
+        double abz;
+        if constexpr (kBwdFusedBc) abz = bc_dot<0, NS, RQ>(AB, dzu);
+        else abz = dot4<NS>(AB, dzb);
         wlv = rx ? -(abz - dzn) : 0.0;
         if constexpr (REFINE) wlv += cu.dwl[1];  // (dzn is the correction's: wl(i + 1) of the step + its increment)
         const double lr = lrn[1] + wlv;

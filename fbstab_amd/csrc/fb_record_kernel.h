@@ -64,7 +64,7 @@ __device__ __forceinline__ void newton_probe(P& p, const C& ctx, const fbstab_op
     ok = p.newton_step(ctx, opts.sigma0, opts.alpha);
     if constexpr (can_refine_of<P>::value) {  // the solver's own rule (Solver::wants_refinement)
       Solver<P, C> rule(p, ctx, opts);
-      if (ok && rule.wants_refinement(p.linear_residual2(ctx, opts.sigma0), opts.abs_tol, opts.abs_tol))
+      if (ok && opts.reserved > 0 && rule.wants_refinement(p.linear_residual2(ctx, opts.sigma0), opts.abs_tol, opts.abs_tol))
         p.refine_step(ctx, opts.sigma0);
     }
   }

@@ -439,6 +439,81 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
   });
 }
 
+// ---- chol_rows and tri_inv_cols[_solve] as ONE pass (round 6) ----------------------------------------
+// Step k of the column-oriented inverse needs column k of L and the reciprocal of pivot k + 1 - exactly
+// what pivot k of the factorisation has just produced.  Run together, pivot j's three streams
+//     a[m] -= L[m][j] L[r][j],   x[m] -= L[m][j] x[j],   w[m] -= L[m][j] w[j]        (m = j + 1 .. N - 1)
+// read the SAME broadcast source (lane m's L[m][j]), the next pivot's reciprocal square root is in every
+// lane when x[j + 1], w[j + 1] want it, and what the two-pass form spends on handing the factor over goes:
+// the diagonal select that parks 1 / L[j][j] in lane j's a[j] (three instructions per pivot), the
+// broadcast that fetches it back (one), and - with the negation as the multiplier's source modifier - the
+// copies -lj, -x[k], -w[k] (two each).  Same operations on the same values in the same order per
+// accumulator: bitwise the results of chol_rows + tri_inv_cols_solve.  On return a[k] = L[r][k] for k < r
+// (the diagonal slot is NOT the reciprocal here: nothing reads it), x = column r of inv(L), w = row r of
+// B inv(L)'.  The next pivot's dependent chain is spread over three times as many independent
+// instructions as in chol_rows.
+#ifndef FB_CHOL_FUSED
+#define FB_CHOL_FUSED 1
+#endif
+template <int N, int R, bool WITH_W>
+FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[N], double (&w)[WITH_W ? N : 1], int r, double diag_add) {
+  static_assert(kFmacDpp<R>, "the fused pass is written for the fused broadcast-FMA");
+  bool ok = true;
+  RsqrtChain ch;
+  double lj = 0.0;
+  sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
+  constexpr int kLevels = RsqrtChain::kStages + 2;
+  auto level = [&](auto J, auto S) {
+    constexpr int j = decltype(J)::value;
+    constexpr int lv = decltype(S)::value;
+    if constexpr (lv == 0) {
+      ch.d = bcr<R, j>(a[j]) + diag_add;  // (chol_rows: the caller's "+ diag_add I" at pivot time)
+      ok = ok && (ch.d > 0.0);
+    } else if constexpr (lv <= RsqrtChain::kStages) {
+      ch.template stage<lv - 1>();
+    } else {
+      lj = a[j] * ch.q;  // L[r][j] for r > j: the streams' broadcast source - written first, two
+      FB_SB();           // instructions ahead of its first reader at the least (the multiplies below)
+      x[j] *= ch.q;      // final: rows < j are all folded in
+      if constexpr (WITH_W) w[j] *= ch.q;
+    }
+    FB_SB();
+  };
+  sfor<0, kLevels>([&](auto S) { level(std::integral_constant<int, 0>{}, S); });
+  if constexpr (!WITH_W) asm volatile("s_nop 0");
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int cnt = N - j - 1;
+    const double ljj = lj, xj = x[j];  // this pivot's values (level 6 of the next pivot rewrites lj)
+    double wj = 0.0;
+    if constexpr (WITH_W) wj = w[j];
+    const Spread<R> src = spread<R>(ljj);
+    sfor<0, cnt>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      fmac_bcs<R, j + 1 + i, j + 1, true>(a[j + 1 + i], src, ljj);
+      fmac_bcs<R, j + 1 + i, j + 1, true, false>(x[j + 1 + i], src, xj);
+      if constexpr (WITH_W) fmac_bcs<R, j + 1 + i, j + 1, true, false>(w[j + 1 + i], src, wj);
+      if constexpr (i < kLevels) level(std::integral_constant<int, j + 1>{}, I);
+    });
+    if constexpr (j + 1 < N) {
+      sfor<(cnt < kLevels ? cnt : kLevels), kLevels>(
+          [&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
+      // (the source's multiply directly in front of its first reader: one more wait state)
+      if constexpr (cnt <= kLevels && !WITH_W) asm volatile("s_nop 0");
+    }
+  });
+  return ok;
+}
+template <int N, int R = 1>
+FB_DEV bool chol_inv_cols_solve(double (&a)[N], double (&x)[N], double (&w)[N], int r, double diag_add) {
+  return chol_inv_fused_impl<N, R, true>(a, x, w, r, diag_add);
+}
+template <int N, int R = 1>
+FB_DEV bool chol_inv_cols(double (&a)[N], double (&x)[N], int r, double diag_add) {
+  double none[1] = {0.0};
+  return chol_inv_fused_impl<N, R, false>(a, x, none, r, diag_add);
+}
+
 // ---- substitution with the row-held factor (the reference's solveInPlace; round 5) ----------------------
 // The sweeps of the one-row instances multiply with an explicitly inverted Lc (tri_inv_cols): every
 // product is an independent stream of broadcast-FMAs, but the result is forward stable only - the

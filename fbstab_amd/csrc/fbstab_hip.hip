@@ -592,7 +592,7 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
 int fbstab_hip_mpc_create_in_flight(int N, int nx, int nu, int nc, int max_batch, int device, int handles_in_flight,
                                     fbstab_mpc_handle_t* handle) {
   if (!handle) return fail(FBSTAB_HIP_ERR_ARGUMENT, "null handle pointer");
-  if (handles_in_flight < 1) return fail(FBSTAB_HIP_ERR_ARGUMENT, "handles_in_flight must be positive");
+  if (handles_in_flight < 1 || handles_in_flight > 64) return fail(FBSTAB_HIP_ERR_ARGUMENT, "handles_in_flight must be in 1..64");
   *handle = nullptr;
   // fbstab_mpc.cc:62-65
   if (N < 1 || nx < 1 || nu < 1 || nc < 1)

@@ -133,7 +133,13 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
  * with its share: each row of a wavefront then gets more QPs of the batch and the tail of the launch - rows
  * that have run out of QPs while their wavefront's last one finishes - shrinks (rows busy 0.95 instead of 0.82
  * per Newton step at eight in flight; +2.7 % throughput, and a quarter of the scratch memory: 0.44 instead
- * of 1.75 GB per handle).  handles_in_flight = 1 is fbstab_hip_mpc_create. */
+ * of 1.75 GB per handle).  handles_in_flight = 1 is fbstab_hip_mpc_create.
+ * What the share costs a handle that is then used ALONE: it keeps its fraction of the grid - one eighth of
+ * the workgroups at handles_in_flight = 8 (never fewer than one per CU), so a lone launch fills an eighth of
+ * the chip - and fbstab_hip_mpc_receding_sweep, whose one-launch form needs batch <= workgroups x QPs per
+ * workgroup, falls back to one launch per step at a batch that much smaller (same results, bitwise; slower).
+ * fbstab_hip_mpc_query reports the handle's `workgroups` and `scratch_bytes` as created, so a caller can see
+ * the share it got.  Values outside 1..64 are refused (FBSTAB_HIP_ERR_ARGUMENT). */
 int fbstab_hip_mpc_create_in_flight(int N, int nx, int nu, int nc, int max_batch, int device,
                                     int handles_in_flight, fbstab_mpc_handle_t* handle);
 int fbstab_hip_mpc_destroy(fbstab_mpc_handle_t handle);

@@ -100,8 +100,11 @@ typedef struct fbstab_options_t {
   int check_feasibility;       /* bool */
   int nonmonotone_linesearch;  /* bool */
   int display_level;           /* enum fbstab_display */
-  int reserved;                /* 0.  (k > 0: the MPC kernels refine a Newton step whose linear residual exceeds
-                                * 2^(1 - k) of the tolerance in play - fbstab_hip.h, fbstab_hip_mpc_refined_steps.) */
+  int reserved;                /* MUST BE 0 unless iterative refinement is wanted (a caller that fills the struct by
+                                * hand: zero it first or start from fbstab_options_default).  k in 1..60: the MPC
+                                * kernels refine a Newton step whose linear residual exceeds 2^(1 - k) of the
+                                * tolerance in play - fbstab_hip.h, fbstab_hip_mpc_refined_steps.  Anything outside
+                                * 0..60 is reset to 0 (off) by fbstab_options_validate. */
 } fbstab_options_t;
 
 /* AlgorithmParameters::DefaultParameters, fbstab_algorithm-impl.h:33-59. */
@@ -175,6 +178,8 @@ static inline void fbstab_options_validate(fbstab_options_t* o) {
   o->max_prox_iters = fbstab_imax_(o->max_prox_iters, 1);
   o->max_inner_iters = fbstab_imax_(o->max_inner_iters, 1);
   o->max_linesearch_iters = fbstab_imax_(o->max_linesearch_iters, 1);
+  /* (not one of the reference's options: an uninitialised value must not switch refinement on) */
+  if (o->reserved < 0 || o->reserved > 60) o->reserved = 0;
 }
 
 #ifdef __cplusplus

@@ -57,10 +57,12 @@ def reliable_options(**kw) -> Options:
     return o
 
 
-def build(ref: bool = False, quiet: bool = True) -> None:
-    """``make`` (and ``make ref`` when the reference tree is present)."""
+def build(ref: bool = False, quiet: bool = True, fma: bool = False) -> None:
+    """``make`` (and ``make ref`` when the reference tree is present, ``make fma`` on request)."""
     out = subprocess.DEVNULL if quiet else None
     subprocess.check_call(["make", "-C", _HERE], stdout=out)
+    if fma:
+        subprocess.check_call(["make", "-C", _HERE, "fma"], stdout=out)
     if ref and os.path.isdir(REFERENCE_ROOT):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=out)
 
@@ -78,11 +80,14 @@ def _p(a: Optional[np.ndarray]):
 class Oracle:
     """Handle on one of the two oracle libraries."""
 
-    def __init__(self, use_reference_loop: bool = False):
-        path = (os.path.join(_HERE, "_ref", "libfbstab_ref.so")
-                if use_reference_loop else os.path.join(_HERE, "liboracle.so"))
+    def __init__(self, use_reference_loop: bool = False, fma: bool = False):
+        """``fma``: liboracle_fma.so - the same sources compiled with fused multiply-adds allowed
+        (oracle/Makefile: ``make fma``)."""
+        assert not (use_reference_loop and fma)
+        path = (os.path.join(_HERE, "_ref", "libfbstab_ref.so") if use_reference_loop else
+                os.path.join(_HERE, "liboracle_fma.so" if fma else "liboracle.so"))
         if not os.path.exists(path):
-            build(ref=use_reference_loop)
+            build(ref=use_reference_loop, fma=fma)
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.path = path

@@ -29,6 +29,15 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_fma():
+    """The same restatement compiled with fused multiply-adds allowed (oracle/Makefile: `make fma`): the
+    second member of the pair {oracle, oracle_fma} a count may come from where only the rounding of the
+    reference's own compiler decides it.  Test infrastructure only."""
+    from oracle.oracle_py import Oracle
+    return Oracle(False, fma=True)
+
+
+@pytest.fixture(scope="session")
 def ref_oracle():
     """Oracle components driven by the reference's own FBstabAlgorithm<>
     template; only available where /root/reference exists (or a prebuilt

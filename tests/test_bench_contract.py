@@ -26,7 +26,9 @@ def test_latest_bench_line_has_the_contract_fields():
     assert r["unit"] == "QPs/sec" and r["dtype"] == "f64" and r["scaling"] == "weak"
     assert "workload" in r["config"] and "model" not in r["config"]
     rf = r["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    # ("issue": round 6 - the lower of the two measured ceilings is named; achieved / peak /
+    # frac remain the algorithmic bytes over the HBM peak either way)
+    assert rf["bound"] in ("hbm", "mfma", "issue") and rf["unit"] in ("GB/s", "TFLOP/s")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["traffic"] is None or rf["traffic"] > rf["algorithmic_bytes_per_launch"]
     cb = r["cpu_baseline"]
@@ -125,3 +127,26 @@ def test_round_5_fields_of_the_bench_line():
         assert rf["hbm_ceiling_qps"] > r["value"] / r["n_gpus"]  # the kernel is not at that wall
     assert r["config"]["untimed_steps"] >= max(r["warmup"], min(r["config"]["steps_in_flight"], r["steps"])), path
     assert r["launch"]["workgroups"] >= 256 and r["launch"]["scratch_bytes"] > 0
+
+
+def test_round_6_fields_of_the_bench_line():
+    """the roofline names the ceiling the kernel is near - issue_bound_qps = batch /
+    (SQ_INSTS_VALU x probed cycles per instruction / 1024 SIMDs / shader clock), replayed from the sq-counter
+    summary, `bound` = the lower of that and the memory wall - and the line carries a `wide` block (the
+    row-pair record instances the driver never saw).  (Lines older than round 6 carry neither.)"""
+    r, path = _latest_line()
+    rf = r["roofline"]
+    if "issue_bound_qps" not in rf:
+        return
+    ib = rf["issue_bound"]
+    if ib is not None:
+        want = r["config"]["batch_per_gpu"] / (ib["valu_instructions_per_launch"] * ib["cycles_per_instruction"] /
+                                               ib["simds"] / (ib["shader_clock_mhz"] * 1e6))
+        assert abs(rf["issue_bound_qps"] - want) < 1e-6 * want, path
+        assert isinstance(ib["build_matches"], bool) and ib["counter_source"].startswith("profiles/")
+        if rf["traffic"] is not None:
+            assert rf["bound"] == ("issue" if rf["issue_bound_qps"] < rf["hbm_ceiling_qps"] else "hbm"), path
+    if "wide" in r:
+        for k, w in r["wide"].items():
+            assert w["value"] > 0 and w["unit"] == "QPs/sec" and w["all_converged"] in (True, False), (path, k)
+            assert w["kernel"].startswith("fbstab_mpc_r32_kernel") and 0 < w["roofline"]["frac"] < 1, (path, k)

@@ -255,13 +255,15 @@ def test_random_shapes_with_sparse_constraint_rows_on_every_mpc_instance(hip, or
         assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
 
 
-def test_the_one_count_the_references_rounding_decides(hip, oracle):
+def test_the_one_count_the_references_rounding_decides(hip, oracle, oracle_fma):
     """The one deviation 12 fuzz seeds of the sparse-row family hold (~8,400 QPs; profiles/r05_a_*): seed 301,
-    shape 144, QP 4 - a one-step QP whose exact Newton step ends at 2e-7.  The record kernel stops there
-    (1 / 1, like the flat-vector logic on the host: tests/test_hostsim.py::test_a_count_that_only_the_
-    references_rounding_decides, which measures the steps); the ORACLE's own step leaves 1.2e-6 of the Newton
-    system behind, over abs_tol by itself, and it runs a second iteration.  The other eight QPs of the shape
-    take the oracle's counts, and the two solutions of QP 4 agree to a third of the tolerance."""
+    shape 144, QP 4 - a one-step QP whose exact Newton step ends at 2e-7.  The ORACLE's own step leaves
+    1.2e-6 of the Newton system behind, over abs_tol by itself, and it runs a second iteration; the oracle
+    compiled with fused multiply-adds allowed (oracle/liboracle_fma.so: same algorithm, same order of
+    operations) stops after one.  No literal counts here: on EVERY QP of the shape the
+    device's (flag, proximal, Newton) triple must be the triple of one of the two builds of the oracle, and
+    wherever the two builds agree with each other - the count is not the compiler's to decide - it is
+    theirs.  The solutions agree to a third of the tolerance either way."""
     p, o = H.fuzz_stream_shape(301, 143, "sparse")
     N, nx, nu, nc = p.sizes()
     B = p.batch
@@ -272,15 +274,16 @@ def test_the_one_count_the_references_rounding_decides(hip, oracle):
     out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
     s.close()
     c = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
-    oc = c[4]
-    others = np.arange(B) != 4
-    assert (out["eflag"] == 0).all() and (oc["eflag"] == 0).all()
-    assert np.array_equal(out["prox_iters"][others], oc["prox_iters"][others])
-    assert np.array_equal(out["newton_iters"][others], oc["newton_iters"][others])
-    assert (out["prox_iters"][4], out["newton_iters"][4]) == (1, 1) and (oc["prox_iters"][4], oc["newton_iters"][4]) == (2, 2)
-    assert out["residual"][4] <= 2.2e-7 and np.abs(z[4] - c[0][4]).max() <= 3e-7
-    o1 = default_options(max_prox_iters=1)
-    assert 1e-6 < oracle.solve_mpc(p, opts=o1)[4]["residual"][4] < 1.3e-6  # what the oracle's one step leaves
+    f = oracle_fma.solve_mpc(p, opts=o, nthreads=oracle_fma.num_threads())
+    triple = lambda r: np.stack([r["eflag"], r["prox_iters"], r["newton_iters"]], axis=1).astype(int)
+    td, tc, tf = triple(out), triple(c[4]), triple(f[4])
+    as_plain, as_fma = (td == tc).all(axis=1), (td == tf).all(axis=1)
+    assert (as_plain | as_fma).all(), (td, tc, tf)
+    both = (tc == tf).all(axis=1)
+    assert as_plain[both].all()
+    assert (~both).sum() <= 1  # (the two builds part on QP 4 alone: what profiles/r05_c_* measured over 25,206 QPs)
+    assert (out["eflag"] == 0).all()
+    assert np.abs(z - c[0]).max() <= 3e-7 * (1.0 + np.abs(c[0]).max())
 
 
 def _solve_on(hipmod, which, p, o, shape):
@@ -348,7 +351,7 @@ def test_pattern_initialised_build_agrees_bitwise_on_every_record_instance(hip, 
         oc = c[4]
         assert np.array_equal(a[5]["eflag"], oc["eflag"]), (shape, p.batch)
         assert np.array_equal(a[5]["prox_iters"], oc["prox_iters"]), (shape, p.batch)
-        assert np.abs(a[5]["newton_iters"].astype(int) - oc["newton_iters"].astype(int)).max() <= 2
+        assert np.array_equal(a[5]["newton_iters"], oc["newton_iters"]), (shape, p.batch)
         good = oc["eflag"] == 0
         if good.any():
             scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
@@ -574,7 +577,7 @@ def test_mpc_stage_wider_than_the_lds(hip, oracle):
     assert np.array_equal(out["eflag"], oc["eflag"]) and (oc["eflag"] == 0).all()
     good = oc["eflag"] == 0
     assert np.array_equal(out["prox_iters"][good], oc["prox_iters"][good])
-    assert np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int))[good].max() <= 2
+    assert np.array_equal(out["newton_iters"][good], oc["newton_iters"][good])
     scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
     assert (np.abs(z - c[0])[good] <= 10 * o.abs_tol * scale[good]).all()
     # one Newton step against the oracle's RiccatiLinearSolver at a random point
@@ -635,7 +638,7 @@ def test_dense_vectors_longer_than_the_lds(hip, oracle):
     oc = c[4]
     assert np.array_equal(out["eflag"], oc["eflag"]) and (oc["eflag"] == 0).all()
     assert np.array_equal(out["prox_iters"], oc["prox_iters"])
-    assert np.abs(out["newton_iters"].astype(int) - oc["newton_iters"].astype(int)).max() <= 2
+    assert np.array_equal(out["newton_iters"], oc["newton_iters"])
     scale = 1.0 + np.abs(c[0]).max(axis=1, keepdims=True)
     assert (np.abs(z - c[0]) <= 10 * o.abs_tol * scale).all()
     assert np.array_equal(out2["newton_iters"], out["newton_iters"])

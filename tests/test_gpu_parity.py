@@ -84,14 +84,19 @@ def _unique_duals(dense, vc, act_tol=1e-7):
     return uniq
 
 
-def _assert_parity(gpu, cpu, abs_tol, exact_frac=0.99, max_dn=2, dense=None):
+def _assert_parity(gpu, cpu, abs_tol, exact_frac=1.0, max_dn=0, dense=None):
+    """The parity bar.  STRICT by default: exit flag, proximal and Newton count of
+    EVERY instance equal to the oracle's.  Only the opt-in dense elimination orders (NATURAL / AUTO: a
+    different pivot order than Eigen's, by the caller's choice) pass a looser `exact_frac` / `max_dn`."""
     zg, lg, vg, yg, og = gpu
     zc, lc, vc, yc, oc = cpu
     assert np.array_equal(og["eflag"], oc["eflag"])
     assert np.array_equal(og["prox_iters"], oc["prox_iters"])
     dn = np.abs(og["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
-    assert dn.max() <= max_dn, dn.max()
-    assert (dn == 0).mean() >= exact_frac or len(dn) < 100 and (dn != 0).sum() <= 1, (dn != 0).sum()
+    assert dn.max() <= max_dn, (dn.max(), np.nonzero(dn)[0][:10])
+    assert (dn == 0).mean() >= exact_frac, ((dn != 0).sum(), np.nonzero(dn)[0][:10])
+    if max_dn == 0:
+        assert int(og["newton_iters"].sum()) == int(oc["newton_iters"].sum())
     pinned = np.ones(zc.shape[0], dtype=bool)
     if dense is not None:
         # multipliers: entry by entry where they are unique, through G'l + A'v everywhere
@@ -169,7 +174,7 @@ def test_mpc_reference_tests(hip, oracle, kats, idx):
     np.testing.assert_allclose(y[0], b - A @ z[0], atol=1e-9)
     cpu = oracle.solve_mpc(p, opts=o)
     assert out["prox_iters"][0] == cpu[4]["prox_iters"][0]
-    assert abs(int(out["newton_iters"][0]) - int(cpu[4]["newton_iters"][0])) <= 2
+    assert int(out["newton_iters"][0]) == int(cpu[4]["newton_iters"][0])
 
 
 # -- one Newton step (LinearSolver::Initialize + Solve) -------------------------
@@ -414,7 +419,7 @@ def test_dense_odd_shapes(hip, oracle, monkeypatch, shape, order):
     if order == "default":
         _assert_parity(gpu, cpu, o.abs_tol, exact_frac=1.0, max_dn=0)
     else:
-        _assert_parity(gpu, cpu, o.abs_tol, dense=p)
+        _assert_parity(gpu, cpu, o.abs_tol, exact_frac=0.99, max_dn=2, dense=p)  # (an opt-in order)
     assert np.abs(gpu[0] - p.solution["z"]).max() < 1e-5
 
 
@@ -627,7 +632,8 @@ def test_line_search_trial_limits_on_the_record_kernel(hip, oracle, max_ls):
     cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
     assert np.array_equal(gpu[4]["eflag"], cpu[4]["eflag"])
     dn = np.abs(gpu[4]["newton_iters"].astype(int) - cpu[4]["newton_iters"].astype(int))
-    assert (dn == 0).mean() >= 0.99 and dn.max() <= 2, ((dn != 0).sum(), dn.max())
+    assert dn.max() == 0, ((dn != 0).sum(), dn.max())
+    assert np.array_equal(gpu[4]["prox_iters"], cpu[4]["prox_iters"])
     ok = cpu[4]["eflag"] == 0
     scale = 1.0 + np.abs(cpu[0]).max(axis=1, keepdims=True)
     assert (np.abs(gpu[0] - cpu[0])[ok] <= 10 * o.abs_tol * scale[ok]).all()
@@ -680,7 +686,19 @@ def test_mpc_mixed_outcome_batch(hip, oracle, monkeypatch, kernel):
     sub = fx.MpcProblem(N, nx, nu, nc)
     sub.arrays = {k: np.ascontiguousarray(v_[keep]) for k, v_ in a.items()}
     cpu = oracle.solve_mpc(sub, opts=o)
-    _assert_parity((z[keep], l[keep], v[keep], y[keep], out[keep]), cpu, o.abs_tol)
+    if kernel == "r16":
+        _assert_parity((z[keep], l[keep], v[keep], y[keep], out[keep]), cpu, o.abs_tol)
+    else:
+        # The flat-vector kernel takes 2 Newton steps more or fewer than the oracle on the INFEASIBLE QP
+        # (measured, round 6, when this test went strict): its iterates run away along the certificate's
+        # ray and every rounding of the substitutions is amplified on the way - flag and proximal count
+        # are the oracle's.  The four QPs that converge are compared strictly.
+        conv = np.array([0, 1, 3, 4])
+        pick = lambda t, idx: tuple(a[idx] for a in t)
+        got = (z[keep], l[keep], v[keep], y[keep], out[keep])
+        _assert_parity(pick(got, conv), pick(cpu, conv), o.abs_tol)
+        assert out["eflag"][3] == cpu[4]["eflag"][2] == 3 and out["prox_iters"][3] == cpu[4]["prox_iters"][2]
+        assert abs(int(out["newton_iters"][3]) - int(cpu[4]["newton_iters"][2])) <= 2
     zs, ls, vs, ys, outs = _solve_mpc_host(hip, sub, o)
     assert np.array_equal(zs, z[keep]) and np.array_equal(outs["newton_iters"], out["newton_iters"][keep])
     with pytest.raises(RuntimeError):
@@ -750,7 +768,8 @@ def test_shard_of_rank_one_matches_the_oracle_including_its_iteration_limit_qps(
     easy = cpu[4]["eflag"] == 0
     assert np.array_equal(gpu[4]["prox_iters"][easy], cpu[4]["prox_iters"][easy])
     dn = np.abs(gpu[4]["newton_iters"][easy].astype(int) - cpu[4]["newton_iters"][easy].astype(int))
-    assert (dn == 0).mean() >= 0.99 and dn.max() <= 2  # the parity bar of DESIGN.md section 2
+    assert dn.max() == 0, ((dn != 0).sum(), dn.max())  # every count equal
+    assert int(gpu[4]["newton_iters"][easy].sum()) == int(cpu[4]["newton_iters"][easy].sum())
     for a, b in zip(gpu[:3], cpu[:3]):
         assert np.abs(a[easy] - b[easy]).max() <= 10 * o.abs_tol * (1 + np.abs(b[easy]).max())
 
@@ -1005,6 +1024,11 @@ def test_receding_sweep_on_padded_and_two_row_instances(hip, oracle, monkeypatch
     assert np.abs(one_launch["x0"] - x_end).max() <= 1e-6 * (1.0 + np.abs(x_end).max())
 
 
+# measured on MI355X (profiles/r06_*_config5_warm_start_count_parity.json): of 12,800 warm-started solves
+WARM_PROX_FLIPS_MEASURED = 0
+WARM_NEWTON_FLIPS_MEASURED = 0
+
+
 def test_config5_full_sweep_with_an_oracle_subset(hip, oracle):
     """BASELINE configs[4] at full size: 4096 trajectories x 200 steps on the device.
     The trajectories are independent, so the 64 of them with ids 0, 64, 128, ... are
@@ -1038,6 +1062,50 @@ def test_config5_full_sweep_with_an_oracle_subset(hip, oracle):
         np.testing.assert_allclose(u[k], ref[k]["u0"], atol=2e-5, err_msg=f"step {k}")
     np.testing.assert_allclose(data["x0"].cpu().numpy()[sub], x_end, atol=2e-5)
     s.close()
+    # ---- warm-start COUNT parity at every one of the 200 steps --------------------
+    # Two closed loops drift apart after the first flip (each applies its own input), so the counts are
+    # compared TEACHER-FORCED: the same 64 trajectories once more, one sweep step per call, and at every
+    # step the oracle solves exactly what the device is about to solve - the device's x0 and the device's
+    # previous solution as the guess.  The step-at-a-time run IS the 200-step launch: its inputs are
+    # asserted bitwise equal to the sweep's log.  12,800 warm-started solves, every exit flag, proximal and
+    # Newton count compared; the measured flips go to gpurun_out/ (-> profiles/) and bound the test.
+    import json, os
+    Ts = len(sub)
+    s2 = hip.FBstabMpcBatch(N, nx, nu, nc, max_batch=Ts)
+    d2 = {k: torch.from_numpy(np.ascontiguousarray(a[sub])).to(dev) for k, a in p.arrays.items()}
+    mk2 = lambda n: torch.zeros((Ts, n), dtype=torch.float64, device=dev)
+    z2, l2, v2, y2 = mk2(p.nz), mk2(p.nl), mk2(p.nv), mk2(p.nv)
+    flips = dict(eflag=0, prox=0, newton=0, solves=0, newton_abs_max=0, first=[])
+    for k in range(S):
+        x0k = d2["x0"].cpu().numpy().copy()
+        guess = (z2.cpu().numpy().copy(), l2.cpu().numpy().copy(), v2.cpu().numpy().copy())
+        r2 = s2.RecedingSweep(d2, z2, l2, v2, y2, A, B, 1, retire=True, log_inputs=True)
+        assert torch.equal(r2["u"][0], r["u"][k][torch.from_numpy(sub).to(dev)]), f"step {k}: not the sweep's inputs"
+        og = hip.out_to_numpy(r2["out"])
+        qk = fx.MpcProblem(N, nx, nu, nc)
+        qk.arrays = dict(q.arrays)
+        qk.arrays["x0"] = np.ascontiguousarray(x0k)
+        oc = oracle.solve_mpc(qk, guess, nthreads=oracle.num_threads())[4]
+        live = np.abs(x0k).max(axis=1) > 0.0  # (a parked trajectory solves the trivial QP at the origin)
+        de = og["eflag"] != oc["eflag"]
+        dp = og["prox_iters"].astype(int) - oc["prox_iters"].astype(int)
+        dn = og["newton_iters"].astype(int) - oc["newton_iters"].astype(int)
+        flips["solves"] += int(live.sum())
+        flips["eflag"] += int(de.sum())
+        flips["prox"] += int((dp != 0).sum())
+        flips["newton"] += int((dn != 0).sum())
+        flips["newton_abs_max"] = max(flips["newton_abs_max"], int(np.abs(dn).max()))
+        for t in np.nonzero(de | (dp != 0) | (dn != 0))[0][:4]:
+            if len(flips["first"]) < 20:
+                flips["first"].append(dict(step=k, trajectory=int(sub[t]), device=[int(og["eflag"][t]), int(og["prox_iters"][t]), int(og["newton_iters"][t])],
+                                           oracle=[int(oc["eflag"][t]), int(oc["prox_iters"][t]), int(oc["newton_iters"][t])],
+                                           residual_device=float(og["residual"][t]), residual_oracle=float(oc["residual"][t])))
+    s2.close()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/config5_warm_start_count_parity.json", "w") as f:
+        json.dump(flips, f, indent=1)
+    assert flips["eflag"] == 0, flips
+    assert flips["prox"] <= WARM_PROX_FLIPS_MEASURED and flips["newton"] <= WARM_NEWTON_FLIPS_MEASURED, flips
 
 
 # -- parity coverage on the record kernel ---------------------------
@@ -1135,9 +1203,9 @@ def test_saturate_error_is_exit_flag_6(hip, oracle, monkeypatch):
 def test_config4_all_eight_shards(hip, oracle):
     """BASELINE configs[3]: ids 0..65535 in eight shards of 8192, as eight ranks would
     hold them (here one GPU, one shard after the other).  For every shard: exit
-    flags equal the oracle's for ALL QPs, Newton counts equal on >= 99 %.  Over the
-    whole batch: the ten ids the oracle runs to the 200-iteration limit are the ones
-    the device reports, and the Newton totals agree to 1e-4."""
+    flags and Newton counts equal the oracle's for ALL QPs, proximal counts on every QP
+    that converges.  Over the whole batch: the ten ids the oracle runs to the
+    200-iteration limit are the ones the device reports, and the Newton totals are EQUAL."""
     import torch
     dev = torch.device("cuda:0")
     B = 8192
@@ -1155,7 +1223,9 @@ def test_config4_all_eight_shards(hip, oracle):
         oc = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())[4]
         assert np.array_equal(og["eflag"], oc["eflag"]), shard
         dn = np.abs(og["newton_iters"].astype(int) - oc["newton_iters"].astype(int))
-        assert (dn == 0).mean() >= 0.99 and dn.max() <= 2, (shard, (dn != 0).sum(), dn.max())
+        assert dn.max() == 0, (shard, (dn != 0).sum(), dn.max(), np.nonzero(dn)[0][:10])
+        conv = oc["eflag"] == 0
+        assert np.array_equal(og["prox_iters"][conv], oc["prox_iters"][conv]), shard
         tot_g += int(og["newton_iters"].sum())
         tot_c += int(oc["newton_iters"].sum())
         limit_g += (shard * B + np.nonzero(og["eflag"] == 2)[0]).tolist()
@@ -1163,7 +1233,7 @@ def test_config4_all_eight_shards(hip, oracle):
         del data
     s.close()
     assert limit_g == limit_c == [11960, 15020, 32011, 32547, 36083, 37816, 46092, 50603, 55479, 56432]
-    assert abs(tot_g - tot_c) <= 1e-4 * tot_c, (tot_g, tot_c)
+    assert tot_g == tot_c, (tot_g, tot_c)
 
 
 def test_reactor_shape_runs_on_the_two_row_record_kernel(hip, oracle):

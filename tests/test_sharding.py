@@ -148,6 +148,121 @@ def test_sharded_receding_sweep_equals_single_process():
     assert np.abs(want).max() > 0.1
 
 
+# ---- world size 8: bench.py's own rank-0 buffer plan under gloo -------------
+def _synthetic_results(first, count, sizes):
+    """Deterministic stand-ins for a shard's results, a function of the GLOBAL instance id alone (no
+    solver here: eight oracle processes on eight CPUs would only slow the suite down - what is under
+    test is the exchange): every entry of x is id + column / 4096, the SolverOut record carries the id."""
+    from fbstab_amd.hip_api import OUT_DTYPE
+    nz, nl, nv = sizes
+    nvar = nz + nl + 2 * nv
+    ids = np.arange(first, first + count)
+    x = ids[:, None].astype(np.float64) + np.arange(nvar)[None, :] / 4096.0
+    out = np.zeros(count, dtype=OUT_DTYPE)
+    out["eflag"] = ids % 3
+    out["newton_iters"] = 7 + ids
+    out["prox_iters"] = 1 + ids % 5
+    out["residual"] = 1e-7 * (1 + ids)
+    return x, out
+
+
+def _world8_worker(rank, world, port, per_rank, lanes, steps, nsteps_sweep, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    from fbstab_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = (12, 5, 9)
+    nvar = sizes[0] + sizes[1] + 2 * sizes[2]
+    first, last = sharding.shard_range(rank, world, per_rank)
+    dev = torch.device("cpu")
+    # exactly what bench.py's Lane allocates, `lanes` of them: on rank 0 every lane's receive list with
+    # the rank's own record as its own slot
+    bufs = [bench.lane_buffers(torch, dev, per_rank, sizes, world, rank, True) for _ in range(lanes)]
+    calls = []
+    real_gather = dist.gather
+    dist.gather = lambda *a, **k: (calls.append(1), real_gather(*a, **k))[1]
+    for k in range(steps):   # the way run_mpc() steps through its lanes
+        b = bufs[k % lanes]
+        x, out = _synthetic_results(first + 1000 * k, per_rank, sizes)
+        b["x"].copy_(torch.from_numpy(x))                    # "the solver writes through the views of the record"
+        b["out"].copy_(torch.from_numpy(np.frombuffer(out.tobytes(), dtype=np.uint8).reshape(per_rank, 40).copy()))
+        got, none = sharding.gather_solutions(b["x"], b["out"], dst=0, record=b["rec"], gather_list=b["grec"], stack=False)
+        assert none is None
+        if rank == 0:
+            assert got is b["grec"] and got[0] is b["rec"]   # nothing stacked, the root's block not copied
+            for g in range(world):
+                xg, og = _synthetic_results(g * per_rank + 1000 * k, per_rank, sizes)
+                assert torch.equal(got[g][:, :nvar], torch.from_numpy(xg)), (k, g)
+                u = sharding.unpack_out(got[g])
+                for f in ("eflag", "newton_iters", "prox_iters", "residual"):
+                    assert np.array_equal(u[f], og[f]), (k, g, f)
+        else:
+            assert got is None
+    # configs[4]: one gather of the input log when the sweep is over, preallocated receive list
+    u_log = torch.from_numpy(np.arange(first, last)[None, :, None] + 0.001 * np.arange(nsteps_sweep)[:, None, None]
+                             + np.zeros((1, 1, 4)))
+    glist = [torch.empty_like(u_log) for _ in range(world)] if rank == 0 else None
+    logs = sharding.gather_input_log(u_log, dst=0, gather_list=glist)
+    dist.gather = real_gather
+    assert len(calls) == steps + 1, "one collective per batch, one per sweep"
+    if rank == 0:
+        assert logs is glist
+        full = torch.cat(logs, dim=1).numpy()
+        assert np.array_equal(full[:, :, 0], np.arange(world * per_rank)[None, :] + 0.001 * np.arange(nsteps_sweep)[:, None])
+        q.put(("ok", sum(t.numel() * 8 for b in bufs for t in b["grec"][1:])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_gather_with_the_bench_lane_plan():
+    """`bench.py --gpus 8` as far as it can be rehearsed without GPUs: eight gloo ranks, each with
+    bench.lane_buffers() for several lanes in flight, stepping through them the way run_mpc() does -
+    gather_solutions(record=, gather_list=, stack=False) with rank 0's slot aliased to its own record -
+    and one gather_input_log() with a preallocated list at the end.  Every block arrives in global
+    instance order in every lane, one collective per batch; the bytes rank 0 receives are the plan's."""
+    import torch.multiprocessing as mp
+    import bench
+    world, per_rank, lanes, steps, sweep_steps = 8, 6, 3, 7, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, per_rank, lanes, steps, sweep_steps, q))
+             for r in range(world)]
+    for pr in procs:
+        pr.start()
+    status, recv_bytes = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert status == "ok"
+    plan = bench.memory_plan(world, lanes, per_rank, (12, 5, 9), 0, 0)
+    assert recv_bytes == plan["receive"]
+
+
+def test_rank0_memory_plan_of_the_8_gpu_headline_fits():
+    """The buffers `bench.py --gpus 8` holds on rank 0 at its defaults (batch 8192 per GPU, eight steps in
+    flight): 8 lanes x 7 receive buffers of 138.5 MB beside the lanes' own records, eight solver handles'
+    scratch (the size fbstab_hip_mpc_create_in_flight gives a handle that shares the device with seven
+    others - taken from the record layout's constants, include/fbstab_hip.h documents the rule) and the
+    resident problem data: ~11 GB of the 288 GB of an MI355X."""
+    import bench
+    N, nx, nu, nc = 30, 12, 4, 20
+    sizes = ((N + 1) * (nx + nu), (N + 1) * nx, (N + 1) * nc)
+    data_bytes = bench.ALG_BYTES_PER_QP - 11904 - 16864 - 40   # the problem data's share (SURVEY 8d)
+    assert data_bytes == 188928
+    scratch = 437 * 2 ** 20   # measured: fbstab_hip_mpc_query of a handle created with handles_in_flight = 8 (DESIGN section 5)
+    plan = bench.memory_plan(8, 8, 8192, sizes, data_bytes, scratch)
+    assert plan["record_bytes"] == 8192 * (2108 + 5) * 8
+    assert 7.5e9 < plan["receive"] < 8.0e9             # 8 lanes x 7 ranks x 138.5 MB
+    assert plan["total"] < 0.05 * 288e9, plan           # ~13 GB: a twentieth of the HBM
+    other = bench.memory_plan(8, 8, 8192, sizes, data_bytes, scratch, rank=3)
+    assert other["receive"] == 0 and other["total"] < plan["total"]
+
+
 # ---- the C-ABI's own multi-GPU entry (include/fbstab_hip.h: fbstab_hip_*_sharded) --------
 def test_shard_group_argument_checks_without_gpu():
     """No GPU here: the group cannot be created (no CPU path), bad arguments are rejected

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Developer tool: random MPC shapes over every record instance (and the flat-vector
 kernel) against the oracle: exit flags, proximal counts equal; Newton counts equal on
-all but a few.  argv: number of shapes [seed] [r16] [bounds | sparse].  With `bounds` the constraints are bounds on single stage
+all but a few.  argv: number of shapes [seed] [r16] [bounds | sparse] [warm].  With `bounds` the constraints are bounds on single stage
 variables (fixtures.random_ltv_mpc_bounds).  With `r16` every shape is drawn inside the
 headline instance <12,4,20> (nx <= 12, nu <= 4, nc <= 20); a shape is flagged ("CHECK") as soon as ANY
 count differs from the oracle's (strict), otherwise when flags / proximal counts differ, a Newton
 count differs by more than two or the solutions part.  The last column counts the Newton steps the kernel
-refined (fbstab_hip_mpc_refined_steps)."""
+refined (fbstab_hip_mpc_refined_steps).  With `warm` (round 6) every shape is solved a SECOND time: x0 perturbed,
+warm-started from the device's first solution - device and oracle get the same guess (the device's), so every
+second solve is an independent comparison on identical inputs; its counts are compared as strictly, and the
+summary line counts the warm solves' flips separately."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +21,11 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r16 = len(sys.argv) > 3 and "r16" in sys.argv[3:]
 bounds = "bounds" in sys.argv[3:]  # bound constraints (one +-1 entry per row): the row form of the costate step
 sparse = "sparse" in sys.argv[3:]  # two or three entries of order one per row: the row form without the bounds' shortcut
+warm = "warm" in sys.argv[3:]      # a second, warm-started solve per shape (teacher-forced: the oracle gets the device's guess)
 strict = r16 or os.environ.get("FUZZ_STRICT", "1") != "0"
 nqp = nref = 0
+nwarm = warm_flips = warm_bad = 0
+wrng = np.random.default_rng(1_000_003 + (int(sys.argv[2]) if len(sys.argv) > 2 else 1))  # (the shape stream stays as it is)
 orc = Oracle(False)
 bad = 0
 for it in range(n):
@@ -40,7 +46,34 @@ for it in range(n):
     s.UpdateOptions(h)
     z = np.zeros((B, p.nz)); l = np.zeros((B, p.nl)); v = np.zeros((B, p.nv)); y = np.zeros((B, p.nv))
     out = s.Solve({k: np.ascontiguousarray(a) for k, a in p.arrays.items()}, z, l, v, y)
-    kn = s.kernel_name(); refined = s.refined_steps(); s.close()
+    kn = s.kernel_name(); refined = s.refined_steps()
+    wline = ""
+    if warm:
+        # second solve: the measured state moves (a few per cent and a small absolute kick), everything else stays
+        p2 = type(p)(*p.sizes())
+        p2.arrays = dict(p.arrays)
+        x0 = p.arrays["x0"]
+        p2.arrays["x0"] = np.ascontiguousarray(x0 * (1.0 + 0.05 * wrng.standard_normal(x0.shape)) + 0.01 * wrng.standard_normal(x0.shape))
+        g = (z.copy(), l.copy(), v.copy())   # the device's first solution: BOTH warm starts
+        z2, l2, v2, y2 = g[0].copy(), g[1].copy(), g[2].copy(), np.zeros((B, p.nv))
+        out2 = s.Solve({k: np.ascontiguousarray(a) for k, a in p2.arrays.items()}, z2, l2, v2, y2)
+        c2 = orc.solve_mpc(p2, g, opts=o, nthreads=orc.num_threads())
+        oc2 = c2[4]
+        dn2 = np.abs(out2["newton_iters"].astype(int) - oc2["newton_iters"].astype(int))
+        dp2 = np.abs(out2["prox_iters"].astype(int) - oc2["prox_iters"].astype(int))
+        ef2 = np.array_equal(out2["eflag"], oc2["eflag"])
+        nwarm += B
+        flips = int(((dn2 != 0) | (dp2 != 0)).sum())
+        warm_flips += flips
+        wbad = (not ef2) or flips > 0
+        warm_bad += wbad
+        wline = f" | warm: flags_equal={ef2} prox_flips={int((dp2 != 0).sum())} newton_flips={int((dn2 != 0).sum())} dn_max={dn2.max()}" + ("  <-- CHECK(warm)" if wbad else "")
+        if wbad:
+            print("   warm device: eflag", out2["eflag"].tolist(), "prox", out2["prox_iters"].tolist(), "newton", out2["newton_iters"].tolist(),
+                  "residual", [f"{r:.2e}" for r in out2["residual"]])
+            print("   warm oracle: eflag", oc2["eflag"].tolist(), "prox", oc2["prox_iters"].tolist(), "newton", oc2["newton_iters"].tolist(),
+                  "residual", [f"{r:.2e}" for r in oc2["residual"]])
+    s.close()
     nqp += B; nref += refined
     c = orc.solve_mpc(p, opts=o, nthreads=orc.num_threads())
     oc = c[4]
@@ -55,5 +88,6 @@ for it in range(n):
               "residual", [f"{r:.2e}" for r in out["residual"]])
         print("   oracle: eflag", oc["eflag"].tolist(), "prox", oc["prox_iters"].tolist(), "newton", oc["newton_iters"].tolist(),
               "residual", [f"{r:.2e}" for r in oc["residual"]])
-    print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e} refined={refined}{flag}")
-print(f"shapes to check: {bad}   ({n} shapes, {nqp} QPs, {nref} refined Newton steps; strict={strict})")
+    print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e} refined={refined}{flag}{wline}")
+print(f"shapes to check: {bad}   ({n} shapes, {nqp} QPs, {nref} refined Newton steps; strict={strict})"
+      + (f"   warm solves: {nwarm}, with any count different: {warm_flips} in {warm_bad} shapes" if warm else ""))
