@@ -1097,6 +1097,106 @@ struct MpcR16 {
     });
     return out;
   }
+  // ---- the same pass with the LAST constraint slot of four stages evaluated as ONE slot (round 6) --------
+  // NC = 20 on 16 lanes: the second slot of a stage holds entries 16..19 on 4 lanes and nothing on the other
+  // 12, and the pass above evaluates it - four step lengths, both functions - once per stage all the same: 37 %
+  // of the pass's arithmetic on 25 % full slots.  Here a row evaluates the full slots of its stage trip by
+  // trip as before, and once per FOUR trips the last slots of the four stages it took in them together: lane
+  // l loads entry l % kTail of the stage of trip l / kTail straight from that stage's record.  Same terms;
+  // a row's partial sums collect them in a different order (as this pass already does against the
+  // sequential one).  12 evaluations of 32 fewer per four trips.
+  // MEASURED (gpurun_out/r06_o, same box, 3 interleaved runs): SQ_INSTS_VALU of the 8192-QP launch 3.953 G ->
+  // 3.779 G (-4.4 %), every count and the Newton total unchanged, 162 parity tests green - and the headline
+  // 630.5 k -> 624.9 k QP/s (-0.9 %), one launch at a time +-0: the pass is a chain of eight trips each
+  // waiting for loads requested one trip earlier, and a trip with half the arithmetic covers half the
+  // latency.  The third time this round that a shorter trial pass was not a faster one (the other two are
+  // in trial_pass_coop).  OFF: the knob is the record of the experiment, not the product.
+#ifndef FB_R16_TAIL_PACK
+#define FB_R16_TAIL_PACK 0
+#endif
+  static constexpr int kTailGroup = 4;
+  static constexpr bool kTailPack = FB_R16_TAIL_PACK != 0 && KS >= 2 && kTail * kTailGroup <= LPQ && kTailCut &&
+                                    FB_R16_TRIAL_STAGES == 1;
+  template <int K>
+  static __device__ __attribute__((noinline)) TrialNorms<K> trial_pass_coop_packed(const double* R0, int N_, double t0,
+                                                                                   double beta, double sigma, double alpha) {
+    constexpr int QW = kQpPerWave, G = kTailGroup, KF = KS - 1;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPQ, r = lane & (LPQ - 1);
+    double tt[K], s[2 * K];
+    tt[0] = t0;
+    sfor<1, K>([&](auto Kk) { tt[decltype(Kk)::value] = tt[decltype(Kk)::value - 1] * beta; });
+    sfor<0, 2 * K>([&](auto Kk) { s[decltype(Kk)::value] = 0.0; });
+    auto stage_ptr = [&](int i) { return R0 + (long)(i < N_ ? i : N_) * kRec; };
+    struct Full {
+      dbl2 vy[KF], da[KF];
+      double vb[KF];
+    };
+    struct Tail {
+      dbl2 vy, da;
+      double vb;
+    };
+    auto load_full = [&](const double* R, Full& in) {
+      sfor<0, KF>([&](auto S_) {
+        constexpr int sl = decltype(S_)::value;
+        in.vy[sl] = ld2(R, sV + 2 * sl);
+        in.da[sl] = ld2(R, sDV + 2 * sl);
+        in.vb[sl] = ld(R, sVB + sl);
+      });
+    };
+    // this lane's place in a packed last slot: entry te of the stage this row takes in trip tsub of the group
+    const int tsub = r / kTail, te = r - tsub * kTail;
+    auto load_tail = [&](int g, Tail& in) {
+      const double* Rt = stage_ptr(q + QW * (G * g + tsub)) - 2 * r + 2 * te;  // (R0 carries this lane's 2 r)
+      in.vy = ld2(Rt, sV + 2 * KF);
+      in.da = ld2(Rt, sDV + 2 * KF);
+      in.vb = ld(Rt, sVB + KF);
+    };
+    auto terms = [&](const dbl2& vy, const dbl2& da, double vb, bool live) {
+      sfor<0, K>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        const double vi = fma(tt[k], da[0], vy[0]);
+        const double yi = fma(-tt[k], da[1], vy[1]);
+        const double ys = yi + sigma * (vi - vb);
+        const double ph = pfb(ys, vi, alpha);
+        const double pn = pnr(yi, vi, alpha);
+        s[k] = live ? fma(ph, ph, s[k]) : s[k];
+        s[K + k] = live ? fma(pn, pn, s[K + k]) : s[K + k];
+      });
+    };
+    const int last_trip = N_ / QW;  // (the same trip count in every row: trips t with QW t <= N)
+    Full in;
+    load_full(stage_ptr(q), in);
+    for (int g = 0; G * g <= last_trip; g++) {
+      FB_PHASE(trip_top);
+      Tail tl;
+      load_tail(g, tl);  // (used at the end of the group: three trips of cover)
+      sfor<0, G>([&](auto J) {
+        const int t = G * g + decltype(J)::value;
+        if (t <= last_trip) {  // (wave-uniform)
+          const Full cu = in;
+          load_full(stage_ptr(q + QW * (t + 1)), in);
+          const bool live = q + QW * t <= N_;
+          sfor<0, KF>([&](auto S_) {
+            constexpr int sl = decltype(S_)::value;
+            terms(cu.vy[sl], cu.da[sl], cu.vb[sl], live);
+          });
+        }
+      });
+      terms(tl.vy, tl.da, tl.vb, tsub < G && q + QW * (G * g + tsub) <= N_);
+      FB_PHASE(trip_end);
+    }
+    TrialNorms<K> out;
+    sfor<0, 2 * K>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      const double rs = qp_reduce<RQ, OpSum16>(s[k]);
+      double tot = lane_value(rs, 0);
+      sfor<1, QW>([&](auto Q_) { tot += lane_value(rs, LPQ * decltype(Q_)::value); });
+      if constexpr (k < K) out.vi[k] = tot;
+      else out.vo[k - K] = tot;
+    });
+    return out;
+  }
   // The z and l blocks' share of the squared trial norms at x + t dx, from four sums of the Newton step.
   // Both residuals are affine there: with a = the inner (natural) residual's z, l blocks at x and b its
   // increment along dx (b = W + sigma dx for the inner one, b = W for the natural one),
@@ -1125,8 +1225,11 @@ struct MpcR16 {
     const unsigned long long rbo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rb >> 32), own0) << 32) |
                                    (unsigned)__builtin_amdgcn_readlane((int)rb, own0);
     const double* const R0 = reinterpret_cast<const double*>(rbo) + 2 * (threadIdx.x & (LPQ - 1));
-    const TrialNorms<K> n = trial_pass_coop<K>(R0, __builtin_amdgcn_readlane(N, own0), lane_value(t0, own0), beta,
-                                               sigma, alpha);
+    TrialNorms<K> n;
+    if constexpr (kTailPack)
+      n = trial_pass_coop_packed<K>(R0, __builtin_amdgcn_readlane(N, own0), lane_value(t0, own0), beta, sigma, alpha);
+    else
+      n = trial_pass_coop<K>(R0, __builtin_amdgcn_readlane(N, own0), lane_value(t0, own0), beta, sigma, alpha);
     sfor<0, K>([&](auto Kk) {
       Vi[decltype(Kk)::value] = n.vi[decltype(Kk)::value];
       Vo[decltype(Kk)::value] = n.vo[decltype(Kk)::value];

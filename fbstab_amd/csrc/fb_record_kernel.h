@@ -239,8 +239,23 @@ struct R16Queue {
 
 // KEEP (FBSTAB_HIP_KEEP_MATRICES): QP q is solved in slot q, so that the slot's
 // matrix copies survive from call to call; `reuse` says they are valid already.
+// FB_R16_REG_CAP: the register budget of the kernel, arch VGPRs + AGPRs, in units of TWO registers (the
+// compiler doubles "amdgpu-num-vgpr" on the unified file of gfx90a and later, and gives a function without
+// MFMA all 256 arch VGPRs first): 248 = 496 registers.  One wavefront holds its SIMD for the whole launch;
+// at 496 of the SIMD's 512 registers sixteen stay free and the small kernels a caller queues between two
+// solves (the fill kernel behind hipMemsetAsync / torch's zero_()) find room beside it - at 504 they wait for a
+// whole launch to end, and eight launches in flight run one after the other: 630 k -> 250 k QP/s
+// (LABNOTES R6.3; tools/check_vgpr_budget.py is the build's gate on the result).
+#ifndef FB_R16_REG_CAP
+#define FB_R16_REG_CAP 248
+#endif
+#if FB_R16_REG_CAP > 0
+#define FB_R16_REG_ATTR __attribute__((amdgpu_num_vgpr(FB_R16_REG_CAP)))
+#else
+#define FB_R16_REG_ATTR
+#endif
 template <int NX, int NU, int NC, bool DBG, bool EXACT, bool KEEP = false, int R = 1>
-__global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
+__global__ __launch_bounds__(64, 1) FB_R16_REG_ATTR void fbstab_mpc_r16_kernel(
     MpcBatchPtrs data, VarBatchPtrs x, fbstab_solver_out_t* out, fbstab_options_t opts, double* scratch,
     int* counter, int batch, int N, int reuse, double* dbg) {
   typedef MpcR16<NX, NU, NC, EXACT, KEEP, R> P;
@@ -249,6 +264,12 @@ __global__ __launch_bounds__(64, 1) void fbstab_mpc_r16_kernel(
   const long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
 #endif
   const int lane = threadIdx.x;
+#if defined(FB_SCRATCH_PAD)
+  // (diagnostic knob: FB_SCRATCH_PAD more bytes of private memory per lane, nothing else changed - the
+  // runtime's handling of a dispatch depends on its scratch size, LABNOTES R6.3)
+  volatile char scratch_pad_[FB_SCRATCH_PAD];
+  scratch_pad_[threadIdx.x % FB_SCRATCH_PAD] = 1;
+#endif
   typename P::C ctx;
   ctx.tid = lane & (P::LPQ - 1);
   P p;

@@ -15,6 +15,7 @@ mkdir -p $out
 # Makefile gates on the same check)
 case " $* " in *FB_FMAC_DPP=0*) expect="" ;; *) expect="--expect-nonzero" ;; esac
 python3 ../../tools/check_dpp_hazards.py $expect $out/$rec.o | tail -1
+python3 ../../tools/check_vgpr_budget.py --max 496 --only fbstab_mpc_r16_kernel $out/$rec.o | grep -v probe | grep "over the\|kernel(s) over" || true
 objs=""
 for o in build/libfbstab_hip/*.o; do
   b=$(basename $o)
