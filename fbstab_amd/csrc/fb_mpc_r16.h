@@ -2296,11 +2296,15 @@ struct MpcR16 {
     return o.ok;
   }
   // ---- one refinement of the step in the record ---------------------------------
-  // The sweeps multiply with explicitly inverted triangular factors where the reference substitutes
-  // (riccati_linear_solver.cc:234-325): forward stable, not backward stable - on ill-conditioned stages
-  // (wide stages, the first ceil(nx / nu) stages of every problem, whose Pi_i keeps eigenvalues of order
-  // sigma) the step can leave a residual r - V dx orders above eps |V| |dx|, and a QP whose convergence
-  // test sits inside that band takes an iteration the reference does not.  refine_step() solves
+  // An OPTION, off by default (fbstab_options_t::reserved).  Which instances it matters for: the ONE-ROW
+  // instances (<12,4,20>, <12,4,32>: kSubst false) multiply with an explicitly inverted inv(Lc) where the
+  // reference substitutes (riccati_linear_solver.cc:234-325) - forward stable, not backward stable: on stages
+  // whose Pi_i keeps eigenvalues of order sigma (nx > N nu) the step can leave a residual r - V dx orders above
+  // eps |V| |dx|.  Measured in round 6: a warm-started one-step solve of a (3, 12, 1, 17) QP left 1.4e-6 where
+  // the oracle leaves 2e-8 and took a second proximal iteration; with the option on it takes the oracle's
+  // counts (tests/test_gpu_components.py::test_warm_started_second_solve_...).  The ROW-PAIR instances and the
+  // flat-vector kernel substitute with the factor itself since round 5 (kSubst, fb_row16.h subst_rows): for
+  // them the option only ever makes a solve more accurate than the reference's.  refine_step() solves
   // V ddx = r - V dx with the SAME factors (the forward sweep is run again on the residual, which it forms
   // from the step in the record; the factorisation is recomputed - identical values - rather than kept:
   // W and, in the row form, inv(Pi) are not in the record) and adds ddx to the step; dv follows the third
@@ -2501,16 +2505,21 @@ struct MpcR16 {
       // (one-row instances, round 6: factorisation, inverse and W solve as ONE pass over the pivots -
       // fb_row16.h, chol_inv_cols_solve; bitwise the two-pass results)
       constexpr bool kFusedChol = FB_CHOL_FUSED != 0 && !kSubst && kFmacDpp<RQ> && FB_FMAC_DPP_SOLVE != 0;
+      // (row-pair instances: factorisation and W solve as one pass likewise, the factor left as chol_rows leaves it)
+      constexpr bool kFusedCholSubst = FB_CHOL_FUSED != 0 && kSubst && kFmacDpp<RQ> && !kPackDma;
       if constexpr (kFusedChol) {
         ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
         ok = chol_inv_cols_solve<NS, RQ>(K, XC, W, ro, sigma) && ok;
+      } else if constexpr (kFusedCholSubst) {
+        ldl<pABr, NS>(Lp, W);
+        ok = chol_solve_right<NS, RQ>(K, W, ro, sigma) && ok;
       } else {
         ok = chol_rows<NS, RQ>(K, ro, sigma) && ok;
       }
       if (!ok) { ret.loff = loff; return ret; }
       FB_STAMP_LAP(3);
       FB_SB();
-      if constexpr (!kFusedChol) ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
+      if constexpr (!kFusedChol && !kFusedCholSubst) ldl<pABr, NS>(Lp, W);  // [A B] row r, the right-hand side of the W solve
       if constexpr (kPackDma) {
         // the image has been read for the last time in this stage: the next stage's copy on its way
         dma_out = i < N_ && pnxt != loff;
@@ -2521,7 +2530,7 @@ struct MpcR16 {
         }
       }
       if constexpr (kSubst) {
-        tri_solve_right<NS, RQ>(K, W, ro);
+        if constexpr (!kFusedCholSubst) tri_solve_right<NS, RQ>(K, W, ro);
       } else if constexpr (!kFusedChol) {
         tri_inv_cols_solve<NS, RQ>(K, XC, W, ro);
       }

@@ -455,13 +455,17 @@ FB_DEV void tri_inv_cols_solve(const double (&a)[N], double (&x)[N], double (&w)
 #ifndef FB_CHOL_FUSED
 #define FB_CHOL_FUSED 1
 #endif
-template <int N, int R, bool WITH_W>
-FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[N], double (&w)[WITH_W ? N : 1], int r, double diag_add) {
+// WITH_X / WITH_W: which of the two riders of the factorisation run (the inverse's column, the right-solve).
+// PARK: lane j's a[j] receives 1 / L[j][j] as chol_rows leaves it - for callers that go on to SUBSTITUTE with
+// the rows of the factor (the row-pair instances: subst_rows reads the reciprocal out of the row).
+template <int N, int R, bool WITH_W, bool WITH_X = true, bool PARK = false>
+FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[WITH_X ? N : 1], double (&w)[WITH_W ? N : 1], int r, double diag_add) {
   static_assert(kFmacDpp<R>, "the fused pass is written for the fused broadcast-FMA");
+  static_assert(WITH_X || WITH_W, "nothing rides along: that is chol_rows");
   bool ok = true;
   RsqrtChain ch;
   double lj = 0.0;
-  sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
+  if constexpr (WITH_X) sfor<0, N>([&](auto RR) { x[decltype(RR)::value] = (r == decltype(RR)::value) ? 1.0 : 0.0; });
   constexpr int kLevels = RsqrtChain::kStages + 2;
   auto level = [&](auto J, auto S) {
     constexpr int j = decltype(J)::value;
@@ -474,24 +478,27 @@ FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[N], double (&w)[WITH
     } else {
       lj = a[j] * ch.q;  // L[r][j] for r > j: the streams' broadcast source - written first, two
       FB_SB();           // instructions ahead of its first reader at the least (the multiplies below)
-      x[j] *= ch.q;      // final: rows < j are all folded in
+      if constexpr (WITH_X) x[j] *= ch.q;  // final: rows < j are all folded in
       if constexpr (WITH_W) w[j] *= ch.q;
+      if constexpr (PARK) a[j] = (r == j) ? ch.q : lj;
     }
     FB_SB();
   };
+  constexpr bool kShortTail = !(WITH_W && WITH_X) && !PARK;  // (one instruction behind the source's multiply: one more wait state)
   sfor<0, kLevels>([&](auto S) { level(std::integral_constant<int, 0>{}, S); });
-  if constexpr (!WITH_W) asm volatile("s_nop 0");
+  if constexpr (kShortTail) asm volatile("s_nop 0");
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int cnt = N - j - 1;
-    const double ljj = lj, xj = x[j];  // this pivot's values (level 6 of the next pivot rewrites lj)
-    double wj = 0.0;
+    const double ljj = lj;  // this pivot's values (level 6 of the next pivot rewrites lj)
+    double xj = 0.0, wj = 0.0;
+    if constexpr (WITH_X) xj = x[j];
     if constexpr (WITH_W) wj = w[j];
     const Spread<R> src = spread<R>(ljj);
     sfor<0, cnt>([&](auto I) {
       constexpr int i = decltype(I)::value;
       fmac_bcs<R, j + 1 + i, j + 1, true>(a[j + 1 + i], src, ljj);
-      fmac_bcs<R, j + 1 + i, j + 1, true, false>(x[j + 1 + i], src, xj);
+      if constexpr (WITH_X) fmac_bcs<R, j + 1 + i, j + 1, true, false>(x[j + 1 + i], src, xj);
       if constexpr (WITH_W) fmac_bcs<R, j + 1 + i, j + 1, true, false>(w[j + 1 + i], src, wj);
       if constexpr (i < kLevels) level(std::integral_constant<int, j + 1>{}, I);
     });
@@ -499,7 +506,7 @@ FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[N], double (&w)[WITH
       sfor<(cnt < kLevels ? cnt : kLevels), kLevels>(
           [&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
       // (the source's multiply directly in front of its first reader: one more wait state)
-      if constexpr (cnt <= kLevels && !WITH_W) asm volatile("s_nop 0");
+      if constexpr (cnt <= kLevels && kShortTail) asm volatile("s_nop 0");
     }
   });
   return ok;
@@ -512,6 +519,13 @@ template <int N, int R = 1>
 FB_DEV bool chol_inv_cols(double (&a)[N], double (&x)[N], int r, double diag_add) {
   double none[1] = {0.0};
   return chol_inv_fused_impl<N, R, false>(a, x, none, r, diag_add);
+}
+// chol_rows + tri_solve_right as one pass: a <- the factor as chol_rows leaves it (reciprocal diagonal parked),
+// w <- W inv(Lc)' (the row-pair instances, which substitute with the factor's rows afterwards)
+template <int N, int R = 1>
+FB_DEV bool chol_solve_right(double (&a)[N], double (&w)[N], int r, double diag_add) {
+  double none[1] = {0.0};
+  return chol_inv_fused_impl<N, R, true, false, true>(a, none, w, r, diag_add);
 }
 
 // ---- substitution with the row-held factor (the reference's solveInPlace; round 5) ----------------------

@@ -24,7 +24,7 @@ sparse = "sparse" in sys.argv[3:]  # two or three entries of order one per row: 
 warm = "warm" in sys.argv[3:]      # a second, warm-started solve per shape (teacher-forced: the oracle gets the device's guess)
 strict = r16 or os.environ.get("FUZZ_STRICT", "1") != "0"
 nqp = nref = 0
-nwarm = warm_flips = warm_bad = 0
+nwarm = warm_flips = warm_bad = warm_loose = warm_fma_agrees = warm_refine_closes = 0
 wrng = np.random.default_rng(1_000_003 + (int(sys.argv[2]) if len(sys.argv) > 2 else 1))  # (the shape stream stays as it is)
 orc = Oracle(False)
 bad = 0
@@ -63,11 +63,37 @@ for it in range(n):
         dp2 = np.abs(out2["prox_iters"].astype(int) - oc2["prox_iters"].astype(int))
         ef2 = np.array_equal(out2["eflag"], oc2["eflag"])
         nwarm += B
-        flips = int(((dn2 != 0) | (dp2 != 0)).sum())
+        # QPs WITH a solution (both exit 0): every count strict.  QPs without one (an infeasibility verdict, an
+        # iteration limit): flag and proximal count strict, the Newton count reported - their iterates run away
+        # along the certificate's ray at norms of 1e8 and more, where the device's incrementally carried residual
+        #  and the reference's freshly evaluated one part by more than an inner tolerance, and a
+        # runaway subproblem ends after a handful of iterations on one side and at max_inner_iters on the other.
+        conv = (oc2["eflag"] == 0) & (out2["eflag"] == 0)
+        flips = int((((dn2 != 0) | (dp2 != 0)) & conv).sum())
+        loose = int(((dn2 != 0) & ~conv).sum())
         warm_flips += flips
-        wbad = (not ef2) or flips > 0
+        warm_loose += loose
+        wbad = (not ef2) or flips > 0 or bool(((dp2 != 0) & ~conv).any())
+        if flips > 0 and ef2:
+            # second opinion: the oracle built with fused multiply-adds allowed
+            fm = Oracle(False, fma=True).solve_mpc(p2, g, opts=o, nthreads=orc.num_threads())[4]
+            same_as_fma = ((out2["newton_iters"] == fm["newton_iters"]) & (out2["prox_iters"] == fm["prox_iters"]))[conv & ((dn2 != 0) | (dp2 != 0))]
+            warm_fma_agrees += int(same_as_fma.sum())
+            # ... and the device with its refinement option on (fbstab_options_t::reserved = 1): a QP on which the
+            # explicit inverse of the one-row instances left more of a Newton system than the tolerance takes the
+            # oracle's counts then (tests/test_gpu_components.py::test_warm_started_second_solve_...)
+            h2 = hip_api.Options()
+            for name, _ in h2._fields_:
+                setattr(h2, name, getattr(o, name))
+            h2.reserved = 1
+            s.UpdateOptions(h2)
+            z3, l3, v3 = g[0].copy(), g[1].copy(), g[2].copy()
+            out3 = s.Solve({k: np.ascontiguousarray(a) for k, a in p2.arrays.items()}, z3, l3, v3, np.zeros((B, p.nv)))
+            flipped = conv & ((dn2 != 0) | (dp2 != 0))
+            warm_refine_closes += int(((out3["newton_iters"] == oc2["newton_iters"]) & (out3["prox_iters"] == oc2["prox_iters"]))[flipped].sum())
         warm_bad += wbad
-        wline = f" | warm: flags_equal={ef2} prox_flips={int((dp2 != 0).sum())} newton_flips={int((dn2 != 0).sum())} dn_max={dn2.max()}" + ("  <-- CHECK(warm)" if wbad else "")
+        wline = (f" | warm: flags_equal={ef2} converged: prox_flips={int(((dp2 != 0) & conv).sum())} newton_flips={int(((dn2 != 0) & conv).sum())}"
+                 f" no-solution QPs with another Newton count={loose} (dn_max={dn2.max()})" + ("  <-- CHECK(warm)" if wbad else ""))
         if wbad:
             print("   warm device: eflag", out2["eflag"].tolist(), "prox", out2["prox_iters"].tolist(), "newton", out2["newton_iters"].tolist(),
                   "residual", [f"{r:.2e}" for r in out2["residual"]])
@@ -90,4 +116,5 @@ for it in range(n):
               "residual", [f"{r:.2e}" for r in oc["residual"]])
     print(f"({N},{nx},{nu},{nc}) B={B} {kn:32s} flags_equal={okf} dnewton_max={dn.max()} nonzero={int((dn != 0).sum())} dz={dz:.2e} refined={refined}{flag}{wline}")
 print(f"shapes to check: {bad}   ({n} shapes, {nqp} QPs, {nref} refined Newton steps; strict={strict})"
-      + (f"   warm solves: {nwarm}, with any count different: {warm_flips} in {warm_bad} shapes" if warm else ""))
+      + (f"   warm solves: {nwarm}; QPs with a solution and any count different: {warm_flips} (of them the FMA build of the oracle takes "
+         f"the device's counts on {warm_fma_agrees}, the device with refinement on takes the oracle's on {warm_refine_closes}), shapes to check {warm_bad}; QPs without a solution and another Newton count: {warm_loose}" if warm else ""))

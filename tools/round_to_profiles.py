@@ -50,6 +50,18 @@ sq["derived"] = {"issuing_share_of_wave_cycles": m["SQ_ACTIVE_INST_ANY"] / m["SQ
                  "waiting_share": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
                  "valu_instructions_per_newton_step": m["SQ_INSTS_VALU"] / newton,
                  "l2_hit_rate": m["TCC_HIT"] / m["TCC_REQ"]}
+sq["batch"] = B
+# the shader clock the wavefronts ran at (tools/stamp_report.py: s_memtime against the 100 MHz counter), the
+# figure bench.py's issue_bound_qps divides by
+try:
+    import re
+    txt = open(os.path.join(src, "mpc_wave_time_shares.txt")).read()
+    mm = re.search(r"mean shader clock over the wavefronts' lifetimes: (\d+) MHz", txt)
+    if mm:
+        sq["mean_shader_clock_mhz"] = float(mm.group(1))
+        sq["mean_shader_clock_source"] = f"profiles/{prefix}_r16_wave_time_shares.txt (diagnostic build, same sources)"
+except OSError:
+    pass
 json.dump(sq, open(dst("r16_sq_counters.json"), "w"), indent=1)
 
 dpath = os.path.join(src, "pmc_dense", "summary.json")
