@@ -227,6 +227,9 @@ struct R16Queue {
       if (taken) return -1;
       taken = true;
     } else {
+      // a batch that does not outnumber the launch's wavefronts: one QP per wavefront (fbstab_hip.hip sizes
+      // the grid to the batch then); the other rows only lend their lanes to the cooperative passes
+      if (batch <= (int)gridDim.x && row() != 0) return -1;
       if (tid() == 0) q = atomicAdd(&ctl[0], 1);
       q = bcri<P::LPQ / 16, 0>(q);
     }

@@ -660,7 +660,9 @@ int fbstab_hip_mpc_create_in_flight(int N, int nx, int nu, int nc, int max_batch
   if (env && atoi(env) > 0) per_cu = atoi(env);
   s->workgroups = cus * per_cu;
   {
-    const int need = (max_batch + s->qps_per_wg - 1) / s->qps_per_wg;
+    // (record kernels: a batch that does not outnumber the grid is SPREAD, one QP per wavefront - below -, so a
+    // handle for a small max_batch keeps one workgroup per QP rather than one per four)
+    const int need = s->rec ? max_batch : (max_batch + s->qps_per_wg - 1) / s->qps_per_wg;
     if (s->workgroups > need) s->workgroups = need;
   }
   const long long ws_doubles = s->rec ? s->rec->ws_doubles(N) : (long long)s->lay.ws_doubles;
@@ -756,6 +758,11 @@ static int mpc_solve_impl(fbstab_mpc_handle_t h, int batch, const fbstab_mpc_bat
   }
   HIP_TRY(hipMemsetAsync(h->counter, 0, kQueueBytes, s));
   int grid = (batch + h->qps_per_wg - 1) / h->qps_per_wg;
+  // Record kernels, a batch of no more QPs than the handle has workgroups: one QP per WAVEFRONT (row 0 of
+  // each; fb_record_kernel.h, R16Queue::fetch) instead of four - the rows of a wavefront share its program
+  // counter and its cooperative passes, so four QPs on one wavefront finish with the slowest of them and
+  // queue for each other's passes, while the chip has SIMDs to spare (round 6: batch 16, 7.9 -> ms below).
+  if (h->rec && batch <= h->workgroups) grid = batch;
   if (grid > h->workgroups) grid = h->workgroups;
   HIP_TRY(hipEventRecord(h->ev0, s));
   if (d_trace) {
