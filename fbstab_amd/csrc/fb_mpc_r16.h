@@ -2296,15 +2296,17 @@ struct MpcR16 {
     return o.ok;
   }
   // ---- one refinement of the step in the record ---------------------------------
-  // An OPTION, off by default (fbstab_options_t::reserved).  Which instances it matters for: the ONE-ROW
-  // instances (<12,4,20>, <12,4,32>: kSubst false) multiply with an explicitly inverted inv(Lc) where the
-  // reference substitutes (riccati_linear_solver.cc:234-325) - forward stable, not backward stable: on stages
-  // whose Pi_i keeps eigenvalues of order sigma (nx > N nu) the step can leave a residual r - V dx orders above
-  // eps |V| |dx|.  Measured in round 6: a warm-started one-step solve of a (3, 12, 1, 17) QP left 1.4e-6 where
-  // the oracle leaves 2e-8 and took a second proximal iteration; with the option on it takes the oracle's
-  // counts (tests/test_gpu_components.py::test_warm_started_second_solve_...).  The ROW-PAIR instances and the
-  // flat-vector kernel substitute with the factor itself since round 5 (kSubst, fb_row16.h subst_rows): for
-  // them the option only ever makes a solve more accurate than the reference's.  refine_step() solves
+  // An OPTION, off by default (fbstab_options_t::reserved).  Where it can still matter: the ONE-ROW instances
+  // (<12,4,20>, <12,4,32>) in the ROW form of the costate step (bounds, sparse rows) multiply with an explicitly
+  // inverted inv(Lc) where the reference substitutes (riccati_linear_solver.cc:234-325) - forward stable, not
+  // backward stable: on stages whose Pi_i keeps eigenvalues of order sigma (nx > N nu) a step can leave a
+  // residual r - V dx orders above eps |V| |dx|.  The REFERENCE form of those instances did the same until round
+  // 6, and there it showed: a warm-started one-step solve of a (3, 12, 1, 17) QP left 1.4e-6 where the oracle
+  // leaves 2e-8 and took a second proximal iteration (the option closed it: one step refined, the oracle's
+  // counts); that form now substitutes (newton_core: FB_R16_SUBST_REF_FORM) and takes the oracle's counts as it
+  // is.  The ROW-PAIR instances and the flat-vector kernel substitute since round 5 (kSubst, fb_row16.h
+  // subst_rows): for all of those the option only ever makes a solve more accurate than the reference's.
+  // refine_step() solves
   // V ddx = r - V dx with the SAME factors (the forward sweep is run again on the residual, which it forms
   // from the step in the record; the factorisation is recomputed - identical values - rather than kept:
   // W and, in the row form, inv(Pi) are not in the record) and adds ddx to the step; dv follows the third
@@ -2351,6 +2353,17 @@ struct MpcR16 {
                                     lds_ptr lds_row, pk_ptr Lp, const int N_, const bool bnd, const double tp,
                                     int loff, double sigma, double alpha) {
     // Locals only below: the lambdas capture no object.
+    // (round 6) The REFERENCE form of the costate step substitutes with the factor on the one-row instances as
+    // well: that form serves the QPs whose constraint rows are dense or large - the reference's servo motor, random
+    // dense rows - and it is where the explicit inverse showed (a warm-started one-step solve of a (3, 12, 1, 17)
+    // QP, nx > N nu: 1.4e-6 left of the Newton system where the oracle leaves 2e-8, one proximal iteration more
+    // than the oracle - LABNOTES R6.5).  The ROW form - bounds, sparse rows: the headline - keeps the explicit
+    // inverse and its independent streams.  A per-template choice: the two forms are two copies of this function.
+#ifndef FB_R16_SUBST_REF_FORM
+#define FB_R16_SUBST_REF_FORM 1
+#endif
+    constexpr bool kSubst = MpcR16::kSubst || (FB_R16_SUBST_REF_FORM != 0 && !ROW);
+    constexpr bool kAsmFwdX = MpcR16::kAsmImages && !kSubst;  // the forward stage's hand-written blocks move COLUMNS of the inverse
     const int r = c.tid;
     lds_ptr Tr = lds_row;
     lds_ptr Cl = lds_row;
@@ -2541,7 +2554,7 @@ struct MpcR16 {
       double XR[NS];
       double Xp[nXs + 1];
       c.sync();
-      if constexpr (kAsmImages) {
+      if constexpr (kAsmFwdX) {
         img_write_x(Tr + kXl + ro, ro, XC);
         c.sync();
         sfor<0, NS>([&](auto J) { XR[decltype(J)::value] = 0.0; });

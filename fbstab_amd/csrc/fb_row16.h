@@ -484,9 +484,14 @@ FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[WITH_X ? N : 1], dou
     }
     FB_SB();
   };
-  constexpr bool kShortTail = !(WITH_W && WITH_X) && !PARK;  // (one instruction behind the source's multiply: one more wait state)
+  // (where the source's multiply stands directly in front of its first reader: with both riders two multiplies
+  // follow it; with one, one more wait state; PARK on one row per QP - the select that follows is the compiler's
+  // to place - two.  Row pairs guard every group themselves, fmac_bcs.)
+  constexpr bool kShortTail = !(WITH_W && WITH_X) && !PARK;
+  constexpr bool kParkTail = PARK && R == 1;
   sfor<0, kLevels>([&](auto S) { level(std::integral_constant<int, 0>{}, S); });
   if constexpr (kShortTail) asm volatile("s_nop 0");
+  if constexpr (kParkTail) asm volatile("s_nop 1");
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int cnt = N - j - 1;
@@ -507,6 +512,7 @@ FB_DEV bool chol_inv_fused_impl(double (&a)[N], double (&x)[WITH_X ? N : 1], dou
           [&](auto S) { level(std::integral_constant<int, j + 1>{}, S); });
       // (the source's multiply directly in front of its first reader: one more wait state)
       if constexpr (cnt <= kLevels && kShortTail) asm volatile("s_nop 0");
+      if constexpr (cnt <= kLevels && kParkTail) asm volatile("s_nop 1");
     }
   });
   return ok;

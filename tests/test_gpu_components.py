@@ -257,20 +257,21 @@ def test_random_shapes_with_sparse_constraint_rows_on_every_mpc_instance(hip, or
 
 @pytest.mark.parametrize("idx", range(0, len(_MPC_SHAPES), 2))
 def test_warm_started_second_solve_on_every_mpc_instance(hip, oracle, oracle_fma, idx):
-    """tools/fuzz_shapes.py ... warm, a fixed subset (the tool's twelve seeds: profiles/r06_*):
-    every shape is solved, then solved AGAIN with x0 moved by a few per cent, warm-started from the device's
-    first solution - device and oracle get the same guess, so the second solve is an independent comparison on
-    identical inputs.  QPs with a solution: flag, proximal and Newton count equal to the oracle's - or to the
-    oracle's FMA build where the two builds of the oracle part (the one-step kind of
-    test_the_one_count_the_references_rounding_decides) - or, MEASURED in round 6 on shape 2 of this list
-    ((3, 12, 1, 17): nx > N nu, the stages whose Pi keeps eigenvalues of order sigma), one proximal iteration
-    MORE than the oracle on a warm-started one-step solve: the one-row instances multiply with an explicitly
-    inverted factor, which left 1.4e-6 of that Newton system behind where the oracle's
-    substitution leaves 2e-8 - over abs_tol by itself.  That is what the refinement option is for
-    (fbstab_options_t::reserved = 1: one step refined, the oracle's counts): such a QP must take the oracle's
-    counts with the option on.  QPs that end without a solution (the moved x0 makes some
-    infeasible): flag and proximal count; their Newton counts are the tool's to report, not a test's to bound
-    (iterates at norms of 1e8: the carried residual and a freshly evaluated one part by more than a tolerance)."""
+    """tools/fuzz_shapes.py ... warm, a fixed subset (the tool's twelve seeds:
+    profiles/r06_*_fuzz_warm_start_family_12_seeds.txt): every shape is solved, then solved AGAIN with x0 moved
+    by a few per cent, warm-started from the device's first solution - device and oracle get the same guess, so
+    the second solve is an independent comparison on identical inputs.  QPs with a solution: flag, proximal and
+    Newton count equal to the oracle's, or to the oracle's FMA build where the two builds of the oracle part
+    (the one-step kind of test_the_one_count_the_references_rounding_decides).  QPs that end without one (the
+    moved x0 makes some infeasible): flag and proximal count; their Newton counts are the tool's to report, not
+    a test's to bound (iterates at norms of 1e8: the carried residual and a freshly evaluated one part by more
+    than a tolerance).
+    Shape 2 of the list ((3, 12, 1, 17): nx > N nu, stages whose Pi keeps eigenvalues of order sigma) is the
+    one that FAILED this test when it was written: the one-row instances multiplied with an explicitly inverted
+    factor in the reference form of the costate step too, a warm-started one-step solve left 1.4e-6 of its
+    Newton system behind (the oracle's substitution: 2e-8) and took a second proximal iteration.  That form
+    substitutes since (fb_mpc_r16.h: FB_R16_SUBST_REF_FORM; LABNOTES R6.5) and the shape passes as it is, with
+    no step refined."""
     (N, nx, nu, nc), kern = _MPC_SHAPES[idx]
     rng = np.random.default_rng(9000 + idx)
     B = int(rng.integers(3, 12))
@@ -287,8 +288,9 @@ def test_warm_started_second_solve_on_every_mpc_instance(hip, oracle, oracle_fma
     p2.arrays["x0"] = np.ascontiguousarray(x0 * (1.0 + 0.05 * rng.standard_normal(x0.shape)) + 0.01 * rng.standard_normal(x0.shape))
     guess = (z.copy(), l.copy(), v.copy())
     y2 = np.zeros((B, p.nv))
-    data2 = {k: np.ascontiguousarray(a) for k, a in p2.arrays.items()}
-    out = s.Solve(data2, z, l, v, y2)
+    out = s.Solve({k: np.ascontiguousarray(a) for k, a in p2.arrays.items()}, z, l, v, y2)
+    assert s.refined_steps() == 0
+    s.close()
     oc = oracle.solve_mpc(p2, guess, opts=o, nthreads=oracle.num_threads())[4]
     assert np.array_equal(out["eflag"], oc["eflag"])
     assert np.array_equal(out["prox_iters"][oc["eflag"] != 0], oc["prox_iters"][oc["eflag"] != 0])
@@ -297,17 +299,7 @@ def test_warm_started_second_solve_on_every_mpc_instance(hip, oracle, oracle_fma
     if not same[conv].all():
         of = oracle_fma.solve_mpc(p2, guess, opts=o, nthreads=oracle_fma.num_threads())[4]
         same = same | ((out["prox_iters"] == of["prox_iters"]) & (out["newton_iters"] == of["newton_iters"]))
-    if not same[conv].all():
-        # what is left must be the linear solve's leftover: more iterations than the oracle, never fewer, and
-        # the oracle's counts once the step is refined
-        assert (out["prox_iters"] >= oc["prox_iters"])[conv & ~same].all() and int((conv & ~same).sum()) <= 1
-        s.UpdateOptions(_opts(hip, default_options(reserved=1)))
-        zr, lr, vr = guess[0].copy(), guess[1].copy(), guess[2].copy()
-        outr = s.Solve(data2, zr, lr, vr, np.zeros((B, p.nv)))
-        assert s.refined_steps() >= 1
-        same = same | ((outr["prox_iters"] == oc["prox_iters"]) & (outr["newton_iters"] == oc["newton_iters"]))
-        assert same[conv].all(), (out[conv], oc[conv], outr[conv])
-    s.close()
+    assert same[conv].all(), (out[conv], oc[conv])
 
 
 def test_the_one_count_the_references_rounding_decides(hip, oracle, oracle_fma):
