@@ -165,3 +165,58 @@ int main() { return 0; }
     with open(os.path.join(ROOT, "fbstab_amd", "csrc", "fb_shard.h")) as f:
         text = f.read()
     assert "ncclGetVersion" in text and "version < 2700 || version >= 30000" in text
+
+
+def test_record_kernels_stay_inside_the_register_budget():
+    """LABNOTES R6.3: a record kernel that allocates more than 496 of a SIMD's 512 registers leaves no room for
+    any other kernel's wavefront and launches on several streams run one after the other (630 k -> 250 k QP/s).
+    The build gates on tools/check_vgpr_budget.py; here the same check on the library the tests load: every
+    <12,4,*> and <18,5,10> record kernel within the budget, the checker refusing a budget they do not meet."""
+    import subprocess
+    import sys
+    from fbstab_amd import hip_api
+    hip_api.load_library()
+    lib = hip_api.current_library_path()
+    tool = os.path.join(ROOT, "tools", "check_vgpr_budget.py")
+    r = subprocess.run([sys.executable, tool, "--max", "496", "--only", "fbstab_mpc_r16_kernel", lib],
+                       capture_output=True, text=True)
+    rows = [l for l in r.stdout.splitlines() if "fbstab_mpc_r16_kernel<" in l]
+    assert len(rows) >= 30, r.stdout[-500:] + r.stderr[-500:]
+    for l in rows:
+        if "<24, 8," in l:
+            continue   # (reported, not refused: their noinline refinement sweeps are out of the kernel attribute's reach)
+        assert "over the budget" not in l, l
+        assert int(l.split("->")[1].split()[0]) <= 496, l
+    headline = [l for l in rows if "<12, 4, 20, false, true, false, 1>" in l]
+    assert len(headline) == 1 and int(headline[0].split("->")[1].split()[0]) == 496
+    r2 = subprocess.run([sys.executable, tool, "--max", "400", "--only", "fbstab_mpc_r16_kernelILi12ELi4ELi20ELb0ELb1ELb0", lib],
+                        capture_output=True, text=True)
+    assert r2.returncode == 1 and "over the register budget of 400" in r2.stdout
+
+
+def test_options_validate_resets_a_stray_refinement_field():
+    """ADVICE r5: fbstab_options_t::reserved switches iterative refinement on; a caller that fills the struct by hand
+    and leaves the field uninitialised must not get it by accident.  fbstab_options_validate resets values outside
+    0..60 to 0 (compiled here from include/fbstab_types.h, plain C)."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "fbstab_types.h"
+int main(void) {
+  fbstab_options_t o; fbstab_options_default(&o);
+  int bad = 0;
+  o.reserved = -7; fbstab_options_validate(&o); bad += o.reserved != 0;
+  o.reserved = 12345; fbstab_options_validate(&o); bad += o.reserved != 0;
+  o.reserved = 3; fbstab_options_validate(&o); bad += o.reserved != 3;
+  o.reserved = 0; fbstab_options_validate(&o); bad += o.reserved != 0;
+  printf("%d\n", bad); return bad;
+}
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        c = os.path.join(tmp, "t.c")
+        with open(c, "w") as f:
+            f.write(src)
+        exe = os.path.join(tmp, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe, c])
+        assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == "0"
