@@ -222,7 +222,9 @@ int fbstab_hip_mpc_receding_sweep(fbstab_mpc_handle_t handle, int batch, const f
  * handle, measured with HIP events on the stream it ran on (ms; < 0 if none). */
 double fbstab_hip_mpc_last_kernel_ms(fbstab_mpc_handle_t handle);
 /* Bytes of device scratch and of LDS per workgroup the handle uses, and the
- * number of resident workgroups it launches (for DESIGN.md / diagnostics). */
+ * number of resident workgroups it launches (for DESIGN.md / diagnostics).  (Record kernels, round 6: a batch
+ * of no more QPs than `workgroups` is spread one QP per wavefront - a handle created for a small max_batch
+ * therefore keeps one workgroup, and four QP slots of scratch, per QP - LABNOTES R6.6.) */
 int fbstab_hip_mpc_query(fbstab_mpc_handle_t handle, long long* scratch_bytes,
                          int* lds_bytes, int* workgroups, int* threads);
 
