@@ -156,8 +156,25 @@ struct MpcR16 {
   // pair: pair p of QP q at p * kPackPair + q * 2 LPQ, lane r at + 2 r.  A slot pair of all the wavefront's
   // lanes is then 1 KiB of consecutive LDS in lane order - what an LDS-DMA load writes
   // (global_load_lds_dwordx4: wave-uniform base + lane x 16 bytes; stage_pack_dma below).
-  static constexpr int kPackPair = 2 * LPQ * kQpPerWave;  // doubles between consecutive slot pairs of a QP's image
-  static constexpr int kPackArea = kQpPerWave * kPackLds;  // doubles of the wavefront's area
+  // Round 6 (FB_R16_ABC_FROM_LDS, the default): the images are laid out per QP instead - pair p of QP q at
+  // q * kPackQp + p * kPackPair, lane r at + 2 r - with a pair stride of 2 LPQ + 2 doubles: PADDED, so that lane r
+  // can read COLUMN r of a row-held matrix out of the image (slot pABr + r, entry j: the lanes' addresses are
+  // (r >> 1) kPackPair + (r & 1) + 2 j apart - with the stride a multiple of the 64 banks all sixteen would
+  // hit two bank pairs, with 2 LPQ + 2 they fall on 16 different ones).  That is what lets the backward sweep
+  // take the columns of [A B] from the rows it has staged anyway instead of reading the 12 column slots of
+  // the matrix copy from memory: for a plant whose matrices change with the stage - 31 copies per sweep, a
+  // workload at the HBM's limit with eight launches in flight - 12 of the 116 slots a stage pair moves.
+  // (The interleaved layout stays behind FB_R16_PACK_DMA: the LDS-DMA load writes a wavefront's lanes in order.)
+#ifndef FB_R16_ABC_FROM_LDS
+#define FB_R16_ABC_FROM_LDS 1
+#endif
+#ifndef FB_R16_PACK_DMA
+#define FB_R16_PACK_DMA 0
+#endif
+  static constexpr bool kAbcFromLds = FB_R16_ABC_FROM_LDS != 0 && FB_R16_PACK_DMA == 0 && kPackInLds;
+  static constexpr int kPackPair = kAbcFromLds ? 2 * LPQ + 2 : 2 * LPQ * kQpPerWave;  // doubles between consecutive slot pairs of a QP's image
+  static constexpr int kPackQp = kAbcFromLds ? (kPackLdsSlots / 2) * kPackPair : 2 * LPQ;  // doubles between the images of two QPs
+  static constexpr int kPackArea = kAbcFromLds ? kQpPerWave * kPackQp : kQpPerWave * kPackLds;  // doubles of the wavefront's area
   // this lane's view of the matrix copy in use
   typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
   static constexpr int kLdsDoubles = LPQ * (CS > TS ? CS : TS);  // a QP's own region: transpose buffer / triangle images
@@ -2691,15 +2708,27 @@ struct MpcR16 {
     {
       const double* R = R0 + (long)N_ * kRec;
       load_fac(R);
-      ldv<pABc, NX>(P0 + pcur, Ac);
+      if constexpr (!kAbcFromLds) ldv<pABc, NX>(P0 + pcur, Ac);
       load_bwd<REFINE>(R, Rd, bin);
     }
+    // (kAbcFromLds) where this lane finds column r of [A B] in the staged image: slot pABr + r, entry j at + 2 j
+    // (lanes without a row or column - NS < LPQ: the <18,5,10> instance - have no such slot: they read lane 0's
+    // and get the zero the column slots of the matrix copy hold for them)
+    const int rcol = (NS < LPQ && r >= NS) ? 0 : r;
+    [[maybe_unused]] const lds_ptr abcol = Lp - 2 * r + ((pABr + rcol) >> 1) * kPackPair + ((pABr + rcol) & 1);
     for (int i = N_; i >= 0; i--) {
       FB_PHASE(bwd_top);
       double* R = R0 + (long)i * kRec;
       const double* Rp = i > 0 ? R - kRec : R;  // the stage fetched next (stage 0 once more at the end)
       if constexpr (kPackDma) stage_pack_dma_wait(dma_out);
       stage_pack_s(c, P0, Lp, loff, pcur);
+      if constexpr (kAbcFromLds) {
+        // the columns of this stage's [A B] out of the rows just staged (entries j < NX of lanes j: rows of A, B)
+        sfor<0, NX>([&](auto J) {
+          const double e = abcol[2 * decltype(J)::value];
+          Ac[decltype(J)::value] = (NS < LPQ && r >= NS) ? 0.0 : e;
+        });
+      }
       pcur = po[i > 0 ? i - 1 : 0];
       int ro = r;
       asm volatile("" : "+v"(ro));
@@ -2740,7 +2769,7 @@ struct MpcR16 {
         bc_all<NX, RQ>(lp, lpb);
         u = dot4<NX>(Ac, lpb);
       }
-      ldv<pABc, NX>(P0 + pcur, Ac);
+      if constexpr (!kAbcFromLds) ldv<pABc, NX>(P0 + pcur, Ac);
       c.sync();
       // column r and row r of inv(Lc), row r of inv(Pi)
       double XC[NS], XR[NS];

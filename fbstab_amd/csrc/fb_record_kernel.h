@@ -187,7 +187,7 @@ struct R16Queue {
   // this row's image in the wavefront's matrix-copy area (in front of the rows' own regions)
   static __device__ __forceinline__ lds_ptr pack_lds() {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
-    return (lds_ptr)smem_ + row() * 2 * P::LPQ;
+    return (lds_ptr)smem_ + row() * P::kPackQp;
   }
   // Twenty spare doubles of the row's LDS region: the solver loop parks its scalars
   // there while a Newton step and its line search run (Solver::solve_stream).
