@@ -27,7 +27,7 @@ for rep in range(2):
     out = hip_api.out_to_numpy(s.Solve(data, z, l, v, y))
     ms = s.last_kernel_ms()
 lib.fbstab_hip_debug_stamps(st, 1)
-newton = max(int(st[31]), 1)   # newton steps executed by row 0 of each wave
+newton = max(int(st[31]) or int(st[27]), 1)   # wave-level Newton steps (st[31]: an older build's count by row 0)
 stages = newton * 31
 if st[30]:
     print("backtracking trials per newton step (row 0):", st[30] / newton)
@@ -58,7 +58,7 @@ if st[29]:
     print(f"mean shader clock over the wavefronts' lifetimes: {st[28] / (st[29] * 0.01):.0f} MHz "
           f"(sum of wave lifetimes {st[29] * 1e-5:.1f} ms)")
 
-if st[4] or st[3]:
+if (st[4] or st[3]) and not st[9]:  # (slots 0..5 are phase laps in a -DFB_STAMP build)
     tot = float(st[28])
     print(f"migration: invitations {st[4]}, solves taken over {st[3]}, sleep trips {st[2]}; wave cycles: idle-row block "
           f"{100.0 * st[0] / tot:.1f} %, owner block {100.0 * st[1] / tot:.1f} %, sleeping {100.0 * st[5] / tot:.1f} %")
