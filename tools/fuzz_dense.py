@@ -51,7 +51,8 @@ for it in range(n):
         okf = np.array_equal(out["eflag"], oc["eflag"]) and np.array_equal(out["prox_iters"], oc["prox_iters"])
         good = oc["eflag"] == 0
         dz = float(np.abs(z - c[0])[good].max()) if good.any() else 0.0
-        flag = "" if (okf and dn.max() <= 2 and dz < 1e-4) else "  <-- CHECK"
+        # (the default / pivoted order claims the oracle's counts: strict; the opt-in orders pivot differently by the caller's choice)
+        flag = "" if (okf and dn.max() <= (0 if m in ("default", "pivoted") else 2) and dz < 1e-4) else "  <-- CHECK"
         t = tot[m]
         t["bad"] += flag != ""
         t["ndiff"] += int((dn != 0).sum())

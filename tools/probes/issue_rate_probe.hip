@@ -24,6 +24,22 @@
 #define MIX2(k) FMA64(k) ADDU(k) MOV32(k)
 #define MIX3(k) FMA64(k) ADDU(k) MOV32(k) CND32(k)
 
+// round 6: DEPENDENT streams - every FMA into one accumulator, into two, into four (the stream above goes round eight)
+#define FMA64D1(k) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(c[0]) : "v"(a), "v"(y));
+#define FMA64D2(k) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(c[k % 2]) : "v"(a), "v"(y));
+#define FMA64D4(k) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(c[k % 4]) : "v"(a), "v"(y));
+// the K row of the record kernel's bounds path (fb_mpc_r16.h, k_bounds): broadcast, product, FMA into ONE accumulator
+#define TRI(k)                                                                                                   \
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:" #k " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(t[k]) : "v"(y)); \
+  asm volatile("v_mul_f64 %0, %1, %0" : "+v"(t[k]) : "v"(c[k]));                                                 \
+  asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(sacc) : "v"(t[k]), "v"(c[k]));
+// the same arithmetic with the eight products formed ahead of the chain
+#define TRI_A(k) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:" #k " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(t[k]) : "v"(y));
+#define TRI_B(k) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(t[k]) : "v"(c[k]));
+#define TRI_C(k) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(sacc) : "v"(t[k]), "v"(c[k]));
+// one LDS round trip: write, wait, read back, wait
+#define LDSRT(k) asm volatile("ds_write_b64 %1, %0\n\ts_waitcnt lgkmcnt(0)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(c[k]) : "v"(laddr) : "memory");
+
 template <int MODE>
 __global__ void rate(double* out, long long* cyc, int iters) {
   const int lane = threadIdx.x & 63, lane2 = lane ^ 5;
@@ -32,6 +48,9 @@ __global__ void rate(double* out, long long* cyc, int iters) {
   double c[8];
   float f[8];
   int u[8];
+  double t[8], sacc = 0.5;
+  __shared__ double lbuf[512];
+  const unsigned laddr = (unsigned)(unsigned long)(lbuf + threadIdx.x);
   for (int k = 0; k < 8; k++) { c[k] = k * 0.125 + lane; f[k] = k * 0.25f; u[k] = k + lane; }
   asm volatile("s_nop 4");
   const long long t0 = __builtin_readcyclecounter();
@@ -49,10 +68,17 @@ __global__ void rate(double* out, long long* cyc, int iters) {
     else if (MODE == 10) { REP8(MIX1) }
     else if (MODE == 11) { REP8(MIX2) }
     else if (MODE == 12) { REP8(MIX3) }
+    else if (MODE == 13) { REP8(FMA64D1) }
+    else if (MODE == 14) { REP8(FMA64D2) }
+    else if (MODE == 15) { REP8(FMA64D4) }
+    else if (MODE == 16) { REP8(TRI) }
+    else if (MODE == 17) { for (int g = 0; g < 8; g++) { REP8_(TRI_A) REP8_(TRI_B) REP8_(TRI_C) } }
+    else if (MODE == 18) { REP8(LDSRT) }
   }
   const long long t1 = __builtin_readcyclecounter();
   double s = 0;
-  for (int k = 0; k < 8; k++) s += c[k] + f[k] + u[k];
+  for (int k = 0; k < 8; k++) s += c[k] + f[k] + u[k] + (MODE == 16 || MODE == 17 ? t[k] : 0.0);
+  s += sacc;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + y;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -93,5 +119,10 @@ int main() {
   printf("   two per SIMD         %6.2f\n", run<0>(out, cyc, it, 2) / 64);
   printf("   four per SIMD        %6.2f\n", run<0>(out, cyc, it, 4) / 64);
   printf("v_fmac_f64_dpp stream, two / four per SIMD: %6.2f / %6.2f\n", run<3>(out, cyc, it, 2) / 64, run<3>(out, cyc, it, 4) / 64);
+  printf("DEPENDENT v_fma_f64 streams, one wavefront per SIMD, cycles per instruction: into ONE accumulator %6.2f, alternating two %6.2f, round four %6.2f (round eight: the first line)\n",
+         run<13>(out, cyc, it, 1) / 64, run<14>(out, cyc, it, 1) / 64, run<15>(out, cyc, it, 1) / 64);
+  printf("broadcast (v_mov_b64_dpp) -> v_mul_f64 -> v_fmac_f64 into one accumulator, cycles per TRIPLE: as a chain %6.2f, eight products formed ahead of the chain %6.2f\n",
+         run<16>(out, cyc, it, 1) / 64, run<17>(out, cyc, it, 1) / 64);
+  printf("LDS round trip (ds_write_b64, wait, ds_read_b64, wait), cycles: %6.1f\n", run<18>(out, cyc, it, 1) / 64);
   return 0;
 }
