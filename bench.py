@@ -698,14 +698,16 @@ def mpc_alg_bytes(N, nx, nu, nc):
     return data + 8 * (nz + nl + nv) + 8 * (nz + nl + 2 * nv) + 40
 
 
-def bench_wide(torch, dev, fx, hip_api, reps=3):
+def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=16):
     """The row-pair record instances (stage widths 17..32), one launch at a time, device pointers
     (the kernel furthest below its roofline had no driver number):
       ltv_30_20_6_16   2048 random time-varying QPs of (N, nx, nu, nc) = (30, 20, 6, 16) - 64 distinct problems
                        tiled over the batch, tools/shape_bench.py's workload - on fbstab_mpc_r32_kernel<24,8,16>;
       reactor_N80      1024 perturbed CopolymerizationReactor problems, N = 80, nx = 18, nu = 5, nc = 10
                        (fbstab/test/ocp_generator.cc:73-174; tools/reactor_bench.py) on <18,5,10>.
-    `roofline`: the shape's own algorithmic bytes over the launch's duration against the HBM peak."""
+    `roofline`: the shape's own algorithmic bytes over the launch's duration against the HBM peak.
+    `value` is ONE launch at a time; `in_flight` is the same batch as a stream, `in_flight` launches on as many
+    streams (the headline's regime), `stream_steps` timed launches after one untimed launch per lane."""
     out = {}
     def run(name, p, what):
         N, nx, nu, nc = p.sizes()
@@ -731,6 +733,36 @@ def bench_wide(torch, dev, fx, hip_api, reps=3):
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_qp": ab}}
         s.close()
+        # the same batch as a STREAM: `lanes` launches in flight on as many streams - the headline's regime
+        # (tools/wide_in_flight.py; a stream of batches fills the tail one launch leaves: LABNOTES R6.11)
+        lanes = []
+        for _ in range(in_flight):
+            h = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B, handles_in_flight=in_flight)
+            lanes.append(dict(s=h, st=torch.cuda.Stream(device=dev), z=mk(p.nz), l=mk(p.nl), v=mk(p.nv), y=mk(p.nv),
+                              out=torch.zeros((B, 40), dtype=torch.uint8, device=dev)))
+        def step(k):
+            ln = lanes[k % in_flight]
+            with torch.cuda.stream(ln["st"]):
+                for a in (ln["z"], ln["l"], ln["v"]):
+                    a.zero_()
+                ln["s"].Solve(data, ln["z"], ln["l"], ln["v"], ln["y"], out=ln["out"], stream=ln["st"].cuda_stream, async_=True)
+        for k in range(in_flight):
+            step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(stream_steps):
+            step(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        oo = [hip_api.out_to_numpy(ln["out"]) for ln in lanes]
+        out[name]["in_flight"] = {"value": B * stream_steps / dt, "unit": "QPs/sec", "steps": stream_steps,
+                                  "steps_in_flight": in_flight, "ms_per_step": 1e3 * dt / stream_steps,
+                                  "workgroups_per_launch": lanes[0]["s"].query()["workgroups"],
+                                  "mean_newton_iters": float(np.mean([x["newton_iters"].mean() for x in oo])),
+                                  "all_converged": bool(all((x["eflag"] == 0).all() for x in oo))}
+        for ln in lanes:
+            ln["s"].close()
+        del lanes
         del data
         torch.cuda.empty_cache()
     one = fx.random_ltv_mpc(np.random.default_rng(5), 64, 30, 20, 6, 16)

@@ -150,3 +150,7 @@ def test_round_6_fields_of_the_bench_line():
         for k, w in r["wide"].items():
             assert w["value"] > 0 and w["unit"] == "QPs/sec" and w["all_converged"] in (True, False), (path, k)
             assert w["kernel"].startswith("fbstab_mpc_r32_kernel") and 0 < w["roofline"]["frac"] < 1, (path, k)
+            if "in_flight" in w:  # (the same batch as a stream of launches: the headline's regime)
+                f = w["in_flight"]
+                assert f["value"] > 0 and f["unit"] == "QPs/sec" and f["steps_in_flight"] >= 2 and f["steps"] >= f["steps_in_flight"], (path, k)
+                assert abs(f["value"] - w["batch"] * 1e3 / f["ms_per_step"]) < 1e-6 * f["value"], (path, k)
