@@ -698,7 +698,7 @@ def mpc_alg_bytes(N, nx, nu, nc):
     return data + 8 * (nz + nl + nv) + 8 * (nz + nl + 2 * nv) + 40
 
 
-def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=16):
+def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=48):
     """The row-pair record instances (stage widths 17..32), one launch at a time, device pointers
     (the kernel furthest below its roofline had no driver number):
       ltv_30_20_6_16   2048 random time-varying QPs of (N, nx, nu, nc) = (30, 20, 6, 16) - 64 distinct problems

@@ -2,7 +2,7 @@
 """Developer tool (GPU box): the bench line's `wide` workloads as a STREAM of batches - P launches in flight on P streams
 (the headline's regime) beside one launch at a time.  Do launches of the row-pair instances share the chip?  (The
 <24,8,*> kernels allocate 512 registers through their noinline sweeps: LABNOTES R6.3.)
-usage: tools/wide_in_flight.py [steps]"""
+usage: tools/wide_in_flight.py [steps [lanes:share,...]]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -63,7 +63,10 @@ for name in ("ltv_30_20_6_16", "reactor_N80"):
     data = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in p.arrays.items()}
     v1, nm, ok, w1 = run(p, data, 1, max(steps // 2, 3), 1)
     print(f"{name:16s} one at a time            {v1:9.0f} QP/s  ({w1} workgroups)  newton mean {nm:.3f} ok={ok}", flush=True)
-    for lanes_n, share in ((2, 1), (2, 2), (4, 2), (4, 4), (8, 8)):
+    combos = ((2, 1), (2, 2), (4, 2), (4, 4), (8, 8))
+    if len(sys.argv) > 2:  # "lanes:share,lanes:share,..."
+        combos = tuple(tuple(int(x) for x in c.split(":")) for c in sys.argv[2].split(","))
+    for lanes_n, share in combos:
         v, nm, ok, w = run(p, data, lanes_n, steps, share)
         print(f"{name:16s} {lanes_n} in flight, share {share}    {v:9.0f} QP/s  ({w} workgroups each)  ok={ok}", flush=True)
     del data
