@@ -707,9 +707,10 @@ def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=48):
                        (fbstab/test/ocp_generator.cc:73-174; tools/reactor_bench.py) on <18,5,10>.
     `roofline`: the shape's own algorithmic bytes over the launch's duration against the HBM peak.
     `value` is ONE launch at a time; `in_flight` is the same batch as a stream, `in_flight` launches on as many
-    streams (the headline's regime), `stream_steps` timed launches after one untimed launch per lane."""
+    streams (the headline's regime), `stream_steps` timed launches after one untimed launch per lane;
+    `in_flight.handles_in_flight` is what each lane's handle was created with (1: it keeps the whole grid)."""
     out = {}
-    def run(name, p, what):
+    def run(name, p, what, share):
         N, nx, nu, nc = p.sizes()
         B = p.batch
         s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
@@ -737,7 +738,7 @@ def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=48):
         # (tools/wide_in_flight.py; a stream of batches fills the tail one launch leaves: LABNOTES R6.11)
         lanes = []
         for _ in range(in_flight):
-            h = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B, handles_in_flight=in_flight)
+            h = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B, handles_in_flight=share)
             lanes.append(dict(s=h, st=torch.cuda.Stream(device=dev), z=mk(p.nz), l=mk(p.nl), v=mk(p.nv), y=mk(p.nv),
                               out=torch.zeros((B, 40), dtype=torch.uint8, device=dev)))
         def step(k):
@@ -756,7 +757,7 @@ def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=48):
         dt = time.perf_counter() - t0
         oo = [hip_api.out_to_numpy(ln["out"]) for ln in lanes]
         out[name]["in_flight"] = {"value": B * stream_steps / dt, "unit": "QPs/sec", "steps": stream_steps,
-                                  "steps_in_flight": in_flight, "ms_per_step": 1e3 * dt / stream_steps,
+                                  "steps_in_flight": in_flight, "handles_in_flight": share, "ms_per_step": 1e3 * dt / stream_steps,
                                   "workgroups_per_launch": lanes[0]["s"].query()["workgroups"],
                                   "mean_newton_iters": float(np.mean([x["newton_iters"].mean() for x in oo])),
                                   "all_converged": bool(all((x["eflag"] == 0).all() for x in oo))}
@@ -768,7 +769,9 @@ def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=48):
     one = fx.random_ltv_mpc(np.random.default_rng(5), 64, 30, 20, 6, 16)
     p = fx.MpcProblem(30, 20, 6, 16)
     p.arrays = {k: np.ascontiguousarray(np.tile(a, (32, 1))) for k, a in one.arrays.items()}
-    run("ltv_30_20_6_16", p, "2048 random time-varying QPs (64 distinct, tiled), N=30 nx=20 nu=6 nc=16, dense constraint rows, cold start")
+    # (the grid each lane's handle takes - fbstab_hip_mpc_create_in_flight's `handles_in_flight` - is the better of 1 and
+    # `in_flight` per workload, LABNOTES R6.11: whole-grid launches for <24,8,16>, an eighth of the grid for <18,5,10>)
+    run("ltv_30_20_6_16", p, "2048 random time-varying QPs (64 distinct, tiled), N=30 nx=20 nu=6 nc=16, dense constraint rows, cold start", 1)
     gen = fx.OcpGenerator()
     gen.CopolymerizationReactor(80)
     one = gen.GetFBstabInput()
@@ -778,7 +781,7 @@ def bench_wide(torch, dev, fx, hip_api, reps=3, in_flight=8, stream_steps=48):
     p = fx.MpcProblem(N, nx, nu, nc)
     p.arrays = {k: np.ascontiguousarray(np.broadcast_to(a, (B, a.shape[1]))).copy() for k, a in one.arrays.items()}
     p.arrays["x0"] = p.arrays["x0"] * (1.0 + 0.2 * rng.standard_normal((B, nx)))
-    run("reactor_N80", p, "1024 CopolymerizationReactor problems (the reference's, N=80 nx=18 nu=5 nc=10), x0 perturbed by 20 %, cold start")
+    run("reactor_N80", p, "1024 CopolymerizationReactor problems (the reference's, N=80 nx=18 nu=5 nc=10), x0 perturbed by 20 %, cold start", in_flight)
     return out
 
 

@@ -150,6 +150,12 @@ struct MpcR16 {
   static constexpr int kXl = 0, kPl = LPQ * nXs, kDump = kPl + LPQ * nPs;
   static constexpr int TS = (kDump + 16 + LPQ - 1) / LPQ;  // LPQ * TS doubles hold them
   static constexpr int kPackLdsSlots = pABc;        // K, C, [A B] rows
+  static constexpr int kLdsDoubles = LPQ * (CS > TS ? CS : TS);  // a QP's own region: transpose buffer / triangle images
+  // region stride: 16 doubles mod 32 (bank placement of neighbouring QPs) and at least
+  // 24 spare doubles behind the images for the solver loop's parked scalars
+  static constexpr int kLdsBase = ((kLdsDoubles + 31) & ~31) + 16;
+  static constexpr int kLdsPerRow = kLdsBase - kLdsDoubles >= 24 ? kLdsBase : kLdsBase + 32;
+  static constexpr int kLdsPerRow_(int) { return kLdsPerRow; }
   static constexpr bool kPackInLds = true;
   static constexpr int kPackLds = kPackInLds ? LPQ * kPackLdsSlots : 0;  // doubles of one QP's image
   // The images of a wavefront's QPs share ONE area in front of the QPs' own regions, interleaved pair by
@@ -173,15 +179,41 @@ struct MpcR16 {
 #endif
   static constexpr bool kAbcFromLds = FB_R16_ABC_FROM_LDS != 0 && FB_R16_PACK_DMA == 0 && kPackInLds;
   static constexpr int kPackPair = kAbcFromLds ? 2 * LPQ + 2 : 2 * LPQ * kQpPerWave;  // doubles between consecutive slot pairs of a QP's image
-  static constexpr int kPackQp = kAbcFromLds ? (kPackLdsSlots / 2) * kPackPair : 2 * LPQ;  // doubles between the images of two QPs
+  // The rows of [A B] are NX: lanes r >= NX hold zeros in those slot pairs (and the sweeps rely on reading them:
+  // W, Pi+ and T come out zero there without a select).  Where it buys a workgroup per CU the pairs of [A B] are
+  // therefore TRIMMED (FB_R16_TRIM_AB, round 6): 2 NX + 2 doubles apart, lanes r < NX at + 2 r and the two
+  // doubles of padding - kept zero: every lane r >= NX stores its zeros there and reads them back from there -
+  // at + 2 NX.  <24,8,16>: 57,600 -> 53,504 bytes (N = 30), three workgroups per CU (160 KB) instead of two; the column
+  // reads of the backward sweep stay conflict-free (pair stride 50 doubles: 100 dwords = 36 mod 64, sixteen
+  // lane pairs on sixteen different bank quads).  Row-pair instances only, and only where a workgroup is gained:
+  // <24,8,32> stays at two, <18,5,10> has its four - no other instance's code changes.
+#ifndef FB_R16_TRIM_AB
+#define FB_R16_TRIM_AB 1
+#endif
+  static constexpr int kAbPairTrim = 2 * NX + 2;
+  static constexpr int pack_qp(int ab_pair) { return (pABr / 2) * kPackPair + (NSP / 2) * ab_pair; }
+  static constexpr int wgs_per_cu(int pack_qp_doubles) {  // by LDS (160 KB a CU), at most the four SIMDs' one wavefront each
+    const int per = 163840 / ((kQpPerWave * (pack_qp_doubles + kLdsPerRow_(0))) * 8 + 512);  // (+ the offset tables: 8 (N + 1) bytes a QP)
+    return per > 4 ? 4 : per;
+  }
+  static constexpr bool kTrimAb = FB_R16_TRIM_AB != 0 && kAbcFromLds && RQ == 2 && NX < LPQ &&
+                                  wgs_per_cu(pack_qp(kAbPairTrim)) > wgs_per_cu(pack_qp(kPackPair));
+  static constexpr int kAbPair = kTrimAb ? kAbPairTrim : kPackPair;  // doubles between consecutive slot pairs of [A B]'s rows
+  // where slot pair `pr` of a QP's image starts, in doubles
+  static constexpr int pair_at(int pr) { return pr < pABr / 2 ? pr * kPackPair : (pABr / 2) * kPackPair + (pr - pABr / 2) * kAbPair; }
+  // this lane's place in the pairs of [A B] relative to its place in the others (+ 2 r): lanes r >= NX share the padding
+  static FB_DEV int ab_lane_shift() {
+    if constexpr (kTrimAb) {
+      const int r = threadIdx.x & (LPQ - 1);
+      return r > NX ? 2 * (NX - r) : 0;
+    } else {
+      return 0;
+    }
+  }
+  static constexpr int kPackQp = kAbcFromLds ? pack_qp(kAbPair) : 2 * LPQ;  // doubles between the images of two QPs
   static constexpr int kPackArea = kAbcFromLds ? kQpPerWave * kPackQp : kQpPerWave * kPackLds;  // doubles of the wavefront's area
   // this lane's view of the matrix copy in use
   typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
-  static constexpr int kLdsDoubles = LPQ * (CS > TS ? CS : TS);  // a QP's own region: transpose buffer / triangle images
-  // region stride: 16 doubles mod 32 (bank placement of neighbouring QPs) and at least
-  // 24 spare doubles behind the images for the solver loop's parked scalars
-  static constexpr int kLdsBase = ((kLdsDoubles + 31) & ~31) + 16;
-  static constexpr int kLdsPerRow = kLdsBase - kLdsDoubles >= 24 ? kLdsBase : kLdsBase + 32;
 
 
   // ---- the triangle images in LDS, hand-scheduled (instance <12,4,20>, one row per QP) ----
@@ -518,6 +550,7 @@ struct MpcR16 {
     lds_ptr dst = view;
     const double* src = pack0 + off;
     c.sync();  // earlier readers of the previous copy
+    [[maybe_unused]] const int ab = ab_lane_shift();
     constexpr int kPairs = kPackLdsSlots / 2, kChunk = 13;
     sfor<0, (kPairs + kChunk - 1) / kChunk>([&](auto Ch) {
       constexpr int c0 = decltype(Ch)::value * kChunk;
@@ -525,7 +558,9 @@ struct MpcR16 {
       dbl2 t[kChunk];
       sfor<0, cn>([&](auto I) { t[decltype(I)::value] = *reinterpret_cast<const dbl2*>(src + (c0 + decltype(I)::value) * 2 * LPQ); });
       sfor<0, cn>([&](auto I) {
-        *reinterpret_cast<FB_LDS dbl2*>(dst + (c0 + decltype(I)::value) * kPackPair) = t[decltype(I)::value];
+        constexpr int pr = c0 + decltype(I)::value;
+        // (kTrimAb: in the pairs of [A B] the lanes r >= NX - zeros in the matrix copy - all store to the padding)
+        *reinterpret_cast<FB_LDS dbl2*>(dst + pair_at(pr) + (pr >= pABr / 2 ? ab : 0)) = t[decltype(I)::value];
       });
     });
     c.sync();
@@ -571,9 +606,11 @@ struct MpcR16 {
   template <int S0, int CNT, int NOUT>
   static FB_DEV void ldl(lds_ptr L, double (&out)[NOUT]) {
     static_assert((S0 & 1) == 0 && S0 + CNT <= kPackLdsSlots, "inside the LDS image, on a pair");
+    static_assert(S0 >= pABr || S0 + CNT <= pABr, "a range lies on one side of the first [A B] pair");
+    if constexpr (kTrimAb && S0 >= pABr) L += ab_lane_shift();
     sfor<0, (CNT + 1) / 2>([&](auto P_) {
       constexpr int pr = decltype(P_)::value;
-      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + (S0 / 2 + pr) * kPackPair);
+      const dbl2 t = *reinterpret_cast<FB_LDS const dbl2*>(L + pair_at(S0 / 2 + pr));
       out[2 * pr] = t[0];
       if constexpr (2 * pr + 1 < CNT) out[2 * pr + 1] = t[1];
     });
@@ -2715,7 +2752,8 @@ struct MpcR16 {
     // (lanes without a row or column - NS < LPQ: the <18,5,10> instance - have no such slot: they read lane 0's
     // and get the zero the column slots of the matrix copy hold for them)
     const int rcol = (NS < LPQ && r >= NS) ? 0 : r;
-    [[maybe_unused]] const lds_ptr abcol = Lp - 2 * r + ((pABr + rcol) >> 1) * kPackPair + ((pABr + rcol) & 1);
+    [[maybe_unused]] const lds_ptr abcol = kTrimAb ? Lp - 2 * r + (pABr / 2) * kPackPair + (rcol >> 1) * kAbPair + (rcol & 1)
+                                                    : Lp - 2 * r + ((pABr + rcol) >> 1) * kPackPair + ((pABr + rcol) & 1);
     for (int i = N_; i >= 0; i--) {
       FB_PHASE(bwd_top);
       double* R = R0 + (long)i * kRec;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: random MPC shapes over every record instance (and the flat-vector
 kernel) against the oracle: exit flags, proximal counts equal; Newton counts equal on
-all but a few.  argv: number of shapes [seed] [r16] [bounds | sparse] [warm].  With `bounds` the constraints are bounds on single stage
+all but a few.  argv: number of shapes [seed] [r16] [bounds | sparse] [warm] [only=<part of a kernel name>].  With `bounds` the constraints are bounds on single stage
 variables (fixtures.random_ltv_mpc_bounds).  With `r16` every shape is drawn inside the
 headline instance <12,4,20> (nx <= 12, nu <= 4, nc <= 20); a shape is flagged ("CHECK") as soon as ANY
 count differs from the oracle's (strict), otherwise when flags / proximal counts differ, a Newton
@@ -22,6 +22,7 @@ r16 = len(sys.argv) > 3 and "r16" in sys.argv[3:]
 bounds = "bounds" in sys.argv[3:]  # bound constraints (one +-1 entry per row): the row form of the costate step
 sparse = "sparse" in sys.argv[3:]  # two or three entries of order one per row: the row form without the bounds' shortcut
 warm = "warm" in sys.argv[3:]      # a second, warm-started solve per shape (teacher-forced: the oracle gets the device's guess)
+only = next((a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("only=")), None)  # only shapes whose kernel name contains this (the streams stay as they are)
 strict = r16 or os.environ.get("FUZZ_STRICT", "1") != "0"
 nqp = nref = 0
 nwarm = warm_flips = warm_bad = warm_loose = warm_fma_agrees = warm_refine_closes = 0
@@ -40,6 +41,11 @@ for it in range(n):
     p = (fx.random_ltv_mpc_bounds(rng, B, N, nx, nu, nc) if bounds else
          fx.random_ltv_mpc_sparse_rows(rng, B, N, nx, nu, nc) if sparse else fx.random_ltv_mpc(rng, B, N, nx, nu, nc))
     s = hip_api.FBstabMpcBatch(N, nx, nu, nc, max_batch=B)
+    if only is not None and only not in s.kernel_name():
+        s.close()
+        if warm:  # (the warm family's own stream moves on as if the shape had been solved)
+            wrng.standard_normal(p.arrays["x0"].shape); wrng.standard_normal(p.arrays["x0"].shape)
+        continue
     h = hip_api.Options()
     for name, _ in h._fields_:
         setattr(h, name, getattr(o, name))
