@@ -1297,6 +1297,27 @@ def test_stage_widths_up_to_32_run_on_the_general_two_row_instances(hip, oracle,
     _assert_parity(gpu, cpu, o.abs_tol)
 
 
+def test_the_wide_bench_shape_matches_the_oracle_and_gets_three_workgroups_per_cu(hip, oracle):
+    """bench.py's `wide.ltv_30_20_6_16` workload (N = 30, the first 24 of its 64 distinct problems) on <24,8,16>,
+    strict against the oracle - and the launch geometry round 6 bought: the rows of [A B] trimmed in the LDS image
+    (fb_mpc_r16.h, kTrimAb: lanes r >= nx share a zero pad) take the workgroup from 57.6 to 53.5 KB, three per CU
+    instead of two (LABNOTES R6.12)."""
+    one = fx.random_ltv_mpc(np.random.default_rng(5), 64, 30, 20, 6, 16)
+    p = fx.MpcProblem(30, 20, 6, 16)
+    p.arrays = {k: np.ascontiguousarray(a[:24]) for k, a in one.arrays.items()}
+    o = default_options()
+    gpu = _solve_mpc_host(hip, p, o)
+    cpu = oracle.solve_mpc(p, opts=o, nthreads=oracle.num_threads())
+    _assert_parity(gpu, cpu, o.abs_tol)
+    assert (cpu[4]["eflag"] == 0).all()
+    s = hip.FBstabMpcBatch(30, 20, 6, 16, max_batch=2048)
+    q = s.query()
+    name = s.kernel_name()
+    s.close()
+    assert name == "fbstab_mpc_r32_kernel<24,8,16>"
+    assert q["lds_bytes"] * 3 <= 160 * 1024 and q["workgroups"] % 3 == 0 and q["workgroups"] >= 3 * 256, q
+
+
 @pytest.mark.parametrize("shape", [(50, 10, 100), (20, 5, 40), (30, 20, 64), (64, 0, 128)])
 def test_dense_newton_step_matches_oracle(hip, oracle, shape):
     """One Newton step of the dense device path (K assembly on the matrix cores,
