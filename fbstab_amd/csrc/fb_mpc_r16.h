@@ -155,7 +155,6 @@ struct MpcR16 {
   // 24 spare doubles behind the images for the solver loop's parked scalars
   static constexpr int kLdsBase = ((kLdsDoubles + 31) & ~31) + 16;
   static constexpr int kLdsPerRow = kLdsBase - kLdsDoubles >= 24 ? kLdsBase : kLdsBase + 32;
-  static constexpr int kLdsPerRow_(int) { return kLdsPerRow; }
   static constexpr bool kPackInLds = true;
   static constexpr int kPackLds = kPackInLds ? LPQ * kPackLdsSlots : 0;  // doubles of one QP's image
   // The images of a wavefront's QPs share ONE area in front of the QPs' own regions, interleaved pair by
@@ -193,7 +192,7 @@ struct MpcR16 {
   static constexpr int kAbPairTrim = 2 * NX + 2;
   static constexpr int pack_qp(int ab_pair) { return (pABr / 2) * kPackPair + (NSP / 2) * ab_pair; }
   static constexpr int wgs_per_cu(int pack_qp_doubles) {  // by LDS (160 KB a CU), at most the four SIMDs' one wavefront each
-    const int per = 163840 / ((kQpPerWave * (pack_qp_doubles + kLdsPerRow_(0))) * 8 + 512);  // (+ the offset tables: 8 (N + 1) bytes a QP)
+    const int per = 163840 / ((kQpPerWave * (pack_qp_doubles + kLdsPerRow)) * 8 + 512);  // (+ the offset tables: 8 (N + 1) bytes a QP)
     return per > 4 ? 4 : per;
   }
   static constexpr bool kTrimAb = FB_R16_TRIM_AB != 0 && kAbcFromLds && RQ == 2 && NX < LPQ &&
