@@ -198,8 +198,21 @@ struct MpcR16 {
   static constexpr bool kTrimAb = FB_R16_TRIM_AB != 0 && kAbcFromLds && RQ == 2 && NX < LPQ &&
                                   wgs_per_cu(pack_qp(kAbPairTrim)) > wgs_per_cu(pack_qp(kPackPair));
   static constexpr int kAbPair = kTrimAb ? kAbPairTrim : kPackPair;  // doubles between consecutive slot pairs of [A B]'s rows
+  // ... and where leaving the rows of K = [Q S'; S R] OUT of the image buys another workgroup they are read from the
+  // matrix copy in memory instead (FB_R16_K_FROM_MEMORY, round 6: the `if constexpr (kKinLds)` at the five places K is read).  A sweep stages a stage's copy once and
+  // reads K from it once, so a plant whose matrices change with the stage moves the same bytes either way, and a
+  // time-invariant one finds its few copies in L2.  <24,8,16>: 53,504 -> 36,608 bytes, FOUR workgroups per CU - every
+  // SIMD; <24,8,32>: 68,032 -> 51,712, three instead of two.
+#ifndef FB_R16_K_FROM_MEMORY
+#define FB_R16_K_FROM_MEMORY 1
+#endif
+  static constexpr bool kKinLds = !(FB_R16_K_FROM_MEMORY != 0 && kAbcFromLds && RQ == 2 &&
+                                    wgs_per_cu(pack_qp(kAbPair) - (pC / 2) * kPackPair) > wgs_per_cu(pack_qp(kAbPair)));
+  static constexpr int kLdsFirstPair = kKinLds ? 0 : pC / 2;  // the image starts with this slot pair of the matrix copy
   // where slot pair `pr` of a QP's image starts, in doubles
-  static constexpr int pair_at(int pr) { return pr < pABr / 2 ? pr * kPackPair : (pABr / 2) * kPackPair + (pr - pABr / 2) * kAbPair; }
+  static constexpr int pair_at(int pr) {
+    return pr < pABr / 2 ? (pr - kLdsFirstPair) * kPackPair : (pABr / 2 - kLdsFirstPair) * kPackPair + (pr - pABr / 2) * kAbPair;
+  }
   // this lane's place in the pairs of [A B] relative to its place in the others (+ 2 r): lanes r >= NX share the padding
   static FB_DEV int ab_lane_shift() {
     if constexpr (kTrimAb) {
@@ -209,7 +222,7 @@ struct MpcR16 {
       return 0;
     }
   }
-  static constexpr int kPackQp = kAbcFromLds ? pack_qp(kAbPair) : 2 * LPQ;  // doubles between the images of two QPs
+  static constexpr int kPackQp = kAbcFromLds ? pack_qp(kAbPair) - kLdsFirstPair * kPackPair : 2 * LPQ;  // doubles between the images of two QPs
   static constexpr int kPackArea = kAbcFromLds ? kQpPerWave * kPackQp : kQpPerWave * kPackLds;  // doubles of the wavefront's area
   // this lane's view of the matrix copy in use
   typedef typename std::conditional<kPackInLds, lds_ptr, const double*>::type pk_ptr;
@@ -551,8 +564,8 @@ struct MpcR16 {
     c.sync();  // earlier readers of the previous copy
     [[maybe_unused]] const int ab = ab_lane_shift();
     constexpr int kPairs = kPackLdsSlots / 2, kChunk = 13;
-    sfor<0, (kPairs + kChunk - 1) / kChunk>([&](auto Ch) {
-      constexpr int c0 = decltype(Ch)::value * kChunk;
+    sfor<0, (kPairs - kLdsFirstPair + kChunk - 1) / kChunk>([&](auto Ch) {
+      constexpr int c0 = kLdsFirstPair + decltype(Ch)::value * kChunk;
       constexpr int cn = c0 + kChunk < kPairs ? kChunk : kPairs - c0;
       dbl2 t[kChunk];
       sfor<0, cn>([&](auto I) { t[decltype(I)::value] = *reinterpret_cast<const dbl2*>(src + (c0 + decltype(I)::value) * 2 * LPQ); });
@@ -606,6 +619,7 @@ struct MpcR16 {
   static FB_DEV void ldl(lds_ptr L, double (&out)[NOUT]) {
     static_assert((S0 & 1) == 0 && S0 + CNT <= kPackLdsSlots, "inside the LDS image, on a pair");
     static_assert(S0 >= pABr || S0 + CNT <= pABr, "a range lies on one side of the first [A B] pair");
+    static_assert(S0 / 2 >= kLdsFirstPair, "the rows of K are not in this instance's image");
     if constexpr (kTrimAb && S0 >= pABr) L += ab_lane_shift();
     sfor<0, (CNT + 1) / 2>([&](auto P_) {
       constexpr int pr = decltype(P_)::value;
@@ -890,7 +904,8 @@ struct MpcR16 {
       const int pofs = po[i];
       stage_pack(c, Lp, pofs);
       double Kr[NS], Cc[NC], ABr[NS], ABc[NX];
-      ldl<pK, NS>(Lp, Kr);
+      if constexpr (kKinLds) ldl<pK, NS>(Lp, Kr);
+      else ldv<pK, NS>(P0 + pofs, Kr);  // (K = [Q S'; S R] is not in this instance's image)
       ldl<pC, NC>(Lp, Cc);
       ldl<pABr, NS>(Lp, ABr);
       ldv<pABc, NX>(P0 + pofs, ABc);
@@ -1407,7 +1422,8 @@ struct MpcR16 {
       if (check) {
         stage_pack(c, Lp, po[i]);
         double Kr[NS], Cc[NC], ABr[NS];
-        ldl<pK, NS>(Lp, Kr);
+        if constexpr (kKinLds) ldl<pK, NS>(Lp, Kr);
+        else ldv<pK, NS>(pack + po[i], Kr);
         ldl<pC, NC>(Lp, Cc);
         ldl<pABr, NS>(Lp, ABr);
         const dbl2 fh = vc.fh;
@@ -1508,7 +1524,8 @@ struct MpcR16 {
       if (i < N_) load_o(i + 1, oin);
       stage_pack(c, Lp, po[i]);
       double Kr[NS], Cc[NC], ABr[NS];
-      ldl<pK, NS>(Lp, Kr);
+      if constexpr (kKinLds) ldl<pK, NS>(Lp, Kr);
+      else ldv<pK, NS>(pack + po[i], Kr);
       ldl<pC, NC>(Lp, Cc);
       ldl<pABr, NS>(Lp, ABr);
       const double (&ABc)[NX] = oc.ABc;
@@ -2453,7 +2470,8 @@ struct MpcR16 {
       asm volatile("" : "+v"(ro));
       double Cc_[NC], K[NS];
       ldl<pC, NC>(Lp, Cc_);
-      ldl<pK, NS>(Lp, K);
+      if constexpr (kKinLds) ldl<pK, NS>(Lp, K);
+      else ldv<pK, NS>(P0 + loff, K);  // (the copy resident in LDS, in memory)
       // ---- pending step (tp = 0: no-op), PFB gradient (riccati_linear_solver.cc:91-99)
       double Gam[KS], Rvm[KS];
       sfor<0, KS>([&](auto S_) {
@@ -2751,8 +2769,8 @@ struct MpcR16 {
     // (lanes without a row or column - NS < LPQ: the <18,5,10> instance - have no such slot: they read lane 0's
     // and get the zero the column slots of the matrix copy hold for them)
     const int rcol = (NS < LPQ && r >= NS) ? 0 : r;
-    [[maybe_unused]] const lds_ptr abcol = kTrimAb ? Lp - 2 * r + (pABr / 2) * kPackPair + (rcol >> 1) * kAbPair + (rcol & 1)
-                                                    : Lp - 2 * r + ((pABr + rcol) >> 1) * kPackPair + ((pABr + rcol) & 1);
+    [[maybe_unused]] const lds_ptr abcol = (kTrimAb || !kKinLds) ? Lp - 2 * r + pair_at(pABr / 2) + (rcol >> 1) * kAbPair + (rcol & 1)
+                                                                 : Lp - 2 * r + ((pABr + rcol) >> 1) * kPackPair + ((pABr + rcol) & 1);
     for (int i = N_; i >= 0; i--) {
       FB_PHASE(bwd_top);
       double* R = R0 + (long)i * kRec;
@@ -2860,7 +2878,8 @@ struct MpcR16 {
       // it in every lane - bc_all, 16 moves - and plain dot products; bitwise the same sums)
       [[maybe_unused]] double dzb[NS];
       if constexpr (!kBwdFusedBc) bc_all<NS, RQ>(dzu, dzb);
-      ldl<pK, NS>(Lp, Hr);
+      if constexpr (kKinLds) ldl<pK, NS>(Lp, Hr);
+      else ldv<pK, NS>(P0 + loff, Hr);
       ldl<pABr, NS>(Lp, AB);
       if constexpr (kPackDma) {
         // (pcur is the stage below's already) its copy on its way while this stage finishes

@@ -1297,11 +1297,12 @@ def test_stage_widths_up_to_32_run_on_the_general_two_row_instances(hip, oracle,
     _assert_parity(gpu, cpu, o.abs_tol)
 
 
-def test_the_wide_bench_shape_matches_the_oracle_and_gets_three_workgroups_per_cu(hip, oracle):
+def test_the_wide_bench_shape_matches_the_oracle_and_fills_every_simd(hip, oracle):
     """bench.py's `wide.ltv_30_20_6_16` workload (N = 30, the first 24 of its 64 distinct problems) on <24,8,16>,
-    strict against the oracle - and the launch geometry round 6 bought: the rows of [A B] trimmed in the LDS image
-    (fb_mpc_r16.h, kTrimAb: lanes r >= nx share a zero pad) take the workgroup from 57.6 to 53.5 KB, three per CU
-    instead of two (LABNOTES R6.12)."""
+    strict against the oracle - and the launch geometry round 6 bought: the kernel ran TWO workgroups per CU for its
+    57.6 KB of LDS; with the rows of [A B] trimmed in the image (fb_mpc_r16.h, kTrimAb: lanes r >= nx share a zero pad)
+    and the rows of K read from the matrix copy in memory (kKinLds false) it takes 36.6 KB: four, one per SIMD
+    (LABNOTES R6.12)."""
     one = fx.random_ltv_mpc(np.random.default_rng(5), 64, 30, 20, 6, 16)
     p = fx.MpcProblem(30, 20, 6, 16)
     p.arrays = {k: np.ascontiguousarray(a[:24]) for k, a in one.arrays.items()}
@@ -1315,7 +1316,7 @@ def test_the_wide_bench_shape_matches_the_oracle_and_gets_three_workgroups_per_c
     name = s.kernel_name()
     s.close()
     assert name == "fbstab_mpc_r32_kernel<24,8,16>"
-    assert q["lds_bytes"] * 3 <= 160 * 1024 and q["workgroups"] % 3 == 0 and q["workgroups"] >= 3 * 256, q
+    assert q["lds_bytes"] * 4 <= 160 * 1024 and q["workgroups"] % 4 == 0 and q["workgroups"] >= 4 * 256, q
 
 
 @pytest.mark.parametrize("shape", [(50, 10, 100), (20, 5, 40), (30, 20, 64), (64, 0, 128)])
