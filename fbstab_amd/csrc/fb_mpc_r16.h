@@ -202,7 +202,7 @@ struct MpcR16 {
   // matrix copy in memory instead (FB_R16_K_FROM_MEMORY, round 6: the `if constexpr (kKinLds)` at the five places K is read).  A sweep stages a stage's copy once and
   // reads K from it once, so a plant whose matrices change with the stage moves the same bytes either way, and a
   // time-invariant one finds its few copies in L2.  <24,8,16>: 53,504 -> 36,608 bytes, FOUR workgroups per CU - every
-  // SIMD; <24,8,32>: 68,032 -> 51,712, three instead of two.
+  // SIMD; <24,8,32>: 68,608 -> 51,712, three instead of two.
 #ifndef FB_R16_K_FROM_MEMORY
 #define FB_R16_K_FROM_MEMORY 1
 #endif

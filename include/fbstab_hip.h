@@ -141,8 +141,8 @@ int fbstab_hip_mpc_create(int N, int nx, int nu, int nc, int max_batch, int devi
  * fbstab_hip_mpc_query reports the handle's `workgroups` and `scratch_bytes` as created, so a caller can see
  * the share it got.  Values outside 1..64 are refused (FBSTAB_HIP_ERR_ARGUMENT).
  * The share is a hint measured on the BASELINE shape.  Shapes of the widest record instance (stage width up
- * to 32 with up to 16 constraint rows: three workgroups per CU by LDS) did better as a stream of batches with
- * every handle keeping the whole grid (handles_in_flight = 1 on each of eight handles: 22 k against 19 k
+ * to 32 with up to 16 constraint rows) did better as a stream of batches with
+ * every handle keeping the whole grid (handles_in_flight = 1 on each of eight handles: 28 k against 24 k
  * QPs/sec on (30,20,6,16)) - measure both on a new shape. */
 int fbstab_hip_mpc_create_in_flight(int N, int nx, int nu, int nc, int max_batch, int device,
                                     int handles_in_flight, fbstab_mpc_handle_t* handle);
